@@ -1,0 +1,158 @@
+/*
+ * telescope_em.h — C ABI of libtelescope_em.so, the MI355X (gfx950) engine for
+ * Telescope's EM reassignment path.
+ *
+ * The reference has no FFI layer: its boundary is the Python class
+ * `TelescopeLikelihood` (telescope/utils/model.py:631-865) on top of
+ * `csr_matrix_plus` (telescope/utils/sparse_plus.py:24-174) and scipy.sparse.
+ * Each entry point below names the reference code it replaces.  The Python
+ * host mirror (telescope_amd/likelihood.py) binds these with ctypes; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, opaque handle, `int` status (0 = TSEM_OK, <0 = error; text via
+ *     tsem_last_error).  No exceptions or abort() cross the boundary.
+ *   - one handle == one GPU == one host thread (not thread-safe).  Multi-GPU is
+ *     one process per GPU; the only per-iteration exchange is a sum all-reduce
+ *     of the reduce buffer (K+2 doubles), done by the host over RCCL between
+ *     tsem_em_pass() and tsem_em_update().
+ *   - host pointers are borrowed for the duration of the call; the library owns
+ *     all device memory except a reduce buffer bound with
+ *     tsem_bind_reduce_buffer().
+ *   - there is no CPU fallback: tsem_create fails if no HIP device is usable.
+ */
+#ifndef TELESCOPE_EM_H
+#define TELESCOPE_EM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSEM_OK            0
+#define TSEM_ERR_ARG      -1   /* bad argument / wrong state              */
+#define TSEM_ERR_HIP      -2   /* HIP runtime error (text in last_error)  */
+#define TSEM_ERR_NOMEM    -3
+#define TSEM_ERR_TIMEOUT  -4   /* in-kernel hand-off watchdog fired       */
+
+/* reassign methods, model.py:808-865 */
+#define TSEM_RA_EXCLUDE 0
+#define TSEM_RA_CHOOSE  1
+#define TSEM_RA_AVERAGE 2
+#define TSEM_RA_CONF    3
+#define TSEM_RA_UNIQUE  4
+#define TSEM_RA_ALL     5
+
+/* which parameters define z: */
+#define TSEM_Z_PREV     0   /* params before the last M-step == reference self.z (model.py:795) */
+#define TSEM_Z_CUR      1   /* current params */
+#define TSEM_Z_INITIAL  2   /* Q.norm(1), model.py:837 (initial=True)      */
+
+/* EM kernel selection (tsem_set_option "em_kernel") */
+#define TSEM_EMK_AUTO     0
+#define TSEM_EMK_TWOPASS  1   /* phase kernels, entries read twice                 */
+#define TSEM_EMK_FUSED    2   /* persistent single-pass kernel with row-sum exchange */
+
+typedef struct tsem_ctx tsem_ctx;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int  tsem_create(tsem_ctx** out, int device);
+void tsem_destroy(tsem_ctx* h);
+const char* tsem_last_error(const tsem_ctx* h);      /* h may be NULL: last create error */
+int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream_t (default: null stream) */
+int  tsem_set_option(tsem_ctx* h, const char* key, int64_t value);
+int  tsem_synchronize(tsem_ctx* h);
+
+/* ---- score matrix (model.py:638-653; sparse_plus.py:89-91) ---------------
+ * CSR of uint16 raw scores for the rows this rank owns.  `lut[r]` is
+ * Q = expm1((r * (1/max_score)) * 100.) for r = 0..lut_len-1, computed by the
+ * host with the reference's numpy expression so Q is bit-identical; max_score
+ * is the GLOBAL maximum (all ranks).  */
+int  tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols,
+                      const int64_t* indptr, const int32_t* indices,
+                      const uint16_t* raw, const double* lut, int32_t lut_len);
+/* Generate rows [row_begin,row_end) of the synthetic matrix on the device
+ * (telescope_amd/synthetic.py is the bit-exact CPU twin).  `len_cdf` is
+ * synthetic.poisson_cdf_u32(mean).  dist: 0 uniform, 1 zipf.  */
+int  tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_cols,
+                   const uint32_t* len_cdf, int32_t cdf_len, uint64_t seed,
+                   int32_t dist, double uniq_frac, const double* lut, int32_t lut_len);
+int  tsem_dims(tsem_ctx* h, int64_t* n_rows, int32_t* n_cols, int64_t* nnz);
+/* copy the CSR back to the host (tests of the generator) */
+int  tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* raw);
+
+/* ---- model setup (model.py:679-699) --------------------------------------
+ * tsem_rowstats: Y, weights w_i = max_j Q_ij, and the LOCAL sums
+ *   stats[0]=sum w, stats[1]=sum w*Y, stats[2]=max w, pisum0[K] = sum of Q over
+ *   unique rows per column.  Multi-GPU hosts all-reduce them (sum,sum,max,sum).
+ * tsem_set_model: global stats + priors; builds the column-partitioned EM
+ *   layout and resets pi = theta = 1/K (model.py:667,673).  */
+int  tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0);
+int  tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0,
+                    double pi_prior, double theta_prior);
+
+/* ---- parameters ---------------------------------------------------------- */
+int  tsem_set_params(tsem_ctx* h, const double* pi, const double* theta);
+int  tsem_get_params(tsem_ctx* h, int which /*TSEM_Z_PREV|TSEM_Z_CUR*/, double* pi, double* theta);
+
+/* ---- EM iteration (estep model.py:702-722 + mstep 724-742, fused) ---------
+ * tsem_em_pass: local fused E+M over this rank's rows with the current
+ *   params; leaves red[0..K) = local thetasum, red[K] = 0, red[K+1] = 0 in the
+ *   reduce buffer (device).  Asynchronous.
+ * tsem_em_update: consumes the (all-reduced) reduce buffer: theta_hat, pi_hat
+ *   (model.py:733-740), diff_est = sum|pi_hat - pi| (model.py:781); current
+ *   params become "prev".  Synchronous when diff_est != NULL.
+ * tsem_lnl_pass: local part of calculate_lnl(z(prev), cur) (model.py:744-760)
+ *   into red[K]; tsem_read_reduce fetches the buffer.  */
+int  tsem_reduce_buffer(tsem_ctx* h, void** dptr, int64_t* count);
+int  tsem_bind_reduce_buffer(tsem_ctx* h, void* dptr, int64_t count); /* count >= K+2 doubles */
+int  tsem_em_pass(tsem_ctx* h);
+int  tsem_em_update(tsem_ctx* h, double* diff_est);
+int  tsem_lnl_pass(tsem_ctx* h);
+int  tsem_read_reduce(tsem_ctx* h, double* out, int64_t offset, int64_t count);
+/* n fixed iterations (pass+update) with no host round trip; the per-iteration
+ * diff_est values are left in a device ring and copied out at the end.
+ * Single-rank only (no exchange step).  == em() with em_epsilon=0, max_iter=n. */
+int  tsem_em_steps(tsem_ctx* h, int32_t n, double* diffs_out /* n or NULL */);
+/* Full single-rank EM loop (model.py:762-806). */
+int  tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likelihood,
+                 int32_t* n_iter, int32_t* converged, double* lnl,
+                 double* diffs /* max_iter */, double* lnls /* max_iter or NULL */,
+                 double* pi_init, double* theta_init /* K each or NULL */);
+
+/* ---- results -------------------------------------------------------------- */
+/* z aligned to the CSR pattern of the loaded scores (-1 where the reference
+ * drops the entry from z's pattern, i.e. where Q_ij * pi_j[*theta_j] == 0).  model.py:795 / 837.  */
+int  tsem_export_z(tsem_ctx* h, int which, double* z /* nnz */);
+/* estep on explicit params (public estep(pi,theta), model.py:702-722) */
+int  tsem_estep(tsem_ctx* h, const double* pi, const double* theta, double* z /* nnz */);
+/* public mstep(z) (model.py:724-742) and calculate_lnl(z,pi,theta) (744-760) on a
+ * caller-supplied z aligned to the CSR pattern (0 where z has no entry) */
+int  tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat);
+int  tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* theta, double* lnl);
+/* rows' best-hit counts for `choose` (sparse_plus.py:117-129): nbest[i] */
+int  tsem_best_counts(tsem_ctx* h, int which, int32_t* nbest /* n_rows */);
+/* reassign(method, thresh, initial).sum(0) (model.py:808-865,435-457) -> colsums[K]
+ * (local rows); optional per-entry mask aligned to the CSR pattern (nnz doubles,
+ * NULL to skip).  `picks[i]` (choose only) = ordinal of the chosen best hit. */
+int  tsem_reassign(tsem_ctx* h, int method, double thresh, int which,
+                   const int32_t* picks, double* colsums, double* mask);
+
+/* ---- csr_matrix_plus primitives on arbitrary fp64 CSR (sparse_plus.py) ---- */
+int  tsem_csr_norm_rows(int device, int64_t n_rows, const int64_t* indptr,
+                        const double* data, double* out);            /* norm(1)  :46-52  */
+int  tsem_csr_binmax_rows(int device, int64_t n_rows, int32_t n_cols, const int64_t* indptr,
+                          const double* data, int8_t* out);          /* binmax(1):117-129 */
+
+/* ---- instrumentation ------------------------------------------------------ */
+/* HIP-event time (ms) and launch count of the dominant EM kernel(s) since the
+ * last call with reset=1; algorithmic bytes one EM pass reads.  */
+int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launches,
+                       int64_t* algo_bytes_per_pass);
+int  tsem_layout_info(tsem_ctx* h, int64_t* info8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TELESCOPE_EM_H */

@@ -1,0 +1,323 @@
+"""ctypes binding of libtelescope_em.so (C ABI: include/telescope_em.h).
+
+There is NO CPU fallback.  If the shared library is missing, or no HIP device
+is usable, every entry point raises — the product path never computes on the
+host.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, 'libtelescope_em.so')
+SRC = os.path.join(HERE, 'csrc', 'tsem.hip')
+
+OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_TIMEOUT = 0, -1, -2, -3, -4
+RA_CODE = {'exclude': 0, 'choose': 1, 'average': 2, 'conf': 3, 'unique': 4, 'all': 5}
+Z_PREV, Z_CUR, Z_INITIAL = 0, 1, 2
+EMK_AUTO, EMK_TWOPASS, EMK_FUSED = 0, 1, 2
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = [SRC, os.path.join(HERE, 'csrc', 'tsem_common.h'),
+            os.path.join(HERE, 'csrc', 'tsem_fused.h'),
+            os.path.join(ROOT, 'include', 'telescope_em.h')]
+    deps = [d for d in deps if os.path.exists(d)]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-munsafe-fp-atomics', '-I' + os.path.join(ROOT, 'include'),
+           '-I' + os.path.join(HERE, 'csrc'), '-o', LIB_PATH, SRC]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def _p(dtype):
+    return np.ctypeslib.ndpointer(dtype=dtype, flags='C_CONTIGUOUS')
+
+
+def exported_symbols():
+    """Names the header declares; tests check the .so exports every one."""
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'telescope_em.h')).read()
+    return sorted(set(re.findall(r'\b(tsem_[a-z0-9_]+)\s*\(', hdr)))
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            'libtelescope_em.so is not built (%s). Run `python -c "import __graft_entry__ as g; '
+            'g.build()"`. There is no CPU fallback.' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+    L.tsem_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.tsem_destroy.argtypes = [vp]
+    L.tsem_destroy.restype = None
+    L.tsem_last_error.argtypes = [vp]
+    L.tsem_last_error.restype = C.c_char_p
+    L.tsem_set_stream.argtypes = [vp, vp]
+    L.tsem_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.tsem_synchronize.argtypes = [vp]
+    L.tsem_load_scores.argtypes = [vp, i64, i32, vp, vp, vp, vp, i32]
+    L.tsem_generate.argtypes = [vp, i64, i64, i32, vp, i32, u64, i32, dbl, vp, i32]
+    L.tsem_dims.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]
+    L.tsem_export_csr.argtypes = [vp, vp, vp, vp]
+    L.tsem_rowstats.argtypes = [vp, vp, vp]
+    L.tsem_set_model.argtypes = [vp, vp, vp, dbl, dbl]
+    L.tsem_set_params.argtypes = [vp, vp, vp]
+    L.tsem_get_params.argtypes = [vp, C.c_int, vp, vp]
+    L.tsem_reduce_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.tsem_bind_reduce_buffer.argtypes = [vp, vp, i64]
+    L.tsem_em_pass.argtypes = [vp]
+    L.tsem_em_update.argtypes = [vp, C.POINTER(dbl)]
+    L.tsem_lnl_pass.argtypes = [vp]
+    L.tsem_read_reduce.argtypes = [vp, vp, i64, i64]
+    L.tsem_em_steps.argtypes = [vp, i32, vp]
+    L.tsem_em_run.argtypes = [vp, dbl, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(dbl),
+                              vp, vp, vp, vp]
+    L.tsem_export_z.argtypes = [vp, C.c_int, vp]
+    L.tsem_estep.argtypes = [vp, vp, vp, vp]
+    L.tsem_mstep.argtypes = [vp, vp, vp, vp]
+    L.tsem_calc_lnl.argtypes = [vp, vp, vp, vp, C.POINTER(dbl)]
+    L.tsem_best_counts.argtypes = [vp, C.c_int, vp]
+    L.tsem_reassign.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, vp]
+    L.tsem_csr_norm_rows.argtypes = [C.c_int, i64, vp, vp, vp]
+    L.tsem_csr_binmax_rows.argtypes = [C.c_int, i64, i32, vp, vp, vp]
+    L.tsem_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
+    L.tsem_layout_info.argtypes = [vp, vp]
+    for name in exported_symbols():
+        fn = getattr(L, name)
+        if name not in ('tsem_destroy', 'tsem_last_error'):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def ptr(a):
+    """Raw pointer of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine(object):
+    """One handle == one GPU.  Thin, typed wrapper over the C ABI."""
+
+    def __init__(self, device=0):
+        L = lib()
+        h = C.c_void_p()
+        rc = L.tsem_create(C.byref(h), int(device))
+        if rc != OK:
+            raise EngineError('tsem_create failed (%d): %s — the EM engine needs an MI355X HIP '
+                              'device; there is no CPU fallback.'
+                              % (rc, L.tsem_last_error(None).decode()))
+        self._L, self._h, self.device = L, h, device
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.tsem_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise EngineError('libtelescope_em error %d: %s' % (rc, self._L.tsem_last_error(self._h).decode()))
+
+    # -- plumbing --
+    def set_stream(self, stream_handle):
+        self._ck(self._L.tsem_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def set_option(self, key, value):
+        self._ck(self._L.tsem_set_option(self._h, key.encode(), int(value)))
+
+    def synchronize(self):
+        self._ck(self._L.tsem_synchronize(self._h))
+
+    # -- matrix --
+    def load_scores(self, indptr, indices, raw, n_cols, lut):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        raw = np.ascontiguousarray(raw, dtype=np.uint16)
+        lut = np.ascontiguousarray(lut, dtype=np.float64)
+        self._ck(self._L.tsem_load_scores(self._h, len(indptr) - 1, int(n_cols), ptr(indptr), ptr(indices),
+                                          ptr(raw), ptr(lut), len(lut)))
+
+    def generate(self, row_begin, row_end, n_cols, len_cdf, seed, dist, uniq_frac, lut):
+        len_cdf = np.ascontiguousarray(len_cdf, dtype=np.uint32)
+        lut = np.ascontiguousarray(lut, dtype=np.float64)
+        self._ck(self._L.tsem_generate(self._h, int(row_begin), int(row_end), int(n_cols), ptr(len_cdf),
+                                       len(len_cdf), int(seed), int(dist), float(uniq_frac), ptr(lut), len(lut)))
+
+    def dims(self):
+        n, k, z = C.c_int64(), C.c_int32(), C.c_int64()
+        self._ck(self._L.tsem_dims(self._h, C.byref(n), C.byref(k), C.byref(z)))
+        return n.value, k.value, z.value
+
+    def export_csr(self):
+        n, k, nnz = self.dims()
+        indptr = np.empty(n + 1, np.int64)
+        indices = np.empty(nnz, np.int32)
+        raw = np.empty(nnz, np.uint16)
+        self._ck(self._L.tsem_export_csr(self._h, ptr(indptr), ptr(indices), ptr(raw)))
+        return indptr, indices, raw
+
+    # -- model --
+    def rowstats(self):
+        _, k, _ = self.dims()
+        stats, pisum0 = np.zeros(3), np.zeros(k)
+        self._ck(self._L.tsem_rowstats(self._h, ptr(stats), ptr(pisum0)))
+        return stats, pisum0
+
+    def set_model(self, stats, pisum0, pi_prior, theta_prior):
+        stats = np.ascontiguousarray(stats, dtype=np.float64)
+        pisum0 = np.ascontiguousarray(pisum0, dtype=np.float64)
+        self._ck(self._L.tsem_set_model(self._h, ptr(stats), ptr(pisum0), float(pi_prior), float(theta_prior)))
+
+    def set_params(self, pi, theta):
+        pi = np.ascontiguousarray(pi, dtype=np.float64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        self._ck(self._L.tsem_set_params(self._h, ptr(pi), ptr(theta)))
+
+    def get_params(self, which=Z_CUR):
+        _, k, _ = self.dims()
+        pi, theta = np.empty(k), np.empty(k)
+        self._ck(self._L.tsem_get_params(self._h, which, ptr(pi), ptr(theta)))
+        return pi, theta
+
+    # -- EM --
+    def reduce_buffer(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._ck(self._L.tsem_reduce_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def bind_reduce_buffer(self, dptr, count):
+        self._ck(self._L.tsem_bind_reduce_buffer(self._h, C.c_void_p(dptr), int(count)))
+
+    def em_pass(self):
+        self._ck(self._L.tsem_em_pass(self._h))
+
+    def em_update(self, want_diff=True):
+        d = C.c_double()
+        self._ck(self._L.tsem_em_update(self._h, C.byref(d) if want_diff else None))
+        return d.value
+
+    def lnl_pass(self):
+        self._ck(self._L.tsem_lnl_pass(self._h))
+
+    def read_reduce(self, offset, count):
+        out = np.empty(count)
+        self._ck(self._L.tsem_read_reduce(self._h, ptr(out), int(offset), int(count)))
+        return out
+
+    def em_steps(self, n, want_diffs=True):
+        out = np.empty(n) if want_diffs else None
+        self._ck(self._L.tsem_em_steps(self._h, int(n), ptr(out)))
+        return out
+
+    def em_run(self, epsilon, max_iter, use_likelihood):
+        _, k, _ = self.dims()
+        n_iter, conv, lnl = C.c_int32(), C.c_int32(), C.c_double()
+        diffs, lnls = np.full(max_iter, np.nan), np.full(max_iter, np.nan)
+        pi0, th0 = np.empty(k), np.empty(k)
+        self._ck(self._L.tsem_em_run(self._h, float(epsilon), int(max_iter), int(bool(use_likelihood)),
+                                     C.byref(n_iter), C.byref(conv), C.byref(lnl), ptr(diffs), ptr(lnls),
+                                     ptr(pi0), ptr(th0)))
+        n = n_iter.value
+        return dict(n_iter=n, converged=bool(conv.value), lnl=lnl.value, diffs=diffs[:n],
+                    lnls=lnls[:n], pi_init=pi0, theta_init=th0)
+
+    # -- results --
+    def export_z(self, which=Z_PREV):
+        _, _, nnz = self.dims()
+        z = np.empty(nnz)
+        self._ck(self._L.tsem_export_z(self._h, which, ptr(z)))
+        return z
+
+    def estep(self, pi, theta):
+        _, _, nnz = self.dims()
+        pi = np.ascontiguousarray(pi, dtype=np.float64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        z = np.empty(nnz)
+        self._ck(self._L.tsem_estep(self._h, ptr(pi), ptr(theta), ptr(z)))
+        return z
+
+    def mstep(self, z_aligned):
+        _, k, _ = self.dims()
+        z_aligned = np.ascontiguousarray(z_aligned, dtype=np.float64)
+        pi, theta = np.empty(k), np.empty(k)
+        self._ck(self._L.tsem_mstep(self._h, ptr(z_aligned), ptr(pi), ptr(theta)))
+        return pi, theta
+
+    def calc_lnl(self, z_aligned, pi, theta):
+        z_aligned = np.ascontiguousarray(z_aligned, dtype=np.float64)
+        pi = np.ascontiguousarray(pi, dtype=np.float64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        out = C.c_double()
+        self._ck(self._L.tsem_calc_lnl(self._h, ptr(z_aligned), ptr(pi), ptr(theta), C.byref(out)))
+        return out.value
+
+    def best_counts(self, which):
+        n, _, _ = self.dims()
+        nb = np.empty(n, np.int32)
+        self._ck(self._L.tsem_best_counts(self._h, which, ptr(nb)))
+        return nb
+
+    def reassign(self, method, thresh, which, picks=None, want_mask=False):
+        n, k, nnz = self.dims()
+        cs = np.empty(k)
+        mask = np.empty(nnz) if want_mask else None
+        if picks is not None:
+            picks = np.ascontiguousarray(picks, dtype=np.int32)
+        self._ck(self._L.tsem_reassign(self._h, RA_CODE[method], float(thresh), which, ptr(picks), ptr(cs),
+                                       ptr(mask)))
+        return cs, mask
+
+    # -- instrumentation --
+    def kernel_stats(self, reset=False):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_int64()
+        self._ck(self._L.tsem_kernel_stats(self._h, int(reset), C.byref(ms), C.byref(n), C.byref(b)))
+        return dict(em_ms=ms.value, em_launches=n.value, algo_bytes_per_pass=b.value)
+
+    def layout_info(self):
+        info = np.zeros(8, np.int64)
+        self._ck(self._L.tsem_layout_info(self._h, ptr(info)))
+        return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad'), info.tolist()))
+
+
+def csr_norm_rows(indptr, data, device=0):
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    out = np.empty_like(data)
+    rc = lib().tsem_csr_norm_rows(device, len(indptr) - 1, ptr(indptr), ptr(data), ptr(out))
+    if rc != OK:
+        raise EngineError('tsem_csr_norm_rows failed (%d): %s' % (rc, lib().tsem_last_error(None).decode()))
+    return out
+
+
+def csr_binmax_rows(indptr, data, n_cols, device=0):
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    out = np.empty(len(data), np.int8)
+    rc = lib().tsem_csr_binmax_rows(device, len(indptr) - 1, int(n_cols), ptr(indptr), ptr(data), ptr(out))
+    if rc != OK:
+        raise EngineError('tsem_csr_binmax_rows failed (%d): %s' % (rc, lib().tsem_last_error(None).decode()))
+    return out

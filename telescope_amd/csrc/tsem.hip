@@ -1,0 +1,1449 @@
+// libtelescope_em.so — MI355X (gfx950 / CDNA4) engine for Telescope's EM
+// reassignment path.  C ABI in include/telescope_em.h.
+//
+// Data layout in HBM:
+//   * canonical CSR of uint16 raw scores (indptr int64, indices int32, raw u16)
+//     + the Q lookup table lut[r] = expm1(r/max*100) (model.py:653);
+//   * for the EM hot loop, the AMBIGUOUS rows (Y_i = 1, model.py:679) re-laid
+//     as a column-partitioned blocked COO ("PCOO"): columns are dealt by
+//     popularity into P parts of Kp <= 7680 columns so that one part's
+//     pi*theta table AND its fp64 column accumulators fit in LDS; rows are cut
+//     in blocks of R; sub-block (b,p) is a contiguous run of
+//     {fp64 Q value, u32 (local row << 16 | local col)} = 12 B per entry.
+//   Global fp64 atomics reach only ~22 G/s on MI355X (2 G/s on hot columns)
+//   while LDS gathers / ds_add_f64 keep up with the 5.8 TB/s HBM stream
+//   (profiles/r01_primitives_ubench.log), hence every per-entry gather and
+//   scatter of the hot loop goes through LDS.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "tsem_common.h"
+
+static std::string g_create_err;
+
+// ============================================================================
+// small device helpers
+// ============================================================================
+__device__ __forceinline__ double recip0(double v) {
+  // sparse_plus.py:16-22 — 1/v with inf -> 0
+  double r = 1.0 / v;
+  return isinf(r) ? 0.0 : r;
+}
+
+template <int W>
+__device__ __forceinline__ double sg_sum(double v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, W);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ double sg_max(double v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, W));
+  return v;
+}
+template <int W>
+__device__ __forceinline__ int sg_sum_i(int v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, W);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ int sg_max_i(int v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, W));
+  return v;
+}
+
+// block-wide sum of one double per thread; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* scratch /* >= 16 doubles */) {
+  v = sg_sum<64>(v);
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+    int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+  }
+  return t;
+}
+
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ============================================================================
+// synthetic generator (bit-exact twin of telescope_amd/synthetic.py)
+// ============================================================================
+__global__ void k_gen_len(int64_t row_begin, int64_t n, int32_t K, const uint32_t* __restrict__ cdf,
+                          int cdf_len, uint64_t seed, uint32_t uniq_thresh, int64_t* __restrict__ lens) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint64_t row = (uint64_t)(row_begin + t);
+  uint32_t h = (uint32_t)(ts_hash3(seed ^ TS_SALT_LEN, row, 0) >> 32);
+  // searchsorted(cdf, h, side='right') == #{cdf[i] <= h}
+  int lo = 0, hi = cdf_len;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (cdf[mid] <= h) lo = mid + 1; else hi = mid;
+  }
+  int len = lo;
+  int cap = min(255, K - 1);
+  len = max(1, min(len, cap));
+  if (uniq_thresh) {
+    uint32_t hu = (uint32_t)(ts_hash3(seed ^ TS_SALT_UNIQ, row, 0) >> 32);
+    if (hu < uniq_thresh) len = 1;
+  }
+  lens[t] = len;
+}
+
+__global__ void k_gen_rows(int64_t row_begin, int64_t n, int32_t K, uint64_t seed, int dist,
+                           const int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
+                           uint16_t* __restrict__ raw) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint64_t row = (uint64_t)(row_begin + t);
+  int64_t s = indptr[t];
+  int len = (int)(indptr[t + 1] - s);
+  int32_t cols[256];
+  bool has0 = (uint32_t)(ts_hash3(seed ^ TS_SALT_COL0, row, 0) >> 32) < 214748364u;  // int(0.05*2^32)
+  for (int k = 0; k < len; ++k) {
+    if (k == 0 && has0) { cols[0] = 0; continue; }
+    for (int attempt = 0;; ++attempt) {
+      uint64_t h = ts_hash3(seed, row, (uint64_t)(k + 256 * attempt));
+      double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+      if (dist == 1) u = __dmul_rn(__dmul_rn(u, u), u);
+      int32_t cand = 1 + (int32_t)floor(__dmul_rn((double)(K - 1), u));
+      bool dup = false;
+      for (int q = 0; q < k; ++q) dup |= (cols[q] == cand);
+      if (!dup) { cols[k] = cand; break; }
+    }
+  }
+  // insertion sort ascending
+  for (int i = 1; i < len; ++i) {
+    int32_t v = cols[i];
+    int j = i - 1;
+    while (j >= 0 && cols[j] > v) { cols[j + 1] = cols[j]; --j; }
+    cols[j + 1] = v;
+  }
+  for (int p = 0; p < len; ++p) {
+    indices[s + p] = cols[p];
+    raw[s + p] = (uint16_t)(139 + (ts_hash3(seed ^ TS_SALT_SCORE, row, (uint64_t)p) % 162ull));
+  }
+}
+
+// ============================================================================
+// row statistics (model.py:679-699)
+// ============================================================================
+// One 16-lane group per row.  Outputs: per-row (len>=2 ? max raw code : 0),
+// flags, per-WG partial sums of w (total / ambiguous), global max code,
+// pisum0[col] += Q for unique rows.
+constexpr int RS_SUB = 16;
+__global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
+    const double* __restrict__ lut, uint16_t* __restrict__ row_code, uint8_t* __restrict__ row_class,
+    double* __restrict__ wsum_part /* [grid][2] */, uint32_t* __restrict__ maxcode,
+    double* __restrict__ pisum0) {
+  __shared__ double scratch[16];
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB;
+  const int subs = blockDim.x / RS_SUB;
+  double wt = 0.0, wa = 0.0;
+  int mymax = 0;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
+    int64_t s = indptr[row], e = indptr[row + 1];
+    int m = 0;
+    for (int64_t k = s + lane; k < e; k += RS_SUB) m = max(m, (int)raw[k]);
+    m = sg_max_i<RS_SUB>(m);
+    int64_t len = e - s;
+    if (lane == 0) {
+      double w = (len > 0) ? lut[m] : 0.0;
+      wt += w;
+      if (len > 1) wa += w;
+      row_code[row] = (uint16_t)m;
+      row_class[row] = (len > 1) ? 2 : (len == 1 ? 1 : 0);
+      mymax = max(mymax, m);
+      if (len == 1) unsafeAtomicAdd(&pisum0[indices[s]], lut[raw[s]]);
+    }
+  }
+  double bt = block_sum(wt, scratch);
+  double ba = block_sum(wa, scratch);
+  int bm = sg_max_i<64>(mymax);
+  if ((threadIdx.x & 63) == 0 && bm > 0) atomicMax(maxcode, (uint32_t)bm);
+  if (threadIdx.x == 0) { wsum_part[2 * blockIdx.x] = bt; wsum_part[2 * blockIdx.x + 1] = ba; }
+}
+
+// ============================================================================
+// layout build
+// ============================================================================
+__global__ void k_class_flags(int64_t N, const uint8_t* __restrict__ cls, int32_t* __restrict__ famb,
+                              int32_t* __restrict__ funi) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { famb[i] = cls[i] == 2; funi[i] = cls[i] == 1; }
+}
+
+__global__ void k_compact_rows(int64_t N, const uint8_t* __restrict__ cls, const int32_t* __restrict__ samb,
+    const int32_t* __restrict__ suni, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const uint16_t* __restrict__ raw, const uint16_t* __restrict__ row_code,
+    int32_t* __restrict__ amb_row, uint16_t* __restrict__ amb_wcode, int32_t* __restrict__ uni_col,
+    uint16_t* __restrict__ uni_code) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (cls[i] == 2) { int a = samb[i]; amb_row[a] = (int32_t)i; amb_wcode[a] = row_code[i]; }
+  else if (cls[i] == 1) { int u = suni[i]; int64_t s = indptr[i]; uni_col[u] = indices[s]; uni_code[u] = raw[s]; }
+}
+
+// column histogram over ambiguous rows' entries, LDS-privatised window of WIN bins
+constexpr int HIST_WIN = 32768;
+__global__ __launch_bounds__(1024) void k_col_hist(int64_t N_amb, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int col_base, int K,
+    unsigned long long* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* h = reinterpret_cast<uint32_t*>(smem);
+  for (int t = threadIdx.x; t < HIST_WIN; t += blockDim.x) h[t] = 0;
+  __syncthreads();
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int64_t a = (int64_t)blockIdx.x * subs + sub; a < N_amb; a += (int64_t)gridDim.x * subs) {
+    int64_t i = amb_row[a];
+    int64_t s = indptr[i], e = indptr[i + 1];
+    for (int64_t k = s + lane; k < e; k += RS_SUB) {
+      int c = indices[k] - col_base;
+      if (c >= 0 && c < HIST_WIN) atomicAdd(&h[c], 1u);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < HIST_WIN; t += blockDim.x)
+    if (h[t] && col_base + t < K) atomicAdd(&counts[col_base + t], (unsigned long long)h[t]);
+}
+
+// per (row block, part) entry counts — one WG per block
+__global__ __launch_bounds__(256) void k_sb_count(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap,
+    int64_t* __restrict__ sb_cnt) {
+  __shared__ uint32_t cnt[64];
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int64_t b = blockIdx.x;
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int lr = sub; lr < R; lr += subs) {
+    int64_t a = b * R + lr;
+    if (a >= N_amb) break;
+    int64_t i = amb_row[a];
+    int64_t s = indptr[i], e = indptr[i + 1];
+    for (int64_t k = s + lane; k < e; k += RS_SUB) atomicAdd(&cnt[colmap[indices[k]] >> 16], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < P) sb_cnt[b * P + threadIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
+    const double* __restrict__ lut, const uint32_t* __restrict__ colmap, const int64_t* __restrict__ sb_off,
+    double* __restrict__ pval, uint32_t* __restrict__ prc) {
+  __shared__ uint32_t cur[64];
+  if (threadIdx.x < 64) cur[threadIdx.x] = 0;
+  __syncthreads();
+  int64_t b = blockIdx.x;
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int lr = sub; lr < R; lr += subs) {
+    int64_t a = b * R + lr;
+    if (a >= N_amb) break;
+    int64_t i = amb_row[a];
+    int64_t s = indptr[i], e = indptr[i + 1];
+    for (int64_t k = s + lane; k < e; k += RS_SUB) {
+      uint32_t cm = colmap[indices[k]];
+      uint32_t p = cm >> 16;
+      int64_t pos = sb_off[b * P + p] + atomicAdd(&cur[p], 1u);
+      pval[pos] = lut[raw[k]];
+      prc[pos] = ((uint32_t)lr << 16) | (cm & 0xFFFFu);
+    }
+  }
+}
+
+// ============================================================================
+// EM hot loop — two-pass form (phase 1: partial row sums; phase 2: scatter)
+// ============================================================================
+// WG = (part p, stripe g).  LDS: ctab[Kp] | y[R]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_phase1(int P, int Kp, int R, int64_t nb, int G, int64_t N_amb_pad,
+    const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
+    const double* __restrict__ ctab, double* __restrict__ ypart) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* c = reinterpret_cast<double*>(smem);
+  double* y = c + Kp;
+  const int p = blockIdx.x % P, g = blockIdx.x / P;
+  for (int t = threadIdx.x; t < Kp; t += NT) c[t] = ctab[p * Kp + t];
+  for (int t = threadIdx.x; t < R; t += NT) y[t] = 0.0;
+  __syncthreads();
+  for (int64_t b = g; b < nb; b += G) {
+    const int64_t q0 = sb_off[b * P + p] >> 2, q1 = sb_off[b * P + p + 1] >> 2;
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += NT) {
+      uint4 rc = reinterpret_cast<const uint4*>(prc)[q];
+      double2 v0 = reinterpret_cast<const double2*>(pval)[2 * q];
+      double2 v1 = reinterpret_cast<const double2*>(pval)[2 * q + 1];
+      lds_add(&y[rc.x >> 16], v0.x * c[rc.x & 0xFFFF]);
+      lds_add(&y[rc.y >> 16], v0.y * c[rc.y & 0xFFFF]);
+      lds_add(&y[rc.z >> 16], v1.x * c[rc.z & 0xFFFF]);
+      lds_add(&y[rc.w >> 16], v1.y * c[rc.w & 0xFFFF]);
+    }
+    __syncthreads();
+    double* out = ypart + (int64_t)p * N_amb_pad + b * R;
+    for (int t = threadIdx.x; t < R; t += NT) { out[t] = y[t]; y[t] = 0.0; }
+    __syncthreads();
+  }
+}
+
+// LDS: ctab[Kp] | acc[Kp] | s[R].  thetasum partials -> partial[g][p*Kp + l]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_phase2_em(int P, int Kp, int R, int64_t nb, int G, int64_t N_amb_pad,
+    const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
+    const double* __restrict__ ctab, const double* __restrict__ ypart, const uint16_t* __restrict__ wcode,
+    const double* __restrict__ lut, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* c = reinterpret_cast<double*>(smem);
+  double* acc = c + Kp;
+  double* s = acc + Kp;
+  const int p = blockIdx.x % P, g = blockIdx.x / P;
+  for (int t = threadIdx.x; t < Kp; t += NT) { c[t] = ctab[p * Kp + t]; acc[t] = 0.0; }
+  for (int64_t b = g; b < nb; b += G) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < R; t += NT) {
+      int64_t a = b * R + t;
+      double ys = 0.0;
+      for (int pp = 0; pp < P; ++pp) ys += ypart[(int64_t)pp * N_amb_pad + a];
+      // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730)
+      s[t] = recip0(ys) * lut[wcode[a]];
+    }
+    __syncthreads();
+    const int64_t q0 = sb_off[b * P + p] >> 2, q1 = sb_off[b * P + p + 1] >> 2;
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += NT) {
+      uint4 rc = reinterpret_cast<const uint4*>(prc)[q];
+      double2 v0 = reinterpret_cast<const double2*>(pval)[2 * q];
+      double2 v1 = reinterpret_cast<const double2*>(pval)[2 * q + 1];
+      lds_add(&acc[rc.x & 0xFFFF], (v0.x * c[rc.x & 0xFFFF]) * s[rc.x >> 16]);
+      lds_add(&acc[rc.y & 0xFFFF], (v0.y * c[rc.y & 0xFFFF]) * s[rc.y >> 16]);
+      lds_add(&acc[rc.z & 0xFFFF], (v1.x * c[rc.z & 0xFFFF]) * s[rc.z >> 16]);
+      lds_add(&acc[rc.w & 0xFFFF], (v1.y * c[rc.w & 0xFFFF]) * s[rc.w >> 16]);
+    }
+  }
+  __syncthreads();
+  double* out = partial + (int64_t)g * (P * Kp) + p * Kp;
+  for (int t = threadIdx.x; t < Kp; t += NT) out[t] = acc[t];
+}
+
+// lnl over ambiguous rows: sum z(prev) * log1p(Q * c_cur)   (model.py:755-758)
+// LDS: c_old[Kp] | c_new[Kp] | r[R]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_phase2_lnl(int P, int Kp, int R, int64_t nb, int G, int64_t N_amb_pad,
+    const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
+    const double* __restrict__ ctab_old, const double* __restrict__ ctab_new, const double* __restrict__ ypart,
+    double* __restrict__ lnl_part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double scratch[16];
+  double* co = reinterpret_cast<double*>(smem);
+  double* cn = co + Kp;
+  double* r = cn + Kp;
+  const int p = blockIdx.x % P, g = blockIdx.x / P;
+  for (int t = threadIdx.x; t < Kp; t += NT) { co[t] = ctab_old[p * Kp + t]; cn[t] = ctab_new[p * Kp + t]; }
+  double acc = 0.0;
+  for (int64_t b = g; b < nb; b += G) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < R; t += NT) {
+      int64_t a = b * R + t;
+      double ys = 0.0;
+      for (int pp = 0; pp < P; ++pp) ys += ypart[(int64_t)pp * N_amb_pad + a];
+      r[t] = recip0(ys);
+    }
+    __syncthreads();
+    const int64_t e0 = sb_off[b * P + p], e1 = sb_off[b * P + p + 1];
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += NT) {
+      uint32_t rc = prc[e];
+      double v = pval[e];
+      double z = (v * co[rc & 0xFFFF]) * r[rc >> 16];
+      if (z != 0.0) acc += z * log1p(v * cn[rc & 0xFFFF]);
+    }
+  }
+  double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) lnl_part[blockIdx.x] = t;
+}
+
+// lnl over unique rows: z = n * recip0(n), n = Q*pi_prev; inner = Q*pi_cur
+__global__ __launch_bounds__(256) void k_lnl_unique(int64_t N_uni, const int32_t* __restrict__ ucol,
+    const uint16_t* __restrict__ ucode, const double* __restrict__ lut, const double* __restrict__ pi_old,
+    const double* __restrict__ pi_new, double* __restrict__ lnl_part) {
+  __shared__ double scratch[16];
+  double acc = 0.0;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < N_uni; u += (int64_t)gridDim.x * blockDim.x) {
+    int col = ucol[u];
+    double q = lut[ucode[u]];
+    double n = q * pi_old[col];
+    if (n != 0.0) {
+      double z = n * recip0(n);
+      if (z != 0.0) acc += z * log1p(q * pi_new[col]);
+    }
+  }
+  double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) lnl_part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ a, int na, const double* __restrict__ b,
+                                                   int nbb, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double acc = 0.0;
+  for (int t = threadIdx.x; t < na; t += blockDim.x) acc += a[t];
+  for (int t = threadIdx.x; t < nbb; t += blockDim.x) acc += b[t];
+  double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// red[col] = sum_g partial[g][pc]   (fixed order -> deterministic given partials)
+__global__ void k_colreduce(int Kpad, int G, const double* __restrict__ partial,
+                            const int32_t* __restrict__ col_of_pc, double* __restrict__ red, int K) {
+  int pc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pc == 0) { red[K] = 0.0; red[K + 1] = 0.0; }
+  if (pc >= Kpad) return;
+  int col = col_of_pc[pc];
+  if (col < 0) return;
+  double s = 0.0;
+  for (int g = 0; g < G; ++g) s += partial[(int64_t)g * Kpad + pc];
+  red[col] = s;
+}
+
+// M-step closed forms (model.py:733-740) + diff_est (model.py:781); single WG
+__global__ __launch_bounds__(1024) void k_update(int K, const double* __restrict__ red,
+    const double* __restrict__ pisum0, double theta_pw, double theta_den, double pi_pw, double pi_den,
+    double* __restrict__ pi, double* __restrict__ theta, double* __restrict__ pi_prev,
+    double* __restrict__ theta_prev, const uint32_t* __restrict__ colmap, int Kp,
+    double* __restrict__ ctab, double* __restrict__ ctab_prev, double* __restrict__ diff_out) {
+  __shared__ double scratch[16];
+  double d = 0.0;
+  for (int j = threadIdx.x; j < K; j += blockDim.x) {
+    double ts = red[j];
+    double th = (ts + theta_pw) / theta_den;
+    double ps = pisum0[j] + ts;
+    double ph = (ps + pi_pw) / pi_den;
+    double po = pi[j], to = theta[j];
+    d += fabs(ph - po);
+    pi_prev[j] = po; theta_prev[j] = to;
+    pi[j] = ph; theta[j] = th;
+    uint32_t cm = colmap[j];
+    int pc = (int)(cm >> 16) * Kp + (int)(cm & 0xFFFF);
+    ctab_prev[pc] = ctab[pc];
+    ctab[pc] = ph * th;
+  }
+  double t = block_sum(d, scratch);
+  if (threadIdx.x == 0) diff_out[0] = t;
+}
+
+__global__ void k_make_ctab(int K, const double* __restrict__ pi, const double* __restrict__ theta,
+                            const uint32_t* __restrict__ colmap, int Kp, double* __restrict__ ctab) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  uint32_t cm = colmap[j];
+  ctab[(int)(cm >> 16) * Kp + (int)(cm & 0xFFFF)] = pi[j] * theta[j];
+}
+
+__global__ void k_fill(double* p, int64_t n, double v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ============================================================================
+// CSR row passes: z export, best-hit counts, reassign (model.py:808-865)
+// ============================================================================
+enum { RP_EXPORT_Z = 0, RP_BEST = 1, RP_REASSIGN = 2 };
+constexpr int RP_SUB = 16;
+
+struct RowPassArgs {
+  int64_t N;
+  int32_t K;
+  const int64_t* indptr;
+  const int32_t* indices;
+  const uint16_t* raw;
+  const double* lut;
+  const double* pi;      // null => initial (c == 1)
+  const double* theta;
+  int method;
+  double thresh;
+  const int32_t* picks;
+  double* zout;          // EXPORT_Z / mask
+  int32_t* nbest;
+  double* colsums;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rowpass(RowPassArgs A) {
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  const bool initial = (A.pi == nullptr);
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < A.N; row += (int64_t)gridDim.x * subs) {
+    const int64_t s = A.indptr[row], e = A.indptr[row + 1];
+    const bool amb = (e - s) > 1;
+    auto numer = [&](int64_t k) -> double {
+      double q = A.lut[A.raw[k]];
+      if (initial) return q;
+      int col = A.indices[k];
+      double c = amb ? A.pi[col] * A.theta[col] : A.pi[col];
+      return q * c;
+    };
+    // sweep 1: row sum
+    double y = 0.0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) y += numer(k);
+    y = sg_sum<RP_SUB>(y);
+    const double r = recip0(y);
+    // sweep 2: row max over z's pattern
+    double zmax = -1.0;
+    int cnt = 0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      double n = numer(k);
+      bool inpat = initial || (n != 0.0);
+      if (inpat) { zmax = fmax(zmax, n * r); ++cnt; }
+    }
+    zmax = sg_max<RP_SUB>(zmax);
+    cnt = sg_sum_i<RP_SUB>(cnt);
+    if (MODE == RP_EXPORT_Z) {
+      for (int64_t k = s + lane; k < e; k += RP_SUB) {
+        double n = numer(k);
+        bool inpat = initial || (n != 0.0);
+        A.zout[k] = inpat ? n * r : -1.0;   // -1 marks an entry the reference drops from z's pattern
+      }
+      continue;
+    }
+    // sweep 3: number of best hits (binmax, sparse_plus.py:117-129)
+    int nb = 0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      double n = numer(k);
+      bool inpat = initial || (n != 0.0);
+      if (inpat && (n * r) == zmax) ++nb;
+    }
+    nb = sg_sum_i<RP_SUB>(nb);
+    if (MODE == RP_BEST) {
+      if (lane == 0) A.nbest[row] = cnt ? nb : 0;
+      continue;
+    }
+    // ---- reassign ----
+    double vsum = 0.0;
+    if (A.method == TSEM_RA_CONF) {
+      for (int64_t k = s + lane; k < e; k += RP_SUB) {
+        double n = numer(k);
+        double z = n * r;
+        if ((initial || n != 0.0) && z >= A.thresh) vsum += z;
+      }
+      vsum = sg_sum<RP_SUB>(vsum);
+    }
+    const int pick = (A.method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[row] : 0;
+    int base = 0;
+    for (int64_t k0 = s; k0 < e; k0 += RP_SUB) {
+      int64_t k = k0 + lane;
+      bool valid = k < e;
+      double n = valid ? numer(k) : 0.0;
+      bool inpat = valid && (initial || n != 0.0);
+      double z = n * r;
+      bool best = inpat && (z == zmax);
+      unsigned long long bal = __ballot(best);
+      unsigned grp = (unsigned)((bal >> ((threadIdx.x & 63) / RP_SUB * RP_SUB)) & 0xFFFFull);
+      int ord = base + __popc(grp & ((1u << lane) - 1u));
+      base += __popc(grp);
+      double val = 0.0;
+      switch (A.method) {
+        case TSEM_RA_EXCLUDE: val = (best && nb == 1) ? 1.0 : 0.0; break;
+        case TSEM_RA_CHOOSE:  val = (best && ord == pick) ? 1.0 : 0.0; break;
+        case TSEM_RA_AVERAGE: val = best ? 1.0 * recip0((double)nb) : 0.0; break;
+        case TSEM_RA_CONF:    val = (inpat && z >= A.thresh) ? z * recip0(vsum) : 0.0; break;
+        case TSEM_RA_UNIQUE:  val = (inpat && !amb) ? ceil(z) : 0.0; break;
+        case TSEM_RA_ALL:     val = (inpat && z > 0.0) ? 1.0 : 0.0; break;
+      }
+      if (valid) {
+        if (A.zout) A.zout[k] = val;
+        if (val != 0.0) unsafeAtomicAdd(&A.colsums[A.indices[k]], val);
+      }
+    }
+  }
+}
+
+// mstep(z) on caller-supplied z (model.py:724-742): colsums[j] = sum_i (z_ij * w_i) * Y_i
+__global__ __launch_bounds__(256) void k_mstep_rows(RowPassArgs A, const double* __restrict__ zin) {
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < A.N; row += (int64_t)gridDim.x * subs) {
+    const int64_t s = A.indptr[row], e = A.indptr[row + 1];
+    if (e - s < 2) continue;
+    int m = 0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) m = max(m, (int)A.raw[k]);
+    m = sg_max_i<RP_SUB>(m);
+    const double w = A.lut[m];
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      double v = zin[k] * w;
+      if (v != 0.0) unsafeAtomicAdd(&A.colsums[A.indices[k]], v);
+    }
+  }
+}
+
+// calculate_lnl(z, pi, theta) on caller-supplied z (model.py:744-760)
+__global__ __launch_bounds__(256) void k_lnl_rows(RowPassArgs A, const double* __restrict__ zin,
+                                                  double* __restrict__ part) {
+  __shared__ double scratch[16];
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  double acc = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < A.N; row += (int64_t)gridDim.x * subs) {
+    const int64_t s = A.indptr[row], e = A.indptr[row + 1];
+    const bool amb = (e - s) > 1;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      int col = A.indices[k];
+      double c = amb ? A.pi[col] * A.theta[col] : A.pi[col];
+      double inner = A.lut[A.raw[k]] * c;
+      double z = zin[k];
+      if (inner != 0.0 && z != 0.0) acc += z * log1p(inner);
+    }
+  }
+  double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// closed forms of mstep without committing (model.py:733-740)
+__global__ void k_hats(int K, const double* __restrict__ ts, const double* __restrict__ pisum0, double theta_pw,
+                       double theta_den, double pi_pw, double pi_den, double* __restrict__ pi_hat,
+                       double* __restrict__ theta_hat) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  theta_hat[j] = (ts[j] + theta_pw) / theta_den;
+  pi_hat[j] = ((pisum0[j] + ts[j]) + pi_pw) / pi_den;
+}
+
+// ---- csr_matrix_plus primitives on fp64 CSR --------------------------------
+__global__ __launch_bounds__(256) void k_norm_rows(int64_t N, const int64_t* __restrict__ indptr,
+                                                   const double* __restrict__ data, double* __restrict__ out) {
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
+    int64_t s = indptr[row], e = indptr[row + 1];
+    double y = 0.0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) y += data[k];
+    y = sg_sum<RP_SUB>(y);
+    double r = recip0(y);
+    for (int64_t k = s + lane; k < e; k += RP_SUB) out[k] = data[k] * r;
+  }
+}
+__global__ __launch_bounds__(256) void k_binmax_rows(int64_t N, int32_t K, const int64_t* __restrict__ indptr,
+                                                     const double* __restrict__ data, int8_t* __restrict__ out) {
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
+    int64_t s = indptr[row], e = indptr[row + 1];
+    bool any = false;
+    double m = 0.0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) { m = any ? fmax(m, data[k]) : data[k]; any = true; }
+    // combine: lanes without entries must not contribute
+    double mm = any ? m : -INFINITY;
+    mm = sg_max<RP_SUB>(mm);
+    if ((e - s) < K) mm = fmax(mm, 0.0);  // implicit zeros take part in max(1)
+    for (int64_t k = s + lane; k < e; k += RP_SUB) out[k] = (data[k] == mm) ? 1 : 0;
+  }
+}
+
+// ============================================================================
+// host side
+// ============================================================================
+template <typename T>
+static int dalloc(tsem_ctx* h, T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) {
+    h->err = std::string("hipMalloc(") + std::to_string(n * sizeof(T)) + " B): " + hipGetErrorString(e);
+    return TSEM_ERR_NOMEM;
+  }
+  return TSEM_OK;
+}
+#define TSEM_ALLOC(ptr, n) do { int rc_ = dalloc(h, &(ptr), (size_t)(n)); if (rc_) return rc_; } while (0)
+
+template <typename T>
+static void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+static inline int cdiv64(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+static int ensure_device(tsem_ctx* h) {
+  TSEM_HIP(hipSetDevice(h->device));
+  return TSEM_OK;
+}
+
+static void free_layout(tsem_ctx* h) {
+  dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_prc);
+  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags);
+}
+static void free_matrix(tsem_ctx* h) {
+  dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_raw); dfree(h->d_lut);
+  dfree(h->d_amb_row); dfree(h->d_amb_wcode); dfree(h->d_uni_col); dfree(h->d_uni_code);
+  dfree(h->d_pisum0);
+  free_layout(h);
+  dfree(h->d_pi); dfree(h->d_theta); dfree(h->d_pi_prev); dfree(h->d_theta_prev);
+  dfree(h->d_ctab); dfree(h->d_ctab_prev); dfree(h->d_red_own); dfree(h->d_tmp_pi); dfree(h->d_tmp_theta);
+  h->d_red = nullptr;
+  h->have_rowstats = h->have_model = false;
+  h->N = h->nnz = 0; h->K = 0;
+}
+
+extern "C" {
+
+int tsem_create(tsem_ctx** out, int device) {
+  if (!out) return TSEM_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_err = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    return TSEM_ERR_HIP;
+  }
+  if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return TSEM_ERR_ARG; }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return TSEM_ERR_HIP; }
+  tsem_ctx* h = new tsem_ctx();
+  h->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+  if (hipMalloc((void**)&h->d_diffs, TS_DIFF_RING * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&h->d_lnl_part, 8192 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&h->d_maxcode, 64) != hipSuccess ||
+      hipMalloc((void**)&h->d_xerr, 64) != hipSuccess) {
+    g_create_err = "hipMalloc failed in tsem_create";
+    delete h;
+    return TSEM_ERR_NOMEM;
+  }
+  (void)hipMemset(h->d_xerr, 0, 64);
+  *out = h;
+  return TSEM_OK;
+}
+
+void tsem_destroy(tsem_ctx* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  free_matrix(h);
+  dfree(h->d_diffs); dfree(h->d_lnl_part); dfree(h->d_maxcode); dfree(h->d_xerr);
+  for (auto& ev : h->ev) (void)hipEventDestroy(ev);
+  delete h;
+}
+
+const char* tsem_last_error(const tsem_ctx* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int tsem_set_stream(tsem_ctx* h, void* s) {
+  if (!h) return TSEM_ERR_ARG;
+  h->stream = (hipStream_t)s;
+  return TSEM_OK;
+}
+
+int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
+  if (!h || !key) return TSEM_ERR_ARG;
+  std::string k(key);
+  if (k == "em_kernel") h->em_kernel = (int)v;
+  else if (k == "block_rows") h->opt_R = v;
+  else if (k == "parts") h->opt_P = v;
+  else TSEM_FAIL(TSEM_ERR_ARG, "unknown option " + k);
+  return TSEM_OK;
+}
+
+int tsem_synchronize(tsem_ctx* h) {
+  if (!h) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return TSEM_OK;
+}
+
+static int set_lut(tsem_ctx* h, const double* lut, int32_t lut_len) {
+  if (!lut || lut_len <= 0 || lut_len > 65536) TSEM_FAIL(TSEM_ERR_ARG, "lut must have 1..65536 entries");
+  h->lut_len = lut_len;
+  h->lut_host.assign(lut, lut + lut_len);
+  TSEM_ALLOC(h->d_lut, lut_len);
+  TSEM_HIP(hipMemcpy(h->d_lut, lut, sizeof(double) * lut_len, hipMemcpyHostToDevice));
+  return TSEM_OK;
+}
+
+int tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols, const int64_t* indptr, const int32_t* indices,
+                     const uint16_t* raw, const double* lut, int32_t lut_len) {
+  if (!h) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (n_rows < 0 || n_cols <= 0 || !indptr) TSEM_FAIL(TSEM_ERR_ARG, "bad matrix dimensions");
+  if (n_rows >= (int64_t)INT32_MAX) TSEM_FAIL(TSEM_ERR_ARG, "more than 2^31-1 rows per rank is not supported");
+  int64_t nnz = indptr[n_rows];
+  if (indptr[0] != 0 || nnz < 0) TSEM_FAIL(TSEM_ERR_ARG, "indptr must start at 0");
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (indptr[i + 1] < indptr[i]) TSEM_FAIL(TSEM_ERR_ARG, "indptr must be non-decreasing");
+  for (int64_t k = 0; k < nnz; ++k) {
+    if (indices[k] < 0 || indices[k] >= n_cols) TSEM_FAIL(TSEM_ERR_ARG, "column index out of range");
+    if ((int)raw[k] >= lut_len) TSEM_FAIL(TSEM_ERR_ARG, "raw score exceeds lookup table");
+  }
+  free_matrix(h);
+  if (int rc = set_lut(h, lut, lut_len)) return rc;
+  h->N = n_rows; h->K = n_cols; h->nnz = nnz;
+  TSEM_ALLOC(h->d_indptr, n_rows + 1);
+  TSEM_ALLOC(h->d_indices, nnz);
+  TSEM_ALLOC(h->d_raw, nnz);
+  TSEM_HIP(hipMemcpy(h->d_indptr, indptr, sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice));
+  if (nnz) {
+    TSEM_HIP(hipMemcpy(h->d_indices, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    TSEM_HIP(hipMemcpy(h->d_raw, raw, sizeof(uint16_t) * nnz, hipMemcpyHostToDevice));
+  }
+  return TSEM_OK;
+}
+
+int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_cols, const uint32_t* len_cdf,
+                  int32_t cdf_len, uint64_t seed, int32_t dist, double uniq_frac, const double* lut,
+                  int32_t lut_len) {
+  if (!h) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  int64_t n = row_end - row_begin;
+  if (n < 0 || n_cols < 2 || !len_cdf || cdf_len <= 0) TSEM_FAIL(TSEM_ERR_ARG, "bad generator arguments");
+  if (n >= (int64_t)INT32_MAX) TSEM_FAIL(TSEM_ERR_ARG, "more than 2^31-1 rows per rank is not supported");
+  if (lut_len < 301) TSEM_FAIL(TSEM_ERR_ARG, "lut must cover scores up to 300");
+  free_matrix(h);
+  if (int rc = set_lut(h, lut, lut_len)) return rc;
+  h->N = n; h->K = n_cols;
+  uint32_t* d_cdf = nullptr;
+  TSEM_ALLOC(d_cdf, cdf_len);
+  TSEM_HIP(hipMemcpy(d_cdf, len_cdf, sizeof(uint32_t) * cdf_len, hipMemcpyHostToDevice));
+  TSEM_ALLOC(h->d_indptr, n + 1);
+  TSEM_HIP(hipMemsetAsync(h->d_indptr, 0, sizeof(int64_t), h->stream));
+  uint32_t uth = 0;
+  if (uniq_frac > 0) {
+    double t = uniq_frac * 4294967296.0;
+    uth = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+  }
+  if (n) {
+    k_gen_len<<<cdiv64(n, 256), 256, 0, h->stream>>>(row_begin, n, n_cols, d_cdf, cdf_len, seed, uth, h->d_indptr + 1);
+    size_t tb = 0;
+    hipcub::DeviceScan::InclusiveSum(nullptr, tb, h->d_indptr + 1, h->d_indptr + 1, n, h->stream);
+    void* tmp = nullptr;
+    TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+    hipcub::DeviceScan::InclusiveSum(tmp, tb, h->d_indptr + 1, h->d_indptr + 1, n, h->stream);
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(tmp);
+  }
+  int64_t nnz = 0;
+  TSEM_HIP(hipMemcpy(&nnz, h->d_indptr + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+  h->nnz = nnz;
+  TSEM_ALLOC(h->d_indices, nnz);
+  TSEM_ALLOC(h->d_raw, nnz);
+  if (n) {
+    k_gen_rows<<<cdiv64(n, 128), 128, 0, h->stream>>>(row_begin, n, n_cols, seed, dist, h->d_indptr, h->d_indices, h->d_raw);
+    TSEM_HIP(hipGetLastError());
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+  }
+  (void)hipFree(d_cdf);
+  return TSEM_OK;
+}
+
+int tsem_dims(tsem_ctx* h, int64_t* n_rows, int32_t* n_cols, int64_t* nnz) {
+  if (!h) return TSEM_ERR_ARG;
+  if (n_rows) *n_rows = h->N;
+  if (n_cols) *n_cols = h->K;
+  if (nnz) *nnz = h->nnz;
+  return TSEM_OK;
+}
+
+int tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* raw) {
+  if (!h || !h->d_indptr) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  if (indptr) TSEM_HIP(hipMemcpy(indptr, h->d_indptr, sizeof(int64_t) * (h->N + 1), hipMemcpyDeviceToHost));
+  if (indices && h->nnz) TSEM_HIP(hipMemcpy(indices, h->d_indices, sizeof(int32_t) * h->nnz, hipMemcpyDeviceToHost));
+  if (raw && h->nnz) TSEM_HIP(hipMemcpy(raw, h->d_raw, sizeof(uint16_t) * h->nnz, hipMemcpyDeviceToHost));
+  return TSEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rowstats: classes, weights, local sums; compacts ambiguous / unique rows
+// ---------------------------------------------------------------------------
+int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0) {
+  if (!h || !h->d_indptr) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  const int64_t N = h->N;
+  const int K = h->K;
+  uint16_t* d_code = nullptr; uint8_t* d_cls = nullptr; double* d_wpart = nullptr;
+  int32_t *d_fa = nullptr, *d_fu = nullptr;
+  TSEM_ALLOC(d_code, N); TSEM_ALLOC(d_cls, N);
+  const int grid = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (N + 15) / 16));
+  TSEM_ALLOC(d_wpart, 2 * grid);
+  TSEM_ALLOC(h->d_pisum0, K);
+  TSEM_HIP(hipMemsetAsync(h->d_pisum0, 0, sizeof(double) * K, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
+  TSEM_HIP(hipMemsetAsync(d_wpart, 0, sizeof(double) * 2 * grid, h->stream));
+  if (N)
+    k_rowstats<<<grid, 256, 0, h->stream>>>(N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, d_code, d_cls,
+                                           d_wpart, h->d_maxcode, h->d_pisum0);
+  TSEM_HIP(hipGetLastError());
+  std::vector<double> wpart(2 * grid);
+  uint32_t maxcode = 0;
+  TSEM_HIP(hipMemcpyAsync(wpart.data(), d_wpart, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipMemcpyAsync(&maxcode, h->d_maxcode, 4, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  double wt = 0, wa = 0;
+  for (int i = 0; i < grid; ++i) { wt += wpart[2 * i]; wa += wpart[2 * i + 1]; }
+  if (stats3) { stats3[0] = wt; stats3[1] = wa; stats3[2] = (N && h->nnz) ? h->lut_host[maxcode] : 0.0; }
+  if (pisum0) TSEM_HIP(hipMemcpy(pisum0, h->d_pisum0, sizeof(double) * K, hipMemcpyDeviceToHost));
+
+  // compact ambiguous and unique rows
+  TSEM_ALLOC(d_fa, N + 1); TSEM_ALLOC(d_fu, N + 1);
+  int32_t na = 0, nu = 0;
+  TSEM_HIP(hipMemsetAsync(d_fa + N, 0, 4, h->stream));
+  TSEM_HIP(hipMemsetAsync(d_fu + N, 0, 4, h->stream));
+  if (N) {
+    k_class_flags<<<cdiv64(N, 256), 256, 0, h->stream>>>(N, d_cls, d_fa, d_fu);
+    size_t tb = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_fa, d_fa, N + 1, h->stream);
+    void* tmp = nullptr;
+    TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+    hipcub::DeviceScan::ExclusiveSum(tmp, tb, d_fa, d_fa, N + 1, h->stream);
+    hipcub::DeviceScan::ExclusiveSum(tmp, tb, d_fu, d_fu, N + 1, h->stream);
+    TSEM_HIP(hipMemcpyAsync(&na, d_fa + N, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(&nu, d_fu + N, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(tmp);
+  }
+  h->N_amb = na; h->N_uni = nu;
+  h->R = h->opt_R > 0 ? (int)h->opt_R : 2048;
+  if (h->R > 65536 || h->R < 64) TSEM_FAIL(TSEM_ERR_ARG, "block_rows must be in [64, 65536]");
+  h->nb = (na + h->R - 1) / h->R;
+  h->N_amb_pad = std::max<int64_t>(1, h->nb) * h->R;
+  TSEM_ALLOC(h->d_amb_row, na);
+  TSEM_ALLOC(h->d_amb_wcode, h->N_amb_pad);
+  TSEM_ALLOC(h->d_uni_col, nu);
+  TSEM_ALLOC(h->d_uni_code, nu);
+  TSEM_HIP(hipMemsetAsync(h->d_amb_wcode, 0, sizeof(uint16_t) * h->N_amb_pad, h->stream));
+  if (N)
+    k_compact_rows<<<cdiv64(N, 256), 256, 0, h->stream>>>(N, d_cls, d_fa, d_fu, h->d_indptr, h->d_indices, h->d_raw,
+                                                         d_code, h->d_amb_row, h->d_amb_wcode, h->d_uni_col,
+                                                         h->d_uni_code);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_code); (void)hipFree(d_cls); (void)hipFree(d_wpart); (void)hipFree(d_fa); (void)hipFree(d_fu);
+  h->have_rowstats = true;
+  return TSEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// layout: column partition by popularity, blocked COO of ambiguous rows
+// ---------------------------------------------------------------------------
+static int build_layout(tsem_ctx* h) {
+  const int K = h->K;
+  const int64_t na = h->N_amb;
+  free_layout(h);
+  // 1. column popularity over ambiguous rows
+  std::vector<unsigned long long> counts(K, 0);
+  {
+    unsigned long long* d_cnt = nullptr;
+    TSEM_ALLOC(d_cnt, K);
+    TSEM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * K, h->stream));
+    if (na) {
+      TSEM_HIP(hipFuncSetAttribute((const void*)k_col_hist, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_WIN * 4));
+      int grid = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, (na + 63) / 64));
+      for (int base = 0; base < K; base += HIST_WIN)
+        k_col_hist<<<grid, 1024, HIST_WIN * 4, h->stream>>>(na, h->d_amb_row, h->d_indptr, h->d_indices, base, K, d_cnt);
+      TSEM_HIP(hipGetLastError());
+    }
+    TSEM_HIP(hipMemcpyAsync(counts.data(), d_cnt, sizeof(unsigned long long) * K, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_cnt);
+  }
+  h->nnz_amb = 0;
+  for (int j = 0; j < K; ++j) h->nnz_amb += (int64_t)counts[j];
+  // 2. parts: deal columns by popularity so every part carries ~equal nnz
+  int P = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP - 1) / TS_MAX_KP;
+  if (P < 1) P = 1;
+  if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
+  int Kp = (K + P - 1) / P;
+  if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
+  h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
+  std::vector<int> order(K);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return counts[a] > counts[b]; });
+  std::vector<uint32_t> colmap(K);
+  std::vector<int32_t> col_of_pc(h->Kpad, -1);
+  for (int rank = 0; rank < K; ++rank) {
+    int j = order[rank];
+    int p = rank % P, l = rank / P;
+    colmap[j] = ((uint32_t)p << 16) | (uint32_t)l;
+    col_of_pc[p * Kp + l] = j;
+  }
+  TSEM_ALLOC(h->d_colmap, K);
+  TSEM_ALLOC(h->d_col_of_pc, h->Kpad);
+  TSEM_HIP(hipMemcpy(h->d_colmap, colmap.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice));
+  TSEM_HIP(hipMemcpy(h->d_col_of_pc, col_of_pc.data(), sizeof(int32_t) * h->Kpad, hipMemcpyHostToDevice));
+  // 3. sub-block sizes -> offsets (each padded to a multiple of 4 entries)
+  const int64_t nb = h->nb;
+  const int R = h->R;
+  std::vector<int64_t> sb(nb * P + 1, 0);
+  if (nb) {
+    int64_t* d_cnt = nullptr;
+    TSEM_ALLOC(d_cnt, nb * P);
+    k_sb_count<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_cnt);
+    TSEM_HIP(hipGetLastError());
+    TSEM_HIP(hipMemcpyAsync(sb.data(), d_cnt, sizeof(int64_t) * nb * P, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_cnt);
+  }
+  int64_t off = 0;
+  for (int64_t i = 0; i < nb * P; ++i) { int64_t c = (sb[i] + 3) & ~3ll; sb[i] = off; off += c; }
+  sb[nb * P] = off;
+  h->nnz_pad = off;
+  TSEM_ALLOC(h->d_sb_off, nb * P + 1);
+  TSEM_HIP(hipMemcpy(h->d_sb_off, sb.data(), sizeof(int64_t) * (nb * P + 1), hipMemcpyHostToDevice));
+  TSEM_ALLOC(h->d_pval, off);
+  TSEM_ALLOC(h->d_prc, off);
+  TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_prc, 0, sizeof(uint32_t) * std::max<int64_t>(1, off), h->stream));
+  if (nb) {
+    k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_amb_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
+                                                  h->d_colmap, h->d_sb_off, h->d_pval, h->d_prc);
+    TSEM_HIP(hipGetLastError());
+  }
+  TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad);
+  // launch geometry
+  const size_t lds1 = (size_t)(Kp + R) * 8, lds2 = (size_t)(2 * Kp + R) * 8;
+  if (lds2 > (size_t)TS_LDS_MAX - 1024) TSEM_FAIL(TSEM_ERR_ARG, "LDS budget exceeded (reduce block_rows)");
+  int w1 = std::max(1, std::min(4, (int)(TS_LDS_MAX / lds1)));   // 512-thread WGs per CU
+  int w2 = std::max(1, std::min(2, (int)(TS_LDS_MAX / lds2)));   // 1024-thread WGs per CU
+  h->G1 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w1 / P));
+  h->G2 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w2 / P));
+  TSEM_ALLOC(h->d_partial, (int64_t)h->G2 * h->Kpad);
+  TSEM_HIP(hipFuncSetAttribute((const void*)k_phase1<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
+  TSEM_HIP(hipFuncSetAttribute((const void*)k_phase2_em<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
+  TSEM_HIP(hipFuncSetAttribute((const void*)k_phase2_lnl<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return TSEM_OK;
+}
+
+int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, double pi_prior, double theta_prior) {
+  if (!h || !h->have_rowstats || !stats3 || !pisum0) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  const int K = h->K;
+  h->W_tot = stats3[0]; h->W_amb = stats3[1]; h->w_max = stats3[2];
+  h->pi_prior = pi_prior; h->theta_prior = theta_prior;
+  TSEM_HIP(hipMemcpy(h->d_pisum0, pisum0, sizeof(double) * K, hipMemcpyHostToDevice));
+  if (int rc = build_layout(h)) return rc;
+  TSEM_ALLOC(h->d_pi, K); TSEM_ALLOC(h->d_theta, K); TSEM_ALLOC(h->d_pi_prev, K); TSEM_ALLOC(h->d_theta_prev, K);
+  TSEM_ALLOC(h->d_tmp_pi, K); TSEM_ALLOC(h->d_tmp_theta, K);
+  TSEM_ALLOC(h->d_ctab, h->Kpad); TSEM_ALLOC(h->d_ctab_prev, h->Kpad);
+  if (!h->d_red) {
+    TSEM_ALLOC(h->d_red_own, K + 2);
+    h->d_red = h->d_red_own; h->red_count = K + 2;
+  } else if (h->red_count < K + 2) {
+    TSEM_FAIL(TSEM_ERR_ARG, "bound reduce buffer is smaller than K+2 doubles");
+  }
+  TSEM_HIP(hipMemsetAsync(h->d_ctab, 0, sizeof(double) * h->Kpad, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_ctab_prev, 0, sizeof(double) * h->Kpad, h->stream));
+  const double init = 1.0 / (double)K;   // model.py:667,673
+  k_fill<<<cdiv64(K, 256), 256, 0, h->stream>>>(h->d_pi, K, init);
+  k_fill<<<cdiv64(K, 256), 256, 0, h->stream>>>(h->d_theta, K, init);
+  k_fill<<<cdiv64(K, 256), 256, 0, h->stream>>>(h->d_pi_prev, K, init);
+  k_fill<<<cdiv64(K, 256), 256, 0, h->stream>>>(h->d_theta_prev, K, init);
+  k_make_ctab<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, h->d_colmap, h->Kp, h->d_ctab);
+  k_make_ctab<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, h->d_colmap, h->Kp, h->d_ctab_prev);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  h->have_model = true;
+  return TSEM_OK;
+}
+
+int tsem_set_params(tsem_ctx* h, const double* pi, const double* theta) {
+  if (!h || !h->have_model || !pi || !theta) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  const int K = h->K;
+  TSEM_HIP(hipMemcpyAsync(h->d_pi_prev, h->d_pi, sizeof(double) * K, hipMemcpyDeviceToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_theta_prev, h->d_theta, sizeof(double) * K, hipMemcpyDeviceToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_ctab_prev, h->d_ctab, sizeof(double) * h->Kpad, hipMemcpyDeviceToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_pi, pi, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_theta, theta, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
+  k_make_ctab<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, h->d_colmap, h->Kp, h->d_ctab);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return TSEM_OK;
+}
+
+int tsem_get_params(tsem_ctx* h, int which, double* pi, double* theta) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  const double* sp = which == TSEM_Z_PREV ? h->d_pi_prev : h->d_pi;
+  const double* st = which == TSEM_Z_PREV ? h->d_theta_prev : h->d_theta;
+  if (pi) TSEM_HIP(hipMemcpy(pi, sp, sizeof(double) * h->K, hipMemcpyDeviceToHost));
+  if (theta) TSEM_HIP(hipMemcpy(theta, st, sizeof(double) * h->K, hipMemcpyDeviceToHost));
+  return TSEM_OK;
+}
+
+int tsem_reduce_buffer(tsem_ctx* h, void** dptr, int64_t* count) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (dptr) *dptr = h->d_red;
+  if (count) *count = h->K + 2;
+  return TSEM_OK;
+}
+
+int tsem_bind_reduce_buffer(tsem_ctx* h, void* dptr, int64_t count) {
+  if (!h || !dptr) return TSEM_ERR_ARG;
+  if (h->K && count < h->K + 2) TSEM_FAIL(TSEM_ERR_ARG, "reduce buffer needs K+2 doubles");
+  h->d_red = (double*)dptr;
+  h->red_count = count;
+  return TSEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// EM pass / update / lnl
+// ---------------------------------------------------------------------------
+static int launch_phase1(tsem_ctx* h, const double* ctab) {
+  if (h->nb == 0) return TSEM_OK;
+  const size_t lds1 = (size_t)(h->Kp + h->R) * 8;
+  k_phase1<512><<<h->G1 * h->P, 512, lds1, h->stream>>>(h->P, h->Kp, h->R, h->nb, h->G1, h->N_amb_pad, h->d_sb_off,
+                                                        h->d_pval, h->d_prc, ctab, h->d_ypart);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+static int begin_timing(tsem_ctx* h, hipEvent_t** pair) {
+  *pair = nullptr;
+  if (h->ev_used + 2 > 8192) return TSEM_OK;
+  while (h->ev.size() < h->ev_used + 2) {
+    hipEvent_t e;
+    TSEM_HIP(hipEventCreate(&e));
+    h->ev.push_back(e);
+  }
+  *pair = &h->ev[h->ev_used];
+  h->ev_used += 2;
+  TSEM_HIP(hipEventRecord((*pair)[0], h->stream));
+  return TSEM_OK;
+}
+
+int tsem_em_pass(tsem_ctx* h) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  hipEvent_t* pair = nullptr;
+  if (int rc = begin_timing(h, &pair)) return rc;
+  if (h->nb > 0) {
+    if (int rc = launch_phase1(h, h->d_ctab)) return rc;
+    const size_t lds2 = (size_t)(2 * h->Kp + h->R) * 8;
+    k_phase2_em<1024><<<h->G2 * h->P, 1024, lds2, h->stream>>>(h->P, h->Kp, h->R, h->nb, h->G2, h->N_amb_pad,
+        h->d_sb_off, h->d_pval, h->d_prc, h->d_ctab, h->d_ypart, h->d_amb_wcode, h->d_lut, h->d_partial);
+    TSEM_HIP(hipGetLastError());
+  }
+  if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
+  h->em_launches += 1;
+  if (h->nb > 0) {
+    k_colreduce<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_red, h->K);
+  } else {
+    TSEM_HIP(hipMemsetAsync(h->d_red, 0, sizeof(double) * (h->K + 2), h->stream));
+  }
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+static int launch_update(tsem_ctx* h, double* d_diff_slot) {
+  const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;   // model.py:696-697
+  const double tden = h->W_amb + tpw * h->K, pden = h->W_tot + ppw * h->K;      // model.py:732,738
+  k_update<<<1, 1024, 0, h->stream>>>(h->K, h->d_red, h->d_pisum0, tpw, tden, ppw, pden, h->d_pi, h->d_theta,
+                                      h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab, h->d_ctab_prev,
+                                      d_diff_slot);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+int tsem_em_update(tsem_ctx* h, double* diff_est) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (int rc = launch_update(h, h->d_diffs)) return rc;
+  if (diff_est) {
+    TSEM_HIP(hipMemcpyAsync(diff_est, h->d_diffs, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+  }
+  return TSEM_OK;
+}
+
+int tsem_lnl_pass(tsem_ctx* h) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  int na = 0, nu = 0;
+  if (h->nb > 0) {
+    if (int rc = launch_phase1(h, h->d_ctab_prev)) return rc;
+    const size_t lds2 = (size_t)(2 * h->Kp + h->R) * 8;
+    na = h->G2 * h->P;
+    k_phase2_lnl<1024><<<na, 1024, lds2, h->stream>>>(h->P, h->Kp, h->R, h->nb, h->G2, h->N_amb_pad, h->d_sb_off,
+        h->d_pval, h->d_prc, h->d_ctab_prev, h->d_ctab, h->d_ypart, h->d_lnl_part);
+    TSEM_HIP(hipGetLastError());
+  }
+  if (h->N_uni > 0) {
+    nu = (int)std::min<int64_t>(2048, (h->N_uni + 255) / 256);
+    k_lnl_unique<<<nu, 256, 0, h->stream>>>(h->N_uni, h->d_uni_col, h->d_uni_code, h->d_lut, h->d_pi_prev, h->d_pi,
+                                           h->d_lnl_part + 4096);
+    TSEM_HIP(hipGetLastError());
+  }
+  k_sum_parts<<<1, 256, 0, h->stream>>>(h->d_lnl_part, na, h->d_lnl_part + 4096, nu, h->d_red + h->K);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+int tsem_read_reduce(tsem_ctx* h, double* out, int64_t offset, int64_t count) {
+  if (!h || !h->have_model || !out || offset < 0 || offset + count > h->K + 2) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipMemcpyAsync(out, h->d_red + offset, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return TSEM_OK;
+}
+
+int tsem_em_steps(tsem_ctx* h, int32_t n, double* diffs_out) {
+  if (!h || !h->have_model || n < 0 || n > TS_DIFF_RING) return TSEM_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    if (int rc = tsem_em_pass(h)) return rc;
+    if (int rc = launch_update(h, h->d_diffs + i)) return rc;
+  }
+  if (diffs_out && n) {
+    TSEM_HIP(hipMemcpyAsync(diffs_out, h->d_diffs, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+  }
+  return TSEM_OK;
+}
+
+int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likelihood, int32_t* n_iter,
+                int32_t* converged, double* lnl_out, double* diffs, double* lnls, double* pi_init,
+                double* theta_init) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  int inum = 0;
+  bool conv = false, reached = false;
+  double lnl = INFINITY;
+  while (!(conv || reached)) {               // model.py:771-797
+    if (int rc = tsem_em_pass(h)) return rc;
+    double diff = 0.0;
+    if (int rc = tsem_em_update(h, &diff)) return rc;
+    ++inum;
+    if (inum == 1) { if (int rc = tsem_get_params(h, TSEM_Z_CUR, pi_init, theta_init)) return rc; }
+    if (diffs) diffs[inum - 1] = diff;
+    if (use_likelihood) {
+      if (int rc = tsem_lnl_pass(h)) return rc;
+      double l = 0.0;
+      if (int rc = tsem_read_reduce(h, &l, h->K, 1)) return rc;
+      conv = fabs(l - lnl) < epsilon;
+      lnl = l;
+      if (lnls) lnls[inum - 1] = l;
+    } else {
+      conv = diff < epsilon;
+    }
+    reached = inum >= max_iter;
+  }
+  if (!use_likelihood) {                     // model.py:800-801
+    if (int rc = tsem_lnl_pass(h)) return rc;
+    if (int rc = tsem_read_reduce(h, &lnl, h->K, 1)) return rc;
+  }
+  if (n_iter) *n_iter = inum;
+  if (converged) *converged = conv ? 1 : 0;
+  if (lnl_out) *lnl_out = lnl;
+  return TSEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// results
+// ---------------------------------------------------------------------------
+static int rowpass_args(tsem_ctx* h, int which, RowPassArgs& A) {
+  A.N = h->N; A.K = h->K; A.indptr = h->d_indptr; A.indices = h->d_indices; A.raw = h->d_raw; A.lut = h->d_lut;
+  A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr;
+  if (which == TSEM_Z_INITIAL) { A.pi = nullptr; A.theta = nullptr; }
+  else if (which == TSEM_Z_PREV) { A.pi = h->d_pi_prev; A.theta = h->d_theta_prev; }
+  else if (which == TSEM_Z_CUR) { A.pi = h->d_pi; A.theta = h->d_theta; }
+  else TSEM_FAIL(TSEM_ERR_ARG, "bad `which`");
+  if (which != TSEM_Z_INITIAL && !h->have_model) TSEM_FAIL(TSEM_ERR_ARG, "model not set");
+  return TSEM_OK;
+}
+static int rowpass_grid(tsem_ctx* h) { return (int)std::min<int64_t>(8192, std::max<int64_t>(1, (h->N + 15) / 16)); }
+
+static int export_z_with(tsem_ctx* h, RowPassArgs& A, double* z) {
+  double* d_z = nullptr;
+  TSEM_ALLOC(d_z, h->nnz);
+  A.zout = d_z;
+  if (h->N) k_rowpass<RP_EXPORT_Z><<<rowpass_grid(h), 256, 0, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  if (h->nnz) TSEM_HIP(hipMemcpyAsync(z, d_z, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_z);
+  return TSEM_OK;
+}
+
+int tsem_export_z(tsem_ctx* h, int which, double* z) {
+  if (!h || !h->d_indptr || !z) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  return export_z_with(h, A, z);
+}
+
+int tsem_estep(tsem_ctx* h, const double* pi, const double* theta, double* z) {
+  if (!h || !h->have_model || !pi || !theta || !z) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipMemcpyAsync(h->d_tmp_pi, pi, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_tmp_theta, theta, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
+  A.pi = h->d_tmp_pi; A.theta = h->d_tmp_theta;
+  return export_z_with(h, A, z);
+}
+
+int tsem_best_counts(tsem_ctx* h, int which, int32_t* nbest) {
+  if (!h || !h->d_indptr || !nbest) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  int32_t* d_nb = nullptr;
+  TSEM_ALLOC(d_nb, h->N);
+  A.nbest = d_nb;
+  if (h->N) k_rowpass<RP_BEST><<<rowpass_grid(h), 256, 0, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  if (h->N) TSEM_HIP(hipMemcpyAsync(nbest, d_nb, sizeof(int32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_nb);
+  return TSEM_OK;
+}
+
+int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks, double* colsums,
+                  double* mask) {
+  if (!h || !h->d_indptr || !colsums) return TSEM_ERR_ARG;
+  if (method < TSEM_RA_EXCLUDE || method > TSEM_RA_ALL) TSEM_FAIL(TSEM_ERR_ARG, "bad reassign method");
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  A.method = method; A.thresh = thresh;
+  double *d_cs = nullptr, *d_mask = nullptr;
+  int32_t* d_picks = nullptr;
+  TSEM_ALLOC(d_cs, h->K);
+  TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
+  if (mask) TSEM_ALLOC(d_mask, h->nnz);
+  if (method == TSEM_RA_CHOOSE && picks) {
+    TSEM_ALLOC(d_picks, h->N);
+    if (h->N) TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+  }
+  A.colsums = d_cs; A.zout = d_mask; A.picks = d_picks;
+  if (h->N) k_rowpass<RP_REASSIGN><<<rowpass_grid(h), 256, 0, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  if (mask && h->nnz) TSEM_HIP(hipMemcpyAsync(mask, d_mask, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_cs);
+  if (d_mask) (void)hipFree(d_mask);
+  if (d_picks) (void)hipFree(d_picks);
+  return TSEM_OK;
+}
+
+int tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat) {
+  if (!h || !h->have_model || !z || !pi_hat || !theta_hat) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
+  double *d_z = nullptr, *d_cs = nullptr;
+  TSEM_ALLOC(d_z, h->nnz);
+  TSEM_ALLOC(d_cs, h->K);
+  if (h->nnz) TSEM_HIP(hipMemcpyAsync(d_z, z, sizeof(double) * h->nnz, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
+  A.colsums = d_cs;
+  if (h->N) k_mstep_rows<<<rowpass_grid(h), 256, 0, h->stream>>>(A, d_z);
+  const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;
+  k_hats<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, d_cs, h->d_pisum0, tpw, h->W_amb + tpw * h->K, ppw,
+                                                  h->W_tot + ppw * h->K, h->d_tmp_pi, h->d_tmp_theta);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipMemcpyAsync(pi_hat, h->d_tmp_pi, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipMemcpyAsync(theta_hat, h->d_tmp_theta, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_z); (void)hipFree(d_cs);
+  return TSEM_OK;
+}
+
+int tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* theta, double* lnl) {
+  if (!h || !h->have_model || !z || !pi || !theta || !lnl) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
+  double* d_z = nullptr;
+  TSEM_ALLOC(d_z, h->nnz);
+  if (h->nnz) TSEM_HIP(hipMemcpyAsync(d_z, z, sizeof(double) * h->nnz, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_tmp_pi, pi, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_tmp_theta, theta, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
+  A.pi = h->d_tmp_pi; A.theta = h->d_tmp_theta;
+  int grid = std::min(4096, rowpass_grid(h));
+  if (h->N) k_lnl_rows<<<grid, 256, 0, h->stream>>>(A, d_z, h->d_lnl_part);
+  k_sum_parts<<<1, 256, 0, h->stream>>>(h->d_lnl_part, h->N ? grid : 0, h->d_lnl_part, 0, h->d_lnl_part + 8000);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipMemcpyAsync(lnl, h->d_lnl_part + 8000, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_z);
+  return TSEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// csr_matrix_plus primitives (stateless)
+// ---------------------------------------------------------------------------
+static int csr_prim(int device, int64_t n_rows, int32_t n_cols, const int64_t* indptr, const double* data,
+                    double* out_d, int8_t* out_b) {
+  if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed (no usable HIP device)"; return TSEM_ERR_HIP; }
+  if (n_rows < 0 || !indptr) return TSEM_ERR_ARG;
+  int64_t nnz = indptr[n_rows];
+  int64_t* d_ip = nullptr; double *d_in = nullptr, *d_od = nullptr; int8_t* d_ob = nullptr;
+  bool ok = hipMalloc((void**)&d_ip, sizeof(int64_t) * (n_rows + 1)) == hipSuccess &&
+            hipMalloc((void**)&d_in, sizeof(double) * std::max<int64_t>(1, nnz)) == hipSuccess;
+  if (ok && out_d) ok = hipMalloc((void**)&d_od, sizeof(double) * std::max<int64_t>(1, nnz)) == hipSuccess;
+  if (ok && out_b) ok = hipMalloc((void**)&d_ob, std::max<int64_t>(1, nnz)) == hipSuccess;
+  int rc = TSEM_OK;
+  if (!ok) { g_create_err = "hipMalloc failed"; rc = TSEM_ERR_NOMEM; }
+  if (ok) {
+    (void)hipMemcpy(d_ip, indptr, sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice);
+    if (nnz) (void)hipMemcpy(d_in, data, sizeof(double) * nnz, hipMemcpyHostToDevice);
+    int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n_rows + 15) / 16));
+    if (n_rows) {
+      if (out_d) k_norm_rows<<<grid, 256>>>(n_rows, d_ip, d_in, d_od);
+      if (out_b) k_binmax_rows<<<grid, 256>>>(n_rows, n_cols, d_ip, d_in, d_ob);
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { g_create_err = hipGetErrorString(e); rc = TSEM_ERR_HIP; }
+    if (rc == TSEM_OK && nnz) {
+      if (out_d) (void)hipMemcpy(out_d, d_od, sizeof(double) * nnz, hipMemcpyDeviceToHost);
+      if (out_b) (void)hipMemcpy(out_b, d_ob, nnz, hipMemcpyDeviceToHost);
+    }
+  }
+  if (d_ip) (void)hipFree(d_ip);
+  if (d_in) (void)hipFree(d_in);
+  if (d_od) (void)hipFree(d_od);
+  if (d_ob) (void)hipFree(d_ob);
+  return rc;
+}
+
+int tsem_csr_norm_rows(int device, int64_t n_rows, const int64_t* indptr, const double* data, double* out) {
+  return csr_prim(device, n_rows, 0, indptr, data, out, nullptr);
+}
+int tsem_csr_binmax_rows(int device, int64_t n_rows, int32_t n_cols, const int64_t* indptr, const double* data,
+                         int8_t* out) {
+  return csr_prim(device, n_rows, n_cols, indptr, data, nullptr, out);
+}
+
+// ---------------------------------------------------------------------------
+// instrumentation
+// ---------------------------------------------------------------------------
+int tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launches, int64_t* algo_bytes) {
+  if (!h) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) h->em_ms_acc += ms;
+  }
+  h->ev_used = 0;
+  if (em_ms) *em_ms = h->em_ms_acc;
+  if (em_launches) *em_launches = h->em_launches;
+  // one EM pass must read every stored entry of the ambiguous rows once:
+  // 12 B per entry (fp64 Q + packed local row/col) + 2 B row weight code per row
+  if (algo_bytes) *algo_bytes = h->nnz_amb * 12 + h->N_amb * 2;
+  if (reset) { h->em_ms_acc = 0; h->em_launches = 0; }
+  return TSEM_OK;
+}
+
+int tsem_layout_info(tsem_ctx* h, int64_t* info) {
+  if (!h || !info) return TSEM_ERR_ARG;
+  info[0] = h->P; info[1] = h->Kp; info[2] = h->R; info[3] = h->nb;
+  info[4] = h->N_amb; info[5] = h->N_uni; info[6] = h->nnz_amb; info[7] = h->nnz_pad;
+  return TSEM_OK;
+}
+
+}  // extern "C"

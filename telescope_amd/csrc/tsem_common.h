@@ -1,0 +1,116 @@
+// Shared declarations for libtelescope_em.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "telescope_em.h"
+
+#define TSEM_HIP(call)                                                           \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_) + " (" +        \
+               __FILE__ + ":" + std::to_string(__LINE__) + ")";                  \
+      return TSEM_ERR_HIP;                                                       \
+    }                                                                            \
+  } while (0)
+
+#define TSEM_FAIL(code, msg)                                                     \
+  do {                                                                           \
+    h->err = (msg);                                                              \
+    return (code);                                                               \
+  } while (0)
+
+// ---- counter-based hash shared with telescope_amd/synthetic.py --------------
+#define TS_GOLDEN 0x9E3779B97F4A7C15ull
+#define TS_M1 0xBF58476D1CE4E5B9ull
+#define TS_M2 0x94D049BB133111EBull
+#define TS_SALT_LEN 0xA5A5A5A5A5A5A5A5ull
+#define TS_SALT_UNIQ 0x5BD1E9955BD1E995ull
+#define TS_SALT_COL0 0xC2B2AE3D27D4EB4Full
+#define TS_SALT_SCORE 0x165667B19E3779F9ull
+
+__host__ __device__ inline uint64_t ts_mix64(uint64_t z) {
+  z += TS_GOLDEN;
+  z = (z ^ (z >> 30)) * TS_M1;
+  z = (z ^ (z >> 27)) * TS_M2;
+  return z ^ (z >> 31);
+}
+__host__ __device__ inline uint64_t ts_hash3(uint64_t seed, uint64_t row, uint64_t k) {
+  return ts_mix64(ts_mix64(seed ^ (row * TS_GOLDEN)) ^ (k * TS_M1));
+}
+
+// LDS budget for the per-part tables (c and acc, 8 B each per column).
+constexpr int TS_LDS_TABLE_BYTES = 120 * 1024;
+constexpr int TS_MAX_KP = TS_LDS_TABLE_BYTES / 16;   // 7680 columns per part
+constexpr int TS_LDS_MAX = 160 * 1024;
+
+struct tsem_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int n_cu = 256;
+
+  // ---- CSR of raw scores (rows owned by this rank) ----
+  int64_t N = 0, nnz = 0;
+  int32_t K = 0;
+  int64_t* d_indptr = nullptr;
+  int32_t* d_indices = nullptr;
+  uint16_t* d_raw = nullptr;
+  double* d_lut = nullptr;
+  int lut_len = 0;
+  std::vector<double> lut_host;
+
+  // ---- row classes ----
+  int64_t N_amb = 0, N_uni = 0, nnz_amb = 0;
+  int32_t* d_amb_row = nullptr;     // [N_amb]  compact ambiguous row -> CSR row
+  uint16_t* d_amb_wcode = nullptr;  // [N_amb_pad] max raw code of the row (w = lut[code])
+  int32_t* d_uni_col = nullptr;     // [N_uni]
+  uint16_t* d_uni_code = nullptr;   // [N_uni]
+  uint32_t* d_maxcode = nullptr;    // [1]
+  bool have_rowstats = false;
+
+  // ---- model scalars (GLOBAL after set_model) ----
+  double W_tot = 0, W_amb = 0, w_max = 0, pi_prior = 0, theta_prior = 0;
+  double* d_pisum0 = nullptr;  // [K]
+  bool have_model = false;
+
+  // ---- column partition + blocked COO layout of ambiguous rows ----
+  int P = 1, Kp = 0, Kpad = 0, R = 2048;
+  int64_t nb = 0, N_amb_pad = 0, nnz_pad = 0;
+  uint32_t* d_colmap = nullptr;     // [K]    col -> (part<<16 | lcol)
+  int32_t* d_col_of_pc = nullptr;   // [Kpad] part*Kp+lcol -> col or -1
+  int64_t* d_sb_off = nullptr;      // [nb*P+1] entry offsets (multiples of 4)
+  double* d_pval = nullptr;         // [nnz_pad]  Q values
+  uint32_t* d_prc = nullptr;        // [nnz_pad]  lrow<<16 | lcol
+  double* d_ypart = nullptr;        // [P][N_amb_pad] partial row sums
+  int G1 = 1, G2 = 1, T1 = 512, T2 = 1024;
+  double* d_partial = nullptr;      // [G2][Kpad]
+  double* d_lnl_part = nullptr;     // [4096]
+  int em_kernel = TSEM_EMK_AUTO;
+  int64_t opt_R = 0, opt_P = 0;
+
+  // ---- parameters ----
+  double *d_pi = nullptr, *d_theta = nullptr, *d_pi_prev = nullptr, *d_theta_prev = nullptr;
+  double *d_ctab = nullptr, *d_ctab_prev = nullptr;  // [Kpad] permuted pi*theta
+  double* d_red = nullptr;          // reduce buffer (K+2), internal or bound
+  double* d_red_own = nullptr;
+  int64_t red_count = 0;
+  double* d_diffs = nullptr;        // [TS_DIFF_RING]
+  double *d_tmp_pi = nullptr, *d_tmp_theta = nullptr;
+
+  // ---- fused-kernel exchange state ----
+  double* d_xchg = nullptr;
+  uint32_t* d_xflags = nullptr;
+  uint32_t* d_xerr = nullptr;
+
+  // ---- instrumentation ----
+  std::vector<hipEvent_t> ev;       // pairs
+  size_t ev_used = 0;
+  double em_ms_acc = 0;
+  int64_t em_launches = 0;
+};
+
+constexpr int TS_DIFF_RING = 65536;

@@ -1,0 +1,311 @@
+"""`TelescopeLikelihood` on the MI355X engine.
+
+Host-side mirror of the reference's operator interface
+(/root/reference/telescope/utils/model.py:631-865): same constructor
+(`TelescopeLikelihood(score_matrix, opts)`), same methods (`estep`, `mstep`,
+`calculate_lnl`, `em`, `reassign`), same attributes (`pi`, `theta`, `pi_init`,
+`theta_init`, `z`, `lnl`, `Q`, `Y`, `N`, `K`, `raw_scores`, ...), same log
+lines and the same `ValueError` for a bad reassign method — so it drops in for
+the scipy.sparse path behind `telescope assign` / `telescope resume`.
+
+All arithmetic runs in libtelescope_em.so (hand-written HIP for gfx950) through
+the C ABI in include/telescope_em.h.  There is no CPU fallback: constructing
+the class without a usable GPU raises `EngineError`.
+
+Multi-GPU: one process per GPU; pass `comm=` (see telescope_amd/distributed.py).
+Each rank constructs the class on ITS row range of the score matrix; the global
+maximum score, the setup sums and, every iteration, the per-locus column sums
+are all-reduced over RCCL.
+"""
+import logging as lg
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import Engine, EngineError, Z_CUR, Z_INITIAL, Z_PREV  # noqa: F401
+
+REASSIGN_METHODS = ('exclude', 'choose', 'average', 'conf', 'unique', 'all')
+_MASK_DTYPE = {'exclude': np.int8, 'choose': np.int8, 'average': np.float64,
+               'conf': np.float64, 'unique': np.uint8, 'all': np.uint8}
+
+
+def score_lut(max_score, scale_factor=100.):
+    """Q for every raw score 0..max_score with the reference's numpy expression
+    (model.py:653 via sparse_plus.py:89-91: `raw.multiply(1./max).multiply(100.).expm1()`),
+    so Q is bit-identical to the reference's."""
+    r = np.arange(int(max_score) + 1, dtype=np.uint16)
+    return np.expm1((r * (1. / max_score)) * scale_factor)
+
+
+class _NullComm(object):
+    """Single-rank stand-in for distributed.Comm."""
+    rank, world = 0, 1
+
+    def max_scalar(self, v):
+        return v
+
+    def sum_array(self, a):
+        return a
+
+    def max_array(self, a):
+        return a
+
+    def allreduce_device(self, engine, offset=0, count=None):
+        pass
+
+    def gather_rows(self, a):
+        return [a]
+
+    def scatter_rows(self, parts):
+        return parts[0]
+
+
+class TelescopeLikelihood(object):
+    """EM model over a fragments x loci score matrix (model.py:631-865)."""
+
+    def __init__(self, score_matrix, opts, device=None, comm=None, engine=None):
+        self.comm = comm if comm is not None else _NullComm()
+        raw = sp.csr_matrix(score_matrix)
+        if not raw.has_canonical_format:
+            raw = raw.copy()
+            raw.sum_duplicates()
+        if raw.nnz and (raw.data.min() < 0 or raw.data.max() > 65535
+                        or not np.all(raw.data == np.floor(raw.data))):
+            raise ValueError('score matrix must hold integer alignment scores in [0, 65535]')
+        self.raw_scores = score_matrix
+        self._raw = raw
+        self.N, self.K = raw.shape                                   # model.py:643
+        local_max = int(raw.data.max()) if raw.nnz else 0
+        self.max_score = self.comm.max_scalar(local_max)             # model.py:640 (global)
+        self.scale_factor = 100.                                     # model.py:652
+        self._lut = score_lut(self.max_score, self.scale_factor) if self.max_score > 0 \
+            else np.zeros(1)
+
+        self.epsilon = opts.em_epsilon                               # model.py:661-662
+        self.max_iter = opts.max_iter
+        self.pi_prior = opts.pi_prior                                # model.py:686-687
+        self.theta_prior = opts.theta_prior
+
+        if device is None:
+            device = getattr(self.comm, 'device', 0)
+        self._eng = engine if engine is not None else Engine(device)
+        if engine is None:
+            self._eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16),
+                                  self.K, self._lut)
+        self._setup_model()
+
+    @classmethod
+    def from_engine(cls, engine, n_cols, max_score, opts, comm=None):
+        """Wrap an engine whose matrix is already resident (device-generated)."""
+        self = cls.__new__(cls)
+        self.comm = comm if comm is not None else _NullComm()
+        self.raw_scores = self._raw = None
+        self._eng = engine
+        self.N, self.K, _ = engine.dims()
+        self.max_score, self.scale_factor = max_score, 100.
+        self._lut = score_lut(max_score)
+        self.epsilon, self.max_iter = opts.em_epsilon, opts.max_iter
+        self.pi_prior, self.theta_prior = opts.pi_prior, opts.theta_prior
+        self._setup_model()
+        return self
+
+    def _setup_model(self):
+        stats, pisum0 = self._eng.rowstats()                         # model.py:679-699 (local)
+        sums = self.comm.sum_array(np.concatenate([stats[:2], pisum0]))
+        wmax = self.comm.max_array(stats[2:3])
+        self._total_wt, self._ambig_wt = float(sums[0]), float(sums[1])
+        self._max_wt = float(wmax[0])
+        self._pisum0 = np.asarray(sums[2:])
+        self._pi_prior_wt = self.pi_prior * self._max_wt             # model.py:696-697
+        self._theta_prior_wt = self.theta_prior * self._max_wt
+        self._eng.set_model(np.array([self._total_wt, self._ambig_wt, self._max_wt]),
+                            self._pisum0, self.pi_prior, self.theta_prior)
+        self.pi = np.repeat(1. / self.K, self.K)                     # model.py:667
+        self.theta = np.repeat(1. / self.K, self.K)                  # model.py:673
+        self.pi_init = self.theta_init = None
+        self.lnl = float('inf')                                      # model.py:683
+        self._z = None
+        self._z_which = None
+        self.n_iter, self.converged = 0, False
+
+    # ---- lazily materialised compat attributes --------------------------------
+    @property
+    def Q(self):
+        """model.py:653 — materialised on the host only when asked for."""
+        r = self._need_raw()
+        return sp.csr_matrix((self._lut[r.data], r.indices, r.indptr), shape=r.shape)
+
+    @property
+    def Y(self):
+        """model.py:679 — N x 1 uint8 ambiguity indicator."""
+        r = self._need_raw()
+        return (np.diff(r.indptr) > 1).astype(np.uint8).reshape(-1, 1)
+
+    @property
+    def z(self):
+        """self.z (model.py:795): posteriors of the last E-step, on demand."""
+        if self._z is None and self._z_which is not None:
+            self._z = self._z_matrix(self._eng.export_z(self._z_which))
+        return self._z
+
+    @z.setter
+    def z(self, value):
+        self._z, self._z_which = value, None
+
+    def _need_raw(self):
+        if self._raw is None:
+            ip, ix, rw = self._eng.export_csr()
+            self._raw = sp.csr_matrix((rw, ix, ip), shape=(self.N, self.K))
+        return self._raw
+
+    def _z_matrix(self, zdata):
+        """Device z (aligned to Q's pattern, -1 = not in z's pattern) -> CSR."""
+        r = self._need_raw()
+        keep = zdata >= 0
+        if keep.all():
+            return sp.csr_matrix((zdata, r.indices.copy(), r.indptr.copy()), shape=r.shape)
+        rows = np.repeat(np.arange(self.N), np.diff(r.indptr))[keep]
+        indptr = np.zeros(self.N + 1, dtype=r.indptr.dtype)
+        np.cumsum(np.bincount(rows, minlength=self.N), out=indptr[1:])
+        return sp.csr_matrix((zdata[keep], r.indices[keep], indptr), shape=r.shape)
+
+    def _align(self, z):
+        """Values of sparse z laid out on Q's CSR pattern (0 where z has no entry)."""
+        r = self._need_raw()
+        z = sp.csr_matrix(z)
+        if z.shape != r.shape:
+            raise ValueError('z has shape %s, expected %s' % (z.shape, r.shape))
+        if z.nnz == r.nnz and np.array_equal(z.indptr, r.indptr) and np.array_equal(z.indices, r.indices):
+            return np.ascontiguousarray(z.data, dtype=np.float64)
+        if not z.has_canonical_format:
+            z = z.copy(); z.sum_duplicates()
+        kq = np.repeat(np.arange(self.N, dtype=np.int64), np.diff(r.indptr)) * self.K + r.indices
+        kz = np.repeat(np.arange(self.N, dtype=np.int64), np.diff(z.indptr)) * self.K + z.indices
+        pos = np.searchsorted(kq, kz)
+        if np.any(pos >= len(kq)) or np.any(kq[np.minimum(pos, len(kq) - 1)] != kz):
+            raise ValueError('z has entries outside the score matrix pattern')
+        out = np.zeros(r.nnz)
+        out[pos] = z.data
+        return out
+
+    # ---- E / M / lnl on explicit arguments (public API) -----------------------------
+    def estep(self, pi, theta):
+        """model.py:702-722."""
+        lg.debug('started e-step')
+        return self._z_matrix(self._eng.estep(pi, theta))
+
+    def mstep(self, z):
+        """model.py:724-742."""
+        lg.debug('started m-step')
+        if self.comm.world > 1:
+            raise NotImplementedError('public mstep(z) is single-rank; em() is the sharded path')
+        return self._eng.mstep(self._align(z))
+
+    def calculate_lnl(self, z, pi, theta):
+        """model.py:744-760."""
+        lg.debug('started lnl')
+        cur = self._eng.calc_lnl(self._align(z), pi, theta)
+        cur = float(self.comm.sum_array(np.array([cur]))[0])
+        lg.debug('completed lnl')
+        return cur
+
+    # ---- EM loop ---------------------------------------------------------------------
+    def em(self, use_likelihood=False, loglev=lg.WARNING, save_memory=True):
+        """model.py:762-806 — same control flow, log lines and final state.
+
+        One fused E+M device pass per iteration; multi-rank runs all-reduce the
+        per-locus column sums between the pass and the parameter update.
+        """
+        inum, converged, reached_max = 0, False, False
+        msgD = 'Iteration {:d}, diff={:.5g}'
+        msgL = 'Iteration {:d}, lnl= {:.5e}, diff={:.5g}'
+        from time import perf_counter
+        eng, comm, K = self._eng, self.comm, self.K
+        while not (converged or reached_max):
+            xtime = perf_counter()
+            eng.em_pass()                       # estep + mstep column sums (local rows)
+            comm.allreduce_device(eng, 0, K)    # sum over ranks (RCCL), no-op single rank
+            diff_est = eng.em_update()          # theta_hat, pi_hat, |pi_hat - pi|_1
+            inum += 1
+            if inum == 1:
+                self.pi_init, self.theta_init = eng.get_params(Z_CUR)
+            if use_likelihood:
+                _lnl = self._device_lnl()
+                diff_lnl = abs(_lnl - self.lnl)
+                lg.log(loglev, msgL.format(inum, _lnl, diff_est))
+                converged = diff_lnl < self.epsilon
+                self.lnl = _lnl
+            else:
+                lg.log(loglev, msgD.format(inum, diff_est))
+                converged = diff_est < self.epsilon
+            reached_max = inum >= self.max_iter
+            lg.debug("time: {}".format(perf_counter() - xtime))
+        self.pi, self.theta = eng.get_params(Z_CUR)
+        self._z, self._z_which = None, Z_PREV   # z of the last E-step, exported on demand
+        _con = 'converged' if converged else 'terminated'
+        if not use_likelihood:
+            self.lnl = self._device_lnl()
+        self.n_iter, self.converged = inum, converged
+        lg.log(loglev, 'EM {:s} after {:d} iterations.'.format(_con, inum))
+        lg.log(loglev, 'Final log-likelihood: {:f}.'.format(self.lnl))
+        return
+
+    def _device_lnl(self):
+        """calculate_lnl(z(prev params), cur params) without moving z (model.py:785,801)."""
+        self._eng.lnl_pass()
+        self.comm.allreduce_device(self._eng, self.K, 1)
+        return float(self._eng.read_reduce(self.K, 1)[0])
+
+    # ---- reassign -------------------------------------------------------------------------
+    def _which(self, initial):
+        if initial:
+            return Z_INITIAL
+        if self._z_which is None:
+            if self._z is None:
+                raise ValueError('reassign() before em(): no posteriors yet')
+            raise NotImplementedError('reassign() on a caller-assigned z is not supported')
+        return self._z_which
+
+    def _picks(self, which):
+        """Random picks for `choose`, drawn exactly like sparse_plus.py:140-154:
+        one draw per row with >1 best hits, in (global) row order, on numpy's
+        legacy global RandomState (seeded by the caller, telescope_assign.py:429-431)."""
+        nbest = self._eng.best_counts(which)
+        parts = self.comm.gather_rows(nbest)
+        if self.comm.rank == 0:
+            allnb = np.concatenate(parts)
+            picks = np.zeros(len(allnb), dtype=np.int32)
+            multi = np.nonzero(allnb > 1)[0]
+            if multi.size:
+                picks[multi] = np.random.randint(0, allnb[multi])
+            cuts = np.cumsum([len(p) for p in parts])[:-1]
+            parts = np.split(picks, cuts)
+        return self.comm.scatter_rows(parts)
+
+    def reassign_colsums(self, method, thresh=0.9, initial=False):
+        """`reassign(...).sum(0).A1` (model.py:435-457) without materialising the mask."""
+        if method not in REASSIGN_METHODS:
+            raise ValueError('Argument "method" should be one of (exclude, choose, average, conf, unique, all)')
+        which = self._which(initial)
+        picks = self._picks(which) if method == 'choose' else None
+        cs, _ = self._eng.reassign(method, thresh, which, picks)
+        cs = self.comm.sum_array(cs)
+        if _MASK_DTYPE[method] != np.float64:
+            cs = np.rint(cs).astype(np.int64)
+        return cs
+
+    def reassign(self, method, thresh=0.9, initial=False):
+        """model.py:808-865 — returns the assignment matrix as a scipy CSR."""
+        if method not in REASSIGN_METHODS:
+            raise ValueError('Argument "method" should be one of (exclude, choose, average, conf, unique, all)')
+        which = self._which(initial)
+        picks = self._picks(which) if method == 'choose' else None
+        _, mask = self._eng.reassign(method, thresh, which, picks, want_mask=True)
+        r = self._need_raw()
+        keep = mask != 0
+        rows = np.repeat(np.arange(self.N), np.diff(r.indptr))[keep]
+        indptr = np.zeros(self.N + 1, dtype=r.indptr.dtype)
+        np.cumsum(np.bincount(rows, minlength=self.N), out=indptr[1:])
+        return sp.csr_matrix((mask[keep].astype(_MASK_DTYPE[method]), r.indices[keep], indptr),
+                             shape=r.shape)
