@@ -77,7 +77,11 @@ int  tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols,
  * synthetic.poisson_cdf_u32(mean).  dist: 0 uniform, 1 zipf.  */
 int  tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_cols,
                    const uint32_t* len_cdf, int32_t cdf_len, uint64_t seed,
-                   int32_t dist, double uniq_frac, const double* lut, int32_t lut_len);
+                   int32_t dist, double uniq_frac);
+/* largest raw score of the local rows; (re)install the Q lookup table once the
+ * GLOBAL maximum is known (model.py:640,653) */
+int  tsem_max_score(tsem_ctx* h, int32_t* max_score);
+int  tsem_set_lut(tsem_ctx* h, const double* lut, int32_t lut_len);
 int  tsem_dims(tsem_ctx* h, int64_t* n_rows, int32_t* n_cols, int64_t* nnz);
 /* copy the CSR back to the host (tests of the generator) */
 int  tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* raw);
@@ -85,11 +89,19 @@ int  tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* r
 /* ---- model setup (model.py:679-699) --------------------------------------
  * tsem_rowstats: Y, weights w_i = max_j Q_ij, and the LOCAL sums
  *   stats[0]=sum w, stats[1]=sum w*Y, stats[2]=max w, pisum0[K] = sum of Q over
- *   unique rows per column.  Multi-GPU hosts all-reduce them (sum,sum,max,sum).
+ *   unique rows per column; col_count[K] = stored entries per column and
+ *   col_hash[K] = order-independent 64-bit signature sum_i hash(global row, score)
+ *   (wrap-around).  Multi-GPU hosts all-reduce them (sum,sum,max,sum,sum,sum).
+ *   Columns with equal (count, hash) are exact twins (same fragments, same
+ *   scores): the reference keeps their pi/theta bit-identical because scipy
+ *   accumulates every column in row order, and `reassign` ties depend on it, so
+ *   the update step gives twins one shared accumulation.
  * tsem_set_model: global stats + priors; builds the column-partitioned EM
  *   layout and resets pi = theta = 1/K (model.py:667,673).  */
-int  tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0);
+int  tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0,
+                   uint64_t* col_count, uint64_t* col_hash);
 int  tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0,
+                    const uint64_t* col_count, const uint64_t* col_hash,
                     double pi_prior, double theta_prior);
 
 /* ---- parameters ---------------------------------------------------------- */
@@ -150,7 +162,7 @@ int  tsem_csr_binmax_rows(int device, int64_t n_rows, int32_t n_cols, const int6
  * last call with reset=1; algorithmic bytes one EM pass reads.  */
 int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launches,
                        int64_t* algo_bytes_per_pass);
-int  tsem_layout_info(tsem_ctx* h, int64_t* info8);
+int  tsem_layout_info(tsem_ctx* h, int64_t* info12);
 
 #ifdef __cplusplus
 }

@@ -76,11 +76,13 @@ def lib():
     L.tsem_set_option.argtypes = [vp, C.c_char_p, i64]
     L.tsem_synchronize.argtypes = [vp]
     L.tsem_load_scores.argtypes = [vp, i64, i32, vp, vp, vp, vp, i32]
-    L.tsem_generate.argtypes = [vp, i64, i64, i32, vp, i32, u64, i32, dbl, vp, i32]
+    L.tsem_generate.argtypes = [vp, i64, i64, i32, vp, i32, u64, i32, dbl]
+    L.tsem_max_score.argtypes = [vp, C.POINTER(i32)]
+    L.tsem_set_lut.argtypes = [vp, vp, i32]
     L.tsem_dims.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]
     L.tsem_export_csr.argtypes = [vp, vp, vp, vp]
-    L.tsem_rowstats.argtypes = [vp, vp, vp]
-    L.tsem_set_model.argtypes = [vp, vp, vp, dbl, dbl]
+    L.tsem_rowstats.argtypes = [vp, vp, vp, vp, vp]
+    L.tsem_set_model.argtypes = [vp, vp, vp, vp, vp, dbl, dbl]
     L.tsem_set_params.argtypes = [vp, vp, vp]
     L.tsem_get_params.argtypes = [vp, C.c_int, vp, vp]
     L.tsem_reduce_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
@@ -161,11 +163,19 @@ class Engine(object):
         self._ck(self._L.tsem_load_scores(self._h, len(indptr) - 1, int(n_cols), ptr(indptr), ptr(indices),
                                           ptr(raw), ptr(lut), len(lut)))
 
-    def generate(self, row_begin, row_end, n_cols, len_cdf, seed, dist, uniq_frac, lut):
+    def generate(self, row_begin, row_end, n_cols, len_cdf, seed, dist, uniq_frac):
         len_cdf = np.ascontiguousarray(len_cdf, dtype=np.uint32)
-        lut = np.ascontiguousarray(lut, dtype=np.float64)
         self._ck(self._L.tsem_generate(self._h, int(row_begin), int(row_end), int(n_cols), ptr(len_cdf),
-                                       len(len_cdf), int(seed), int(dist), float(uniq_frac), ptr(lut), len(lut)))
+                                       len(len_cdf), int(seed), int(dist), float(uniq_frac)))
+
+    def max_score(self):
+        m = C.c_int32()
+        self._ck(self._L.tsem_max_score(self._h, C.byref(m)))
+        return m.value
+
+    def set_lut(self, lut):
+        lut = np.ascontiguousarray(lut, dtype=np.float64)
+        self._ck(self._L.tsem_set_lut(self._h, ptr(lut), len(lut)))
 
     def dims(self):
         n, k, z = C.c_int64(), C.c_int32(), C.c_int64()
@@ -184,13 +194,17 @@ class Engine(object):
     def rowstats(self):
         _, k, _ = self.dims()
         stats, pisum0 = np.zeros(3), np.zeros(k)
-        self._ck(self._L.tsem_rowstats(self._h, ptr(stats), ptr(pisum0)))
-        return stats, pisum0
+        cnt, hsh = np.zeros(k, np.uint64), np.zeros(k, np.uint64)
+        self._ck(self._L.tsem_rowstats(self._h, ptr(stats), ptr(pisum0), ptr(cnt), ptr(hsh)))
+        return stats, pisum0, cnt, hsh
 
-    def set_model(self, stats, pisum0, pi_prior, theta_prior):
+    def set_model(self, stats, pisum0, col_count, col_hash, pi_prior, theta_prior):
         stats = np.ascontiguousarray(stats, dtype=np.float64)
         pisum0 = np.ascontiguousarray(pisum0, dtype=np.float64)
-        self._ck(self._L.tsem_set_model(self._h, ptr(stats), ptr(pisum0), float(pi_prior), float(theta_prior)))
+        col_count = np.ascontiguousarray(col_count, dtype=np.uint64)
+        col_hash = np.ascontiguousarray(col_hash, dtype=np.uint64)
+        self._ck(self._L.tsem_set_model(self._h, ptr(stats), ptr(pisum0), ptr(col_count), ptr(col_hash),
+                                        float(pi_prior), float(theta_prior)))
 
     def set_params(self, pi, theta):
         pi = np.ascontiguousarray(pi, dtype=np.float64)
@@ -298,9 +312,10 @@ class Engine(object):
         return dict(em_ms=ms.value, em_launches=n.value, algo_bytes_per_pass=b.value)
 
     def layout_info(self):
-        info = np.zeros(8, np.int64)
+        info = np.zeros(12, np.int64)
         self._ck(self._L.tsem_layout_info(self._h, ptr(info)))
-        return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad'), info.tolist()))
+        return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad', 'twin_cols',
+                         'G1', 'G2'), info.tolist()))
 
 
 def csr_norm_rows(indptr, data, device=0):

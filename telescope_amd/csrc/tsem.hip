@@ -200,27 +200,37 @@ __global__ void k_compact_rows(int64_t N, const uint8_t* __restrict__ cls, const
   else if (cls[i] == 1) { int u = suni[i]; int64_t s = indptr[i]; uni_col[u] = indices[s]; uni_code[u] = raw[s]; }
 }
 
-// column histogram over ambiguous rows' entries, LDS-privatised window of WIN bins
-constexpr int HIST_WIN = 32768;
-__global__ __launch_bounds__(1024) void k_col_hist(int64_t N_amb, const int32_t* __restrict__ amb_row,
-    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int col_base, int K,
-    unsigned long long* __restrict__ counts) {
+// per-column entry count and order-independent signature sum_i hash(row_i, raw_ij)
+// over ALL rows, LDS-privatised over a window of SIG_WIN columns per sweep.
+// Counts order columns by popularity; (count, hash) identifies exact twin
+// columns (same rows, same scores) whose parameters the reference keeps
+// bit-identical (it accumulates every column in row order).
+constexpr int SIG_WIN = 8192;
+__global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw, int col_base, int K,
+    unsigned long long* __restrict__ counts, unsigned long long* __restrict__ hashes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* h = reinterpret_cast<uint32_t*>(smem);
-  for (int t = threadIdx.x; t < HIST_WIN; t += blockDim.x) h[t] = 0;
+  unsigned long long* hh = reinterpret_cast<unsigned long long*>(smem);
+  uint32_t* hc = reinterpret_cast<uint32_t*>(hh + SIG_WIN);
+  for (int t = threadIdx.x; t < SIG_WIN; t += blockDim.x) { hh[t] = 0; hc[t] = 0; }
   __syncthreads();
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
-  for (int64_t a = (int64_t)blockIdx.x * subs + sub; a < N_amb; a += (int64_t)gridDim.x * subs) {
-    int64_t i = amb_row[a];
+  for (int64_t i = (int64_t)blockIdx.x * subs + sub; i < N; i += (int64_t)gridDim.x * subs) {
     int64_t s = indptr[i], e = indptr[i + 1];
     for (int64_t k = s + lane; k < e; k += RS_SUB) {
       int c = indices[k] - col_base;
-      if (c >= 0 && c < HIST_WIN) atomicAdd(&h[c], 1u);
+      if (c >= 0 && c < SIG_WIN) {
+        atomicAdd(&hc[c], 1u);
+        atomicAdd(&hh[c], (unsigned long long)ts_hash3(0x7715ull, (uint64_t)(row_offset + i), (uint64_t)raw[k]));
+      }
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < HIST_WIN; t += blockDim.x)
-    if (h[t] && col_base + t < K) atomicAdd(&counts[col_base + t], (unsigned long long)h[t]);
+  for (int t = threadIdx.x; t < SIG_WIN; t += blockDim.x)
+    if (hc[t] && col_base + t < K) {
+      atomicAdd(&counts[col_base + t], (unsigned long long)hc[t]);
+      atomicAdd(&hashes[col_base + t], hh[t]);
+    }
 }
 
 // per (row block, part) entry counts — one WG per block
@@ -421,11 +431,19 @@ __global__ __launch_bounds__(1024) void k_update(int K, const double* __restrict
     const double* __restrict__ pisum0, double theta_pw, double theta_den, double pi_pw, double pi_den,
     double* __restrict__ pi, double* __restrict__ theta, double* __restrict__ pi_prev,
     double* __restrict__ theta_prev, const uint32_t* __restrict__ colmap, int Kp,
-    double* __restrict__ ctab, double* __restrict__ ctab_prev, double* __restrict__ diff_out) {
+    double* __restrict__ ctab, double* __restrict__ ctab_prev, const int32_t* __restrict__ twin_rep,
+    double* __restrict__ diff_out) {
   __shared__ double scratch[16];
   double d = 0.0;
   for (int j = threadIdx.x; j < K; j += blockDim.x) {
+    // exact twin columns share one accumulation (see k_colsig) as long as their
+    // sums agree to rounding, i.e. their parameters are still symmetric
+    const int jr = twin_rep[j];
     double ts = red[j];
+    if (jr != j) {
+      double tr = red[jr];
+      if (fabs(ts - tr) <= 1e-12 * fmax(fabs(ts), fabs(tr))) ts = tr;
+    }
     double th = (ts + theta_pw) / theta_den;
     double ps = pisum0[j] + ts;
     double ph = (ps + pi_pw) / pi_den;
@@ -677,7 +695,7 @@ static void free_layout(tsem_ctx* h) {
 static void free_matrix(tsem_ctx* h) {
   dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_raw); dfree(h->d_lut);
   dfree(h->d_amb_row); dfree(h->d_amb_wcode); dfree(h->d_uni_col); dfree(h->d_uni_code);
-  dfree(h->d_pisum0);
+  dfree(h->d_pisum0); dfree(h->d_twin_rep);
   free_layout(h);
   dfree(h->d_pi); dfree(h->d_theta); dfree(h->d_pi_prev); dfree(h->d_theta_prev);
   dfree(h->d_ctab); dfree(h->d_ctab_prev); dfree(h->d_red_own); dfree(h->d_tmp_pi); dfree(h->d_tmp_theta);
@@ -741,6 +759,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   if (k == "em_kernel") h->em_kernel = (int)v;
   else if (k == "block_rows") h->opt_R = v;
   else if (k == "parts") h->opt_P = v;
+  else if (k == "row_offset") h->row_offset = v;
   else TSEM_FAIL(TSEM_ERR_ARG, "unknown option " + k);
   return TSEM_OK;
 }
@@ -790,16 +809,13 @@ int tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols, const int64_t*
 }
 
 int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_cols, const uint32_t* len_cdf,
-                  int32_t cdf_len, uint64_t seed, int32_t dist, double uniq_frac, const double* lut,
-                  int32_t lut_len) {
+                  int32_t cdf_len, uint64_t seed, int32_t dist, double uniq_frac) {
   if (!h) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
   int64_t n = row_end - row_begin;
   if (n < 0 || n_cols < 2 || !len_cdf || cdf_len <= 0) TSEM_FAIL(TSEM_ERR_ARG, "bad generator arguments");
   if (n >= (int64_t)INT32_MAX) TSEM_FAIL(TSEM_ERR_ARG, "more than 2^31-1 rows per rank is not supported");
-  if (lut_len < 301) TSEM_FAIL(TSEM_ERR_ARG, "lut must cover scores up to 300");
   free_matrix(h);
-  if (int rc = set_lut(h, lut, lut_len)) return rc;
   h->N = n; h->K = n_cols;
   uint32_t* d_cdf = nullptr;
   TSEM_ALLOC(d_cdf, cdf_len);
@@ -835,6 +851,36 @@ int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_col
   return TSEM_OK;
 }
 
+__global__ void k_max_u16(const uint16_t* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
+  uint32_t m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, (uint32_t)v[i]);
+  m = (uint32_t)sg_max_i<64>((int)m);
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+int tsem_max_score(tsem_ctx* h, int32_t* max_score) {
+  if (!h || !h->d_indptr || !max_score) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
+  if (h->nnz) k_max_u16<<<1024, 256, 0, h->stream>>>(h->d_raw, h->nnz, h->d_maxcode);
+  uint32_t m = 0;
+  TSEM_HIP(hipMemcpyAsync(&m, h->d_maxcode, 4, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  *max_score = (int32_t)m;
+  return TSEM_OK;
+}
+
+int tsem_set_lut(tsem_ctx* h, const double* lut, int32_t lut_len) {
+  if (!h || !h->d_indptr) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  int32_t m = 0;
+  if (int rc = tsem_max_score(h, &m)) return rc;
+  if (m >= lut_len) TSEM_FAIL(TSEM_ERR_ARG, "lookup table shorter than the largest raw score");
+  h->have_rowstats = h->have_model = false;
+  return set_lut(h, lut, lut_len);
+}
+
 int tsem_dims(tsem_ctx* h, int64_t* n_rows, int32_t* n_cols, int64_t* nnz) {
   if (!h) return TSEM_ERR_ARG;
   if (n_rows) *n_rows = h->N;
@@ -856,7 +902,7 @@ int tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* ra
 // ---------------------------------------------------------------------------
 // rowstats: classes, weights, local sums; compacts ambiguous / unique rows
 // ---------------------------------------------------------------------------
-int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0) {
+int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_count, uint64_t* col_hash) {
   if (!h || !h->d_indptr) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
   const int64_t N = h->N;
@@ -884,6 +930,25 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0) {
   if (stats3) { stats3[0] = wt; stats3[1] = wa; stats3[2] = (N && h->nnz) ? h->lut_host[maxcode] : 0.0; }
   if (pisum0) TSEM_HIP(hipMemcpy(pisum0, h->d_pisum0, sizeof(double) * K, hipMemcpyDeviceToHost));
 
+  // column signatures (popularity + twin detection)
+  if (col_count && col_hash) {
+    unsigned long long *d_cnt = nullptr, *d_hash = nullptr;
+    TSEM_ALLOC(d_cnt, K); TSEM_ALLOC(d_hash, K);
+    TSEM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * K, h->stream));
+    TSEM_HIP(hipMemsetAsync(d_hash, 0, sizeof(unsigned long long) * K, h->stream));
+    if (N) {
+      const int lds = SIG_WIN * 12;
+      TSEM_HIP(hipFuncSetAttribute((const void*)k_colsig, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      int g2 = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, (N + 63) / 64));
+      for (int base = 0; base < K; base += SIG_WIN)
+        k_colsig<<<g2, 1024, lds, h->stream>>>(N, h->row_offset, h->d_indptr, h->d_indices, h->d_raw, base, K, d_cnt, d_hash);
+      TSEM_HIP(hipGetLastError());
+    }
+    TSEM_HIP(hipMemcpyAsync(col_count, d_cnt, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(col_hash, d_hash, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_cnt); (void)hipFree(d_hash);
+  }
   // compact ambiguous and unique rows
   TSEM_ALLOC(d_fa, N + 1); TSEM_ALLOC(d_fu, N + 1);
   int32_t na = 0, nu = 0;
@@ -930,25 +995,9 @@ static int build_layout(tsem_ctx* h) {
   const int K = h->K;
   const int64_t na = h->N_amb;
   free_layout(h);
-  // 1. column popularity over ambiguous rows
-  std::vector<unsigned long long> counts(K, 0);
-  {
-    unsigned long long* d_cnt = nullptr;
-    TSEM_ALLOC(d_cnt, K);
-    TSEM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * K, h->stream));
-    if (na) {
-      TSEM_HIP(hipFuncSetAttribute((const void*)k_col_hist, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_WIN * 4));
-      int grid = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, (na + 63) / 64));
-      for (int base = 0; base < K; base += HIST_WIN)
-        k_col_hist<<<grid, 1024, HIST_WIN * 4, h->stream>>>(na, h->d_amb_row, h->d_indptr, h->d_indices, base, K, d_cnt);
-      TSEM_HIP(hipGetLastError());
-    }
-    TSEM_HIP(hipMemcpyAsync(counts.data(), d_cnt, sizeof(unsigned long long) * K, hipMemcpyDeviceToHost, h->stream));
-    TSEM_HIP(hipStreamSynchronize(h->stream));
-    (void)hipFree(d_cnt);
-  }
   h->nnz_amb = 0;
-  for (int j = 0; j < K; ++j) h->nnz_amb += (int64_t)counts[j];
+  // 1. column popularity: global entry counts handed in by set_model
+  const std::vector<uint64_t>& counts = h->col_count;
   // 2. parts: deal columns by popularity so every part carries ~equal nnz
   int P = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP - 1) / TS_MAX_KP;
   if (P < 1) P = 1;
@@ -985,7 +1034,7 @@ static int build_layout(tsem_ctx* h) {
     (void)hipFree(d_cnt);
   }
   int64_t off = 0;
-  for (int64_t i = 0; i < nb * P; ++i) { int64_t c = (sb[i] + 3) & ~3ll; sb[i] = off; off += c; }
+  for (int64_t i = 0; i < nb * P; ++i) { h->nnz_amb += sb[i]; int64_t c = (sb[i] + 3) & ~3ll; sb[i] = off; off += c; }
   sb[nb * P] = off;
   h->nnz_pad = off;
   TSEM_ALLOC(h->d_sb_off, nb * P + 1);
@@ -1015,13 +1064,43 @@ static int build_layout(tsem_ctx* h) {
   return TSEM_OK;
 }
 
-int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, double pi_prior, double theta_prior) {
-  if (!h || !h->have_rowstats || !stats3 || !pisum0) return TSEM_ERR_ARG;
+int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, const uint64_t* col_count,
+                   const uint64_t* col_hash, double pi_prior, double theta_prior) {
+  if (!h || !h->have_rowstats || !stats3 || !pisum0 || !col_count || !col_hash) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
   const int K = h->K;
+  h->col_count.assign(col_count, col_count + K);
+  {  // exact twin columns -> representative = smallest column index of the class
+    std::vector<int> ord(K);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) {
+      if (col_count[a] != col_count[b]) return col_count[a] < col_count[b];
+      if (col_hash[a] != col_hash[b]) return col_hash[a] < col_hash[b];
+      return a < b;
+    });
+    std::vector<int32_t> rep(K);
+    h->n_twin_cols = 0;
+    for (int i = 0; i < K;) {
+      int j = i;
+      while (j + 1 < K && col_count[ord[j + 1]] == col_count[ord[i]] && col_hash[ord[j + 1]] == col_hash[ord[i]]) ++j;
+      for (int t = i; t <= j; ++t) rep[ord[t]] = (col_count[ord[i]] == 0) ? ord[t] : ord[i];
+      if (j > i && col_count[ord[i]] != 0) h->n_twin_cols += (j - i + 1);
+      i = j + 1;
+    }
+    TSEM_ALLOC(h->d_twin_rep, K);
+    TSEM_HIP(hipMemcpy(h->d_twin_rep, rep.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice));
+    h->twin_rep_host = rep;
+  }
   h->W_tot = stats3[0]; h->W_amb = stats3[1]; h->w_max = stats3[2];
   h->pi_prior = pi_prior; h->theta_prior = theta_prior;
-  TSEM_HIP(hipMemcpy(h->d_pisum0, pisum0, sizeof(double) * K, hipMemcpyHostToDevice));
+  {
+    std::vector<double> ps(pisum0, pisum0 + K);
+    for (int j = 0; j < K; ++j) {   // twins: identical unique-row sums up to atomics order
+      int r = h->twin_rep_host[j];
+      if (r != j && std::fabs(ps[j] - ps[r]) <= 1e-12 * std::max(std::fabs(ps[j]), std::fabs(ps[r]))) ps[j] = ps[r];
+    }
+    TSEM_HIP(hipMemcpy(h->d_pisum0, ps.data(), sizeof(double) * K, hipMemcpyHostToDevice));
+  }
   if (int rc = build_layout(h)) return rc;
   TSEM_ALLOC(h->d_pi, K); TSEM_ALLOC(h->d_theta, K); TSEM_ALLOC(h->d_pi_prev, K); TSEM_ALLOC(h->d_theta_prev, K);
   TSEM_ALLOC(h->d_tmp_pi, K); TSEM_ALLOC(h->d_tmp_theta, K);
@@ -1142,7 +1221,7 @@ static int launch_update(tsem_ctx* h, double* d_diff_slot) {
   const double tden = h->W_amb + tpw * h->K, pden = h->W_tot + ppw * h->K;      // model.py:732,738
   k_update<<<1, 1024, 0, h->stream>>>(h->K, h->d_red, h->d_pisum0, tpw, tden, ppw, pden, h->d_pi, h->d_theta,
                                       h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab, h->d_ctab_prev,
-                                      d_diff_slot);
+                                      h->d_twin_rep, d_diff_slot);
   TSEM_HIP(hipGetLastError());
   return TSEM_OK;
 }
@@ -1443,6 +1522,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   if (!h || !info) return TSEM_ERR_ARG;
   info[0] = h->P; info[1] = h->Kp; info[2] = h->R; info[3] = h->nb;
   info[4] = h->N_amb; info[5] = h->N_uni; info[6] = h->nnz_amb; info[7] = h->nnz_pad;
+  info[8] = h->n_twin_cols; info[9] = h->G1; info[10] = h->G2; info[11] = 0;
   return TSEM_OK;
 }
 

@@ -75,6 +75,11 @@ struct tsem_ctx {
   // ---- model scalars (GLOBAL after set_model) ----
   double W_tot = 0, W_amb = 0, w_max = 0, pi_prior = 0, theta_prior = 0;
   double* d_pisum0 = nullptr;  // [K]
+  int32_t* d_twin_rep = nullptr;  // [K] representative column of each exact-twin class
+  std::vector<uint64_t> col_count;  // global entries per column
+  std::vector<int32_t> twin_rep_host;
+  int64_t row_offset = 0;      // global index of this rank's first row
+  int n_twin_cols = 0;
   bool have_model = false;
 
   // ---- column partition + blocked COO layout of ambiguous rows ----

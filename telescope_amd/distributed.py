@@ -1,0 +1,137 @@
+"""Row-sharded EM across GPUs: one process per GPU, torch.distributed plumbing.
+
+Fragments (rows) are independent given (pi, theta), so each rank owns a
+contiguous row range of the score matrix.  Exchange steps:
+
+  setup      max  : largest raw score (Q depends on the GLOBAL max, model.py:640,653)
+             sum  : total/ambiguous weight, pisum0[K]           (model.py:691-699)
+             max  : largest fragment weight                       (model.py:696-697)
+             sum  : column signatures (u64 wrap-around)           (twin detection)
+  every iter sum  : per-locus column sums thetasum[K]             (model.py:731)
+                    -> ONE all-reduce of K doubles (240 KB at K=30k) on RCCL/xGMI
+  lnl        sum  : one scalar
+  reassign   sum  : K-vector per mode; `choose` gathers best-hit counts to
+                    rank 0, which alone consumes the legacy RNG stream.
+
+backend "nccl" is RCCL on ROCm; "gloo" runs the same host logic on CPU tensors
+(tests/test_distributed_gloo.py).  torch is plumbing only: it owns the reduce
+tensor and the process group; all arithmetic is in libtelescope_em.so.
+"""
+import os
+
+import numpy as np
+
+
+def shard_bounds(n_rows, world, rank=None, indptr=None):
+    """Contiguous row ranges, balanced by nnz when `indptr` is given."""
+    if indptr is None:
+        cuts = [(n_rows * r) // world for r in range(world + 1)]
+    else:
+        nnz = int(indptr[-1])
+        targets = [(nnz * r) // world for r in range(1, world)]
+        cuts = [0] + [int(np.searchsorted(indptr, t, side='left')) for t in targets] + [n_rows]
+        cuts = [min(max(c, 0), n_rows) for c in cuts]
+        for i in range(1, len(cuts)):
+            cuts[i] = max(cuts[i], cuts[i - 1])
+    if rank is None:
+        return cuts
+    return cuts[rank], cuts[rank + 1]
+
+
+class Comm(object):
+    """Thin wrapper over an initialised torch.distributed process group."""
+
+    def __init__(self, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self._torch, self._dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        if self.backend == 'nccl':
+            self.device = int(os.environ.get('LOCAL_RANK', 0)) if device is None else device
+            self.tdev = torch.device('cuda', self.device)
+            torch.cuda.set_device(self.device)
+        else:
+            self.device = 0 if device is None else device
+            self.tdev = torch.device('cpu')
+        self._red = None
+        self._eng = None
+
+    # ---- small host-side collectives (setup / reporting) --------------------
+    def _allreduce_np(self, a, op, dtype):
+        t = self._torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.tdev)
+        self._dist.all_reduce(t, op=op, group=self.group)
+        return t.cpu().numpy()
+
+    def max_scalar(self, v):
+        return int(self._allreduce_np(np.array([v], np.int64), self._dist.ReduceOp.MAX,
+                                      self._torch.int64)[0])
+
+    def sum_array(self, a):
+        return self._allreduce_np(np.asarray(a, np.float64), self._dist.ReduceOp.SUM,
+                                  self._torch.float64)
+
+    def max_array(self, a):
+        return self._allreduce_np(np.asarray(a, np.float64), self._dist.ReduceOp.MAX,
+                                  self._torch.float64)
+
+    def sum_array_u64(self, a):
+        """Wrap-around integer sums (two's complement int64 == uint64 mod 2^64)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)
+        out = self._allreduce_np(a, self._dist.ReduceOp.SUM, self._torch.int64)
+        return out.view(np.uint64)
+
+    def gather_rows(self, a):
+        parts = [None] * self.world
+        self._dist.all_gather_object(parts, np.asarray(a), group=self.group)
+        return parts
+
+    def scatter_rows(self, parts):
+        out = [None]
+        self._dist.scatter_object_list(out, list(parts) if self.rank == 0 else None, src=0,
+                                       group=self.group)
+        return out[0]
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+    # ---- the per-iteration exchange ---------------------------------------------
+    def attach(self, engine, n_cols):
+        """Give the engine a reduce buffer that torch can all-reduce in place, and
+        make the engine launch on torch's current stream so the collective is
+        ordered after the EM pass without a host sync."""
+        t = self._torch
+        self._red = t.zeros(n_cols + 2, dtype=t.float64, device=self.tdev)
+        self._eng = engine
+        engine.bind_reduce_buffer(self._red.data_ptr(), n_cols + 2)
+        if self.backend == 'nccl':
+            engine.set_stream(t.cuda.current_stream(self.tdev).cuda_stream)
+
+    def allreduce_device(self, engine, offset=0, count=None):
+        if self.world == 1:
+            return
+        red = self._red if count is None else self._red[offset:offset + count]
+        self._dist.all_reduce(red, op=self._dist.ReduceOp.SUM, group=self.group)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (RANK, WORLD_SIZE,
+    LOCAL_RANK, MASTER_ADDR/PORT) and return a Comm; None when single-process."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        kw = {}
+        if backend == 'nccl':
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend=backend, **kw)
+    return Comm(device=local)

@@ -51,6 +51,12 @@ class _NullComm(object):
     def max_array(self, a):
         return a
 
+    def sum_array_u64(self, a):
+        return a
+
+    def attach(self, engine, n_cols):
+        pass
+
     def allreduce_device(self, engine, offset=0, count=None):
         pass
 
@@ -96,31 +102,36 @@ class TelescopeLikelihood(object):
         self._setup_model()
 
     @classmethod
-    def from_engine(cls, engine, n_cols, max_score, opts, comm=None):
-        """Wrap an engine whose matrix is already resident (device-generated)."""
+    def from_engine(cls, engine, opts, comm=None):
+        """Wrap an engine whose score matrix is already resident (device-generated)."""
         self = cls.__new__(cls)
         self.comm = comm if comm is not None else _NullComm()
         self.raw_scores = self._raw = None
         self._eng = engine
         self.N, self.K, _ = engine.dims()
-        self.max_score, self.scale_factor = max_score, 100.
-        self._lut = score_lut(max_score)
+        self.max_score = self.comm.max_scalar(engine.max_score())   # model.py:640 (global)
+        self.scale_factor = 100.
+        self._lut = score_lut(self.max_score) if self.max_score > 0 else np.zeros(1)
+        engine.set_lut(self._lut)
         self.epsilon, self.max_iter = opts.em_epsilon, opts.max_iter
         self.pi_prior, self.theta_prior = opts.pi_prior, opts.theta_prior
         self._setup_model()
         return self
 
     def _setup_model(self):
-        stats, pisum0 = self._eng.rowstats()                         # model.py:679-699 (local)
+        self.comm.attach(self._eng, self.K)
+        stats, pisum0, cnt, hsh = self._eng.rowstats()               # model.py:679-699 (local)
         sums = self.comm.sum_array(np.concatenate([stats[:2], pisum0]))
         wmax = self.comm.max_array(stats[2:3])
+        sig = self.comm.sum_array_u64(np.concatenate([cnt, hsh]))    # wrap-around integer sums
+        cnt, hsh = sig[:self.K], sig[self.K:]
         self._total_wt, self._ambig_wt = float(sums[0]), float(sums[1])
         self._max_wt = float(wmax[0])
         self._pisum0 = np.asarray(sums[2:])
         self._pi_prior_wt = self.pi_prior * self._max_wt             # model.py:696-697
         self._theta_prior_wt = self.theta_prior * self._max_wt
         self._eng.set_model(np.array([self._total_wt, self._ambig_wt, self._max_wt]),
-                            self._pisum0, self.pi_prior, self.theta_prior)
+                            self._pisum0, cnt, hsh, self.pi_prior, self.theta_prior)
         self.pi = np.repeat(1. / self.K, self.K)                     # model.py:667
         self.theta = np.repeat(1. / self.K, self.K)                  # model.py:673
         self.pi_init = self.theta_init = None
