@@ -1,0 +1,251 @@
+"""Parity tests proper: the HIP path (through the C ABI) against golden vectors
+captured from the reference, against the oracle on seeded inputs, and — at
+BASELINE.json's sizes — through size-independent properties.
+
+Tolerances.  north_star: final log-likelihood and per-locus counts within 1e-4
+relative, integer reassign outputs bit-exact.  Everything is fp64 on the
+device, so the float checks below use RTOL = 1e-9 (five orders tighter than
+the bar); integer outputs are compared with array_equal."""
+import logging
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import Opts, case_matrix, case_names, load_case
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+INT_METHODS = ('exclude', 'choose', 'unique', 'all')
+ALL_METHODS = ('exclude', 'choose', 'average', 'conf', 'unique', 'all')
+
+
+def make_tl(raw, opts, **kw):
+    from telescope_amd.likelihood import TelescopeLikelihood
+    return TelescopeLikelihood(raw, opts, **kw)
+
+
+def run_case(name, em_kernel=None, block_rows=None):
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import TelescopeLikelihood
+    c = load_case(name)
+    raw = case_matrix(c)
+    o = Opts(c)
+    if em_kernel is None and block_rows is None:
+        tl = TelescopeLikelihood(raw, o)
+    else:
+        eng = _lib.Engine(0)
+        if em_kernel is not None:
+            eng.set_option('em_kernel', em_kernel)
+        if block_rows is not None:
+            eng.set_option('block_rows', block_rows)
+        lut_max = int(raw.data.max())
+        from telescope_amd.likelihood import score_lut
+        eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), raw.shape[1], score_lut(lut_max))
+        tl = TelescopeLikelihood.from_engine(eng, o)
+        tl._raw = sp.csr_matrix(raw)
+    msgs = []
+
+    class H(logging.Handler):
+        def emit(self, rec):
+            msgs.append(rec.getMessage())
+    lg = logging.getLogger(); h = H(); lg.addHandler(h); old = lg.level; lg.setLevel(logging.INFO)
+    try:
+        tl.em(use_likelihood=bool(c['use_likelihood']), loglev=logging.INFO)
+    finally:
+        lg.removeHandler(h); lg.setLevel(old)
+    return c, raw, tl, msgs
+
+
+@pytest.mark.parametrize('name', case_names())
+def test_em_matches_reference(gpu_device, name):
+    c, raw, tl, msgs = run_case(name)
+    assert tl.n_iter == int(c['n_iter'])
+    assert tl.converged == bool(c['converged'])
+    assert abs(tl.lnl - float(c['lnl'])) <= RTOL * abs(float(c['lnl']))
+    assert np.allclose(tl.pi, c['pi'], rtol=RTOL, atol=0)
+    assert np.allclose(tl.theta, c['theta'], rtol=RTOL, atol=0)
+    assert np.allclose(tl.pi_init, c['pi_init'], rtol=RTOL, atol=0)
+    assert np.allclose(tl.theta_init, c['theta_init'], rtol=RTOL, atol=0)
+    # log lines (model.py:767-768,804-805): same count, same text up to the printed precision
+    ref = list(c['log_lines'])
+    assert len(msgs) == len(ref)
+    assert msgs[-2] == ref[-2]                       # 'EM converged|terminated after N iterations.'
+    assert msgs[-1] == ref[-1]                       # 'Final log-likelihood: %f.'
+    import re
+    num = re.compile(r'[-+]?\d+\.?\d*(?:e[-+]?\d+)?')
+    for a, b in zip(msgs[:-2], ref[:-2]):            # 'Iteration N, [lnl= x,] diff=y'
+        va, vb = [float(x) for x in num.findall(a)], [float(x) for x in num.findall(b)]
+        assert len(va) == len(vb) and va[0] == vb[0]
+        # diffs below ~1e-10 are summation-order noise of |pi_hat - pi|_1 in BOTH implementations
+        assert np.allclose(va[1:], vb[1:], rtol=2e-4, atol=1e-11), (a, b)
+
+
+@pytest.mark.parametrize('name', case_names())
+def test_reassign_colsums_match_reference(gpu_device, name):
+    c, raw, tl, _ = run_case(name)
+    for initial in (False, True):
+        for meth in ALL_METHODS:
+            np.random.seed(int(c['seed']))
+            got = tl.reassign_colsums(meth, 0.9, initial)
+            ref = c['ra_%s_%d_colsum' % (meth, int(initial))]
+            if meth in INT_METHODS:
+                assert np.array_equal(got, ref), (meth, initial)
+            else:
+                assert np.allclose(got, ref, rtol=RTOL, atol=1e-12), (meth, initial)
+    got = tl.reassign_colsums('conf', 0.3)
+    assert np.allclose(got, c['ra_conf03_0_colsum'], rtol=RTOL, atol=1e-12)
+
+
+def test_report_columns_in_output_report_order(gpu_device):
+    """model.py:432-457: the RNG is consumed by init_best_random BEFORE the final mode."""
+    c, raw, tl, _ = run_case('bundled')
+    np.random.seed(int(c['seed']))
+    got = dict(
+        final_conf=tl.reassign_colsums('conf', 0.9),
+        init_aligned=tl.reassign_colsums('all', initial=True),
+        unique_count=tl.reassign_colsums('unique'),
+        init_best=tl.reassign_colsums('exclude', initial=True),
+        init_best_random=tl.reassign_colsums('choose', initial=True),
+        init_best_avg=tl.reassign_colsums('average', initial=True),
+        final_count=tl.reassign_colsums('exclude', 0.9))
+    for k, v in got.items():
+        assert np.allclose(v, c['report_' + k], rtol=RTOL, atol=1e-12), k
+    assert got['final_count'][np.argmax(c['pi'])] == 1000 and got['init_best'][np.argmax(c['pi'])] == 326
+
+
+@pytest.mark.parametrize('name', case_names(full_only=True))
+def test_z_and_masks_match_reference(gpu_device, name):
+    c, raw, tl, _ = run_case(name)
+    z = sp.csr_matrix(tl.z)
+    assert np.array_equal(z.indptr, c['z_indptr']) and np.array_equal(z.indices, c['z_indices'])
+    assert np.allclose(z.data, c['z_data'], rtol=RTOL, atol=1e-300)
+    for initial in (False, True):
+        for meth in ALL_METHODS:
+            np.random.seed(int(c['seed']))
+            m = sp.csr_matrix(tl.reassign(meth, 0.9, initial))
+            tag = 'ra_%s_%d_' % (meth, int(initial))
+            ref = sp.csr_matrix((c[tag + 'data'], c[tag + 'indices'], c[tag + 'indptr']), shape=raw.shape)
+            assert str(m.dtype) == str(c[tag + 'dtype'])
+            if meth in INT_METHODS:
+                assert (m != ref).nnz == 0, (meth, initial)
+            else:
+                assert abs(m - ref).max() <= 1e-12 if ref.nnz or m.nnz else True
+
+
+@pytest.mark.parametrize('name', ['bundled', 'tiny_ties', 'tiny_wide_range', 'tiny_twins', 'tiny_priors'])
+def test_public_estep_mstep_lnl(gpu_device, name):
+    """estep/mstep/calculate_lnl keep their signatures (model.py:702-760); params with
+    exact zeros drop entries from z's pattern like scipy's CSR addition."""
+    c = load_case(name)
+    raw = case_matrix(c)
+    tl = make_tl(raw, Opts(c))
+    pi, theta = c['x_pi'], c['x_theta']
+    z = sp.csr_matrix(tl.estep(pi, theta))
+    assert np.array_equal(z.indptr, c['x_z_indptr']) and np.array_equal(z.indices, c['x_z_indices'])
+    assert np.allclose(z.data, c['x_z_data'], rtol=RTOL, atol=1e-300)
+    p2, t2 = tl.mstep(z)
+    assert np.allclose(p2, c['x_pi2'], rtol=RTOL, atol=0) and np.allclose(t2, c['x_theta2'], rtol=RTOL, atol=0)
+    l2 = tl.calculate_lnl(z, p2, t2)
+    assert abs(l2 - float(c['x_lnl2'])) <= RTOL * abs(float(c['x_lnl2']))
+
+
+def test_error_behaviour(gpu_device):
+    c = load_case('tiny_ties')
+    tl = make_tl(case_matrix(c), Opts(c))
+    with pytest.raises(ValueError, match='Argument "method" should be one of'):
+        tl.reassign('best')
+    with pytest.raises(ValueError):
+        tl.reassign('exclude')        # before em(): no posteriors
+    with pytest.raises(ValueError):
+        make_tl(sp.csr_matrix(np.array([[1.5, 2.0]])), Opts())
+
+
+def test_csr_matrix_plus_primitives(gpu_device):
+    """norm(1) / binmax(1) known answers of telescope/tests/test_sparse_plus.py:24-55."""
+    from telescope_amd import _lib
+    m = sp.csr_matrix(np.array([[1, 0, 2], [0, 0, 0], [4, 5, 6]], dtype=np.float64))
+    out = _lib.csr_norm_rows(m.indptr, m.data)
+    assert np.allclose(out, [1 / 3, 2 / 3, 4 / 15, 5 / 15, 6 / 15], rtol=1e-15)
+    m = sp.csr_matrix(np.array([[6, 0, 2], [0, 0, 3], [4, 5, 6]], dtype=np.float64))
+    assert np.array_equal(_lib.csr_binmax_rows(m.indptr, m.data, 3), [1, 0, 1, 0, 0, 1])
+
+
+@pytest.mark.parametrize('dist,uniq', [('uniform', 0.0), ('zipf', 0.1)])
+def test_device_generator_is_bit_exact(gpu_device, dist, uniq):
+    from telescope_amd import _lib, synthetic
+    n, k, d = 20000, 3000, 20
+    eng = _lib.Engine(0)
+    eng.generate(0, n, k, synthetic.poisson_cdf_u32(d), 99, synthetic.DIST_CODE[dist], uniq)
+    ip, ix, rw = eng.export_csr()
+    ip2, ix2, rw2 = synthetic.generate(n, k, d, seed=99, dist=dist, uniq_frac=uniq)
+    assert np.array_equal(ip, ip2) and np.array_equal(ix, ix2) and np.array_equal(rw, rw2)
+    eng.generate(5000, 7000, k, synthetic.poisson_cdf_u32(d), 99, synthetic.DIST_CODE[dist], uniq)
+    _, ix3, _ = eng.export_csr()
+    assert np.array_equal(ix3, ix2[ip2[5000]:ip2[7000]])
+
+
+def _synthetic_tl(rows, cols, d, dist, seed=42, uniq=0.0, r0=0, r1=None, options=(), opts=None):
+    from telescope_amd import _lib, synthetic
+    from telescope_amd.likelihood import TelescopeLikelihood
+    eng = _lib.Engine(0)
+    for k, v in options:
+        eng.set_option(k, v)
+    eng.set_option('row_offset', r0)
+    eng.generate(r0, rows if r1 is None else r1, cols, synthetic.poisson_cdf_u32(d), seed,
+                 synthetic.DIST_CODE[dist], uniq)
+    return TelescopeLikelihood.from_engine(eng, opts or Opts(max_iter=5, em_epsilon=0.0))
+
+
+def test_against_oracle_midsize_seeded(gpu_device):
+    """200k x 30k (4 column parts), 10 % unique rows, against the oracle."""
+    from oracle.telescope_oracle import OracleModel
+    tl = _synthetic_tl(200000, 30000, 20, 'zipf', seed=5, uniq=0.1)
+    assert tl._eng.layout_info()['P'] == 4
+    ip, ix, rw = tl._eng.export_csr()
+    om = OracleModel(sp.csr_matrix((rw, ix, ip), shape=(200000, 30000)))
+    trace = om.em(0.0, 5)
+    tl.em()
+    assert abs(tl.lnl - om.lnl) <= RTOL * abs(om.lnl)
+    assert np.allclose(tl.pi, om.pi, rtol=RTOL, atol=0) and np.allclose(tl.theta, om.theta, rtol=RTOL, atol=0)
+    np.random.seed(3); a = tl.reassign_colsums('choose')
+    np.random.seed(3); b = np.asarray(om.reassign('choose').sum(0)).ravel()
+    assert np.array_equal(a, b)
+    assert np.array_equal(tl.reassign_colsums('exclude'), np.asarray(om.reassign('exclude').sum(0)).ravel())
+    assert np.allclose(tl.reassign_colsums('conf'), np.asarray(om.reassign('conf').sum(0)).ravel(), rtol=RTOL)
+
+
+@pytest.mark.parametrize('dist', ['zipf', 'uniform'])
+def test_full_size_properties(gpu_device, dist):
+    """BASELINE config 3 shape (10M x 30k, ~40 nnz/row): size-independent checks.
+       * sum(pi) = sum(theta) = 1: every ambiguous fragment's posteriors sum to 1, so the
+         column sums add up to the total weight (a checksum of checksums);
+       * the all-ones initial assignment counts every stored entry once;
+       * sharding is linear: column sums of two half-shards add up to the full pass."""
+    n, k = 10_000_000, 30000
+    tl = _synthetic_tl(n, k, 40, dist)
+    eng = tl._eng
+    _, _, nnz = eng.dims()
+    tl.em()
+    assert abs(tl.pi.sum() - 1.0) < 1e-9 and abs(tl.theta.sum() - 1.0) < 1e-9
+    assert tl.reassign_colsums('all', initial=True).sum() == nnz
+    assert np.isfinite(tl.lnl)
+    lnl_full, pi_full = tl.lnl, tl.pi.copy()
+    eng.set_params(np.repeat(1. / k, k), np.repeat(1. / k, k))
+    eng.em_pass()
+    full = eng.read_reduce(0, k)
+    del tl, eng
+    parts = []
+    for (a, b) in ((0, n // 2), (n // 2, n)):
+        t2 = _synthetic_tl(n, k, 40, dist, r0=a, r1=b)
+        t2._eng.em_pass()
+        parts.append(t2._eng.read_reduce(0, k))
+        del t2
+    assert np.allclose(parts[0] + parts[1], full, rtol=1e-9, atol=0)
+
+
+def test_em_is_reproducible_and_blocksize_independent(gpu_device):
+    a = run_case('mid_zipf_20k')[2]
+    b = run_case('mid_zipf_20k', block_rows=256)[2]
+    assert np.allclose(a.pi, b.pi, rtol=1e-11, atol=0) and abs(a.lnl - b.lnl) <= 1e-11 * abs(a.lnl)
+    assert a.n_iter == b.n_iter

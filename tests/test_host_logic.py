@@ -1,0 +1,105 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every
+declared symbol, the product path fails loudly without a device, the synthetic
+generator spec, row sharding, the Q lookup table."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ROOT, Opts, case_matrix, load_case
+from telescope_amd import _lib, synthetic
+from telescope_amd.distributed import shard_bounds
+from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+
+
+@pytest.fixture(scope='module')
+def built():
+    _lib.build_library()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(built):
+    names = _lib.exported_symbols()
+    assert len(names) >= 30 and 'tsem_em_pass' in names and 'tsem_reassign' in names
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), n
+
+
+def test_header_cites_reference_interfaces():
+    hdr = open(os.path.join(ROOT, 'include', 'telescope_em.h')).read()
+    for cite in ('model.py:702-722', 'model.py:724-742', 'model.py:744-760', 'model.py:762-806',
+                 'model.py:808-865', 'sparse_plus.py'):
+        assert cite in hdr
+
+
+def has_gpu():
+    try:
+        _lib.Engine(0).close()
+        return True
+    except _lib.EngineError:
+        return False
+
+
+@pytest.mark.skipif(has_gpu(), reason='a GPU is present')
+def test_product_path_fails_loudly_without_gpu(built):
+    c = load_case('tiny_ties')
+    with pytest.raises(_lib.EngineError, match='no CPU fallback'):
+        TelescopeLikelihood(case_matrix(c), Opts(c))
+    with pytest.raises(_lib.EngineError):
+        _lib.csr_norm_rows(np.array([0, 1]), np.array([1.0]))
+
+
+def test_no_product_import_of_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, 'telescope_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_score_lut_matches_reference_expression():
+    c = load_case('bundled')
+    raw = case_matrix(c)
+    lut = score_lut(int(c['max_score']))
+    assert np.array_equal(lut[raw.data], c['Q_data'])
+    c = load_case('tiny_wide_range')
+    assert np.array_equal(score_lut(int(c['max_score']))[case_matrix(c).data], c['Q_data'])
+
+
+def test_synthetic_generator_spec():
+    ip, ix, rw = synthetic.generate(5000, 300, 12, seed=7, dist='zipf', uniq_frac=0.1)
+    lens = np.diff(ip)
+    assert lens.min() >= 1 and abs(lens[lens > 1].mean() - 12) < 0.5
+    assert 0.07 < (lens == 1).mean() < 0.13
+    assert rw.min() >= 139 and rw.max() <= 300 and ix.min() >= 0 and ix.max() < 300
+    starts = np.zeros(len(ix), bool); starts[ip[:-1]] = True
+    assert (np.diff(ix)[~starts[1:]] > 0).all()          # sorted, no duplicates within a row
+    # any row range reproduces the same rows
+    ip2, ix2, rw2 = synthetic.generate(5000, 300, 12, seed=7, dist='zipf', uniq_frac=0.1,
+                                       row_begin=1234, row_end=2345)
+    assert np.array_equal(ix2, ix[ip[1234]:ip[2345]]) and np.array_equal(rw2, rw[ip[1234]:ip[2345]])
+    # zipf is skewed, uniform is not
+    _, ixu, _ = synthetic.generate(5000, 300, 12, seed=7, dist='uniform')
+    assert np.bincount(ix, minlength=300)[1] > 5 * np.bincount(ixu, minlength=300)[1]
+
+
+def test_poisson_cdf_table():
+    cdf = synthetic.poisson_cdf_u32(40)
+    assert (np.diff(cdf.astype(np.int64)) >= 0).all() and cdf[-1] > 0.999999 * 2 ** 32
+    h = (synthetic.hash3(1, np.arange(200000), 0) >> np.uint64(32)).astype(np.uint32)
+    s = np.searchsorted(cdf, h, side='right')
+    assert abs(s.mean() - 40) < 0.1 and abs(s.var() - 40) < 1.0
+
+
+def test_shard_bounds():
+    assert shard_bounds(10, 4) == [0, 2, 5, 7, 10]
+    assert shard_bounds(10, 4, 3) == (7, 10)
+    indptr = np.concatenate([[0], np.cumsum([100] * 5 + [1] * 95)])
+    cuts = shard_bounds(100, 2, indptr=indptr)
+    assert cuts[0] == 0 and cuts[-1] == 100 and 2 <= cuts[1] <= 4      # balanced by nnz, not rows
+    assert shard_bounds(3, 8)[-1] == 3 and len(shard_bounds(3, 8)) == 9  # more ranks than rows
