@@ -51,6 +51,10 @@ def parse():
     ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
     ap.add_argument('--em-kernel', choices=('auto', 'twopass', 'fused'), default='auto')
     ap.add_argument('--block-rows', type=int, default=0)
+    ap.add_argument('--chunk-blocks', type=int, default=0)
+    ap.add_argument('--xcd-local', type=int, default=1)
+    ap.add_argument('--poll-delay', type=int, default=-1)
+    ap.add_argument('--fused-dbg', type=int, default=0)
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
     ap.add_argument('--cpu-iters', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -115,6 +119,13 @@ def main():
     eng.set_option('em_kernel', {'auto': EMK_AUTO, 'twopass': EMK_TWOPASS, 'fused': EMK_FUSED}[args.em_kernel])
     if args.block_rows:
         eng.set_option('block_rows', args.block_rows)
+    if args.chunk_blocks:
+        eng.set_option('chunk_blocks', args.chunk_blocks)
+    eng.set_option('xcd_local', args.xcd_local)
+    if args.fused_dbg:
+        eng.set_option('fused_dbg', args.fused_dbg)
+    if args.poll_delay >= 0:
+        eng.set_option('poll_delay', args.poll_delay)
     t_setup = time.perf_counter()
     eng.generate(r0, r1, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
     tl = TelescopeLikelihood.from_engine(eng, Opts(args.steps), comm)

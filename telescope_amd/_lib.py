@@ -104,6 +104,7 @@ def lib():
     L.tsem_csr_binmax_rows.argtypes = [C.c_int, i64, i32, vp, vp, vp]
     L.tsem_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
     L.tsem_layout_info.argtypes = [vp, vp]
+    L.tsem_debug_fused_prof.argtypes = [vp, vp]
     for name in exported_symbols():
         fn = getattr(L, name)
         if name not in ('tsem_destroy', 'tsem_last_error'):
@@ -311,11 +312,16 @@ class Engine(object):
         self._ck(self._L.tsem_kernel_stats(self._h, int(reset), C.byref(ms), C.byref(n), C.byref(b)))
         return dict(em_ms=ms.value, em_launches=n.value, algo_bytes_per_pass=b.value)
 
+    def fused_prof(self):
+        out = np.zeros((64, 16), np.uint64)
+        self._ck(self._L.tsem_debug_fused_prof(self._h, ptr(out)))
+        return out
+
     def layout_info(self):
         info = np.zeros(12, np.int64)
         self._ck(self._L.tsem_layout_info(self._h, ptr(info)))
         return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad', 'twin_cols',
-                         'G1', 'G2'), info.tolist()))
+                         'G1', 'G2', 'fused'), info.tolist()))
 
 
 def csr_norm_rows(indptr, data, device=0):

@@ -270,7 +270,14 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
     for (int64_t k = s + lane; k < e; k += RS_SUB) {
       uint32_t cm = colmap[indices[k]];
       uint32_t p = cm >> 16;
-      int64_t pos = sb_off[b * P + p] + atomicAdd(&cur[p], 1u);
+      // Entries of one row are handed consecutive tickets; writing ticket t of a
+      // sub-block to slot (t % S) * L + t / S (S strands of L slots) puts them S..L
+      // slots apart, so the lanes of one wave instruction hit different rows and the
+      // LDS row-sum atomics do not serialise on one address.
+      const int64_t base = sb_off[b * P + p];
+      const uint32_t L = (uint32_t)((sb_off[b * P + p + 1] - base) / TS_STRANDS);
+      const uint32_t t = atomicAdd(&cur[p], 1u);
+      int64_t pos = base + (int64_t)(t % TS_STRANDS) * L + t / TS_STRANDS;
       pval[pos] = lut[raw[k]];
       prc[pos] = ((uint32_t)lr << 16) | (cm & 0xFFFFu);
     }
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
 // ============================================================================
 // WG = (part p, stripe g).  LDS: ctab[Kp] | y[R]
 template <int NT>
-__global__ __launch_bounds__(NT) void k_phase1(int P, int Kp, int R, int64_t nb, int G, int64_t N_amb_pad,
+__global__ __launch_bounds__(NT) void k_phase1(int P, int Kp, int R, int64_t b0, int64_t nb, int G, int64_t N_amb_pad,
     const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
     const double* __restrict__ ctab, double* __restrict__ ypart) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(NT) void k_phase1(int P, int Kp, int R, int64_t nb,
   for (int t = threadIdx.x; t < Kp; t += NT) c[t] = ctab[p * Kp + t];
   for (int t = threadIdx.x; t < R; t += NT) y[t] = 0.0;
   __syncthreads();
-  for (int64_t b = g; b < nb; b += G) {
+  for (int64_t b = b0 + g; b < nb; b += G) {
     const int64_t q0 = sb_off[b * P + p] >> 2, q1 = sb_off[b * P + p + 1] >> 2;
     for (int64_t q = q0 + threadIdx.x; q < q1; q += NT) {
       uint4 rc = reinterpret_cast<const uint4*>(prc)[q];
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(NT) void k_phase1(int P, int Kp, int R, int64_t nb,
 
 // LDS: ctab[Kp] | acc[Kp] | s[R].  thetasum partials -> partial[g][p*Kp + l]
 template <int NT>
-__global__ __launch_bounds__(NT) void k_phase2_em(int P, int Kp, int R, int64_t nb, int G, int64_t N_amb_pad,
+__global__ __launch_bounds__(NT) void k_phase2_em(int P, int Kp, int R, int64_t b0, int64_t nb, int G, int accumulate, int64_t N_amb_pad,
     const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
     const double* __restrict__ ctab, const double* __restrict__ ypart, const uint16_t* __restrict__ wcode,
     const double* __restrict__ lut, double* __restrict__ partial) {
@@ -321,8 +328,11 @@ __global__ __launch_bounds__(NT) void k_phase2_em(int P, int Kp, int R, int64_t 
   double* acc = c + Kp;
   double* s = acc + Kp;
   const int p = blockIdx.x % P, g = blockIdx.x / P;
-  for (int t = threadIdx.x; t < Kp; t += NT) { c[t] = ctab[p * Kp + t]; acc[t] = 0.0; }
-  for (int64_t b = g; b < nb; b += G) {
+  {
+    const double* prev = partial + (int64_t)g * (P * Kp) + p * Kp;
+    for (int t = threadIdx.x; t < Kp; t += NT) { c[t] = ctab[p * Kp + t]; acc[t] = accumulate ? prev[t] : 0.0; }
+  }
+  for (int64_t b = b0 + g; b < nb; b += G) {
     __syncthreads();
     for (int t = threadIdx.x; t < R; t += NT) {
       int64_t a = b * R + t;
@@ -468,10 +478,18 @@ __global__ void k_make_ctab(int K, const double* __restrict__ pi, const double* 
   ctab[(int)(cm >> 16) * Kp + (int)(cm & 0xFFFF)] = pi[j] * theta[j];
 }
 
+__global__ void k_row_weights(int64_t n, const uint16_t* __restrict__ code, const double* __restrict__ lut,
+                              double* __restrict__ w) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = lut[code[i]];
+}
+
 __global__ void k_fill(double* p, int64_t n, double v) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+
+#include "tsem_fused.h"
 
 // ============================================================================
 // CSR row passes: z export, best-hit counts, reassign (model.py:808-865)
@@ -690,7 +708,8 @@ static int ensure_device(tsem_ctx* h) {
 
 static void free_layout(tsem_ctx* h) {
   dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_prc);
-  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags);
+  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fpartial); dfree(h->d_amb_w);
+  h->fused_launched = false;
 }
 static void free_matrix(tsem_ctx* h) {
   dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_raw); dfree(h->d_lut);
@@ -760,6 +779,14 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "block_rows") h->opt_R = v;
   else if (k == "parts") h->opt_P = v;
   else if (k == "row_offset") h->row_offset = v;
+  else if (k == "chunk_blocks") h->opt_chunk = v;
+  else if (k == "xcd_local") h->opt_xcd_local = v;
+  else if (k == "poll_delay") h->opt_poll_delay = v;
+  else if (k == "fused_dbg") h->opt_dbg = v;
+  else if (k == "fused_prof") {
+    if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
+    if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
+  }
   else TSEM_FAIL(TSEM_ERR_ARG, "unknown option " + k);
   return TSEM_OK;
 }
@@ -968,7 +995,27 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     (void)hipFree(tmp);
   }
   h->N_amb = na; h->N_uni = nu;
-  h->R = h->opt_R > 0 ? (int)h->opt_R : 2048;
+  {
+    // column parts (tables of one part must fit LDS) and rows per block
+    int P = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP - 1) / TS_MAX_KP;
+    if (P < 1) P = 1;
+    if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
+    int Kp = (K + P - 1) / P;
+    if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
+    h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
+    h->use_fused = (h->em_kernel == TSEM_EMK_FUSED) && P <= 8;   // AUTO = two-pass until the fused kernel wins
+    int R = 2048;
+    if (h->use_fused && na > 0) {
+      // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
+      double mean_len = (double)(h->nnz - nu) / (double)na;
+      double r = 0.85 * FZ_CAP * P / std::max(2.0, mean_len);
+      int rmax = (TS_LDS_MAX - 2048 - 2 * Kp * 8) / 32;
+      R = (int)std::min<double>(std::min<double>(r, rmax), 8192.0);
+      R = std::max(64, R / 64 * 64);
+    }
+    if (h->opt_R > 0) R = (int)h->opt_R;
+    h->R = R;
+  }
   if (h->R > 65536 || h->R < 64) TSEM_FAIL(TSEM_ERR_ARG, "block_rows must be in [64, 65536]");
   h->nb = (na + h->R - 1) / h->R;
   h->N_amb_pad = std::max<int64_t>(1, h->nb) * h->R;
@@ -999,12 +1046,7 @@ static int build_layout(tsem_ctx* h) {
   // 1. column popularity: global entry counts handed in by set_model
   const std::vector<uint64_t>& counts = h->col_count;
   // 2. parts: deal columns by popularity so every part carries ~equal nnz
-  int P = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP - 1) / TS_MAX_KP;
-  if (P < 1) P = 1;
-  if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
-  int Kp = (K + P - 1) / P;
-  if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
-  h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
+  const int P = h->P, Kp = h->Kp;
   std::vector<int> order(K);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return counts[a] > counts[b]; });
@@ -1034,7 +1076,11 @@ static int build_layout(tsem_ctx* h) {
     (void)hipFree(d_cnt);
   }
   int64_t off = 0;
-  for (int64_t i = 0; i < nb * P; ++i) { h->nnz_amb += sb[i]; int64_t c = (sb[i] + 3) & ~3ll; sb[i] = off; off += c; }
+  for (int64_t i = 0; i < nb * P; ++i) {   // sub-blocks padded to TS_STRANDS*4 entries (strand-transposed order)
+    h->nnz_amb += sb[i];
+    int64_t c = (sb[i] + (TS_STRANDS * 4 - 1)) / (TS_STRANDS * 4) * (TS_STRANDS * 4);
+    sb[i] = off; off += c;
+  }
   sb[nb * P] = off;
   h->nnz_pad = off;
   TSEM_ALLOC(h->d_sb_off, nb * P + 1);
@@ -1057,6 +1103,24 @@ static int build_layout(tsem_ctx* h) {
   h->G1 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w1 / P));
   h->G2 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w2 / P));
   TSEM_ALLOC(h->d_partial, (int64_t)h->G2 * h->Kpad);
+  if (h->use_fused) {
+    const size_t ldsf = (size_t)(2 * Kp + 4 * R) * 8 + 64;
+    if (ldsf > (size_t)TS_LDS_MAX - 1024) {
+      h->use_fused = false;
+    } else {
+      h->fz_grid = h->n_cu;
+      h->fz_teams = std::max(1, h->fz_grid / P);
+      TSEM_ALLOC(h->d_fpartial, (int64_t)h->fz_teams * h->Kpad);
+      TSEM_ALLOC(h->d_xchg, (int64_t)h->fz_teams * 2 * P * R);
+      TSEM_ALLOC(h->d_xflags, FZ_SYNC_WORDS);
+      TSEM_HIP(hipMemset(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS));
+      TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
+      k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
+#define FZ_ATTR(n) TSEM_HIP(hipFuncSetAttribute((const void*)k_em_fused<n>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      FZ_ATTR(1) FZ_ATTR(2) FZ_ATTR(3) FZ_ATTR(4) FZ_ATTR(5) FZ_ATTR(6) FZ_ATTR(7) FZ_ATTR(8)
+#undef FZ_ATTR
+    }
+  }
   TSEM_HIP(hipFuncSetAttribute((const void*)k_phase1<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
   TSEM_HIP(hipFuncSetAttribute((const void*)k_phase2_em<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
   TSEM_HIP(hipFuncSetAttribute((const void*)k_phase2_lnl<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
@@ -1170,10 +1234,11 @@ int tsem_bind_reduce_buffer(tsem_ctx* h, void* dptr, int64_t count) {
 // ---------------------------------------------------------------------------
 // EM pass / update / lnl
 // ---------------------------------------------------------------------------
-static int launch_phase1(tsem_ctx* h, const double* ctab) {
+static int launch_phase1(tsem_ctx* h, const double* ctab, int64_t b0 = 0, int64_t b1 = -1) {
   if (h->nb == 0) return TSEM_OK;
+  if (b1 < 0) b1 = h->nb;
   const size_t lds1 = (size_t)(h->Kp + h->R) * 8;
-  k_phase1<512><<<h->G1 * h->P, 512, lds1, h->stream>>>(h->P, h->Kp, h->R, h->nb, h->G1, h->N_amb_pad, h->d_sb_off,
+  k_phase1<512><<<h->G1 * h->P, 512, lds1, h->stream>>>(h->P, h->Kp, h->R, b0, b1, h->G1, h->N_amb_pad, h->d_sb_off,
                                                         h->d_pval, h->d_prc, ctab, h->d_ypart);
   TSEM_HIP(hipGetLastError());
   return TSEM_OK;
@@ -1198,16 +1263,45 @@ int tsem_em_pass(tsem_ctx* h) {
   if (int rc = ensure_device(h)) return rc;
   hipEvent_t* pair = nullptr;
   if (int rc = begin_timing(h, &pair)) return rc;
-  if (h->nb > 0) {
-    if (int rc = launch_phase1(h, h->d_ctab)) return rc;
+  bool fused_done = false;
+  if (h->nb > 0 && h->use_fused) {
+    const size_t sync_bytes = sizeof(uint32_t) * FZ_SYNC_WORDS;
+    TSEM_HIP(hipMemsetAsync(h->d_xflags, 0, sync_bytes, h->stream));
+    TSEM_HIP(hipMemsetAsync(h->d_fpartial, 0, sizeof(double) * (size_t)h->fz_teams * h->Kpad, h->stream));
+    if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * 2 * h->P * h->R, h->stream));
+    FusedArgs A;
+    A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
+    A.sb_off = h->d_sb_off; A.pval = h->d_pval; A.prc = h->d_prc; A.ctab = h->d_ctab;
+    A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg;
+    A.sync = h->d_xflags; A.xcd_local = h->opt_xcd_local ? 1 : 0;
+    A.prof = h->d_prof; A.prof_blocks = h->d_prof ? 64 : 0; A.poll_delay = (int)h->opt_poll_delay; A.dbg = (int)h->opt_dbg;
+    const size_t ldsf = (size_t)(2 * h->Kp + 4 * h->R) * 8 + 64;
+    if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
+    switch (h->P) {
+#define FZ_CASE(n) case n: k_em_fused<n><<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A); break;
+      FZ_CASE(1) FZ_CASE(2) FZ_CASE(3) FZ_CASE(4) FZ_CASE(5) FZ_CASE(6) FZ_CASE(7) FZ_CASE(8)
+#undef FZ_CASE
+      default: TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
+    }
+    TSEM_HIP(hipGetLastError());
+    h->fused_launched = true;
+    fused_done = true;
+  } else if (h->nb > 0) {
     const size_t lds2 = (size_t)(2 * h->Kp + h->R) * 8;
-    k_phase2_em<1024><<<h->G2 * h->P, 1024, lds2, h->stream>>>(h->P, h->Kp, h->R, h->nb, h->G2, h->N_amb_pad,
-        h->d_sb_off, h->d_pval, h->d_prc, h->d_ctab, h->d_ypart, h->d_amb_wcode, h->d_lut, h->d_partial);
+    const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : h->nb;
+    for (int64_t b0 = 0; b0 < h->nb; b0 += chunk) {
+      const int64_t b1 = std::min(h->nb, b0 + chunk);
+      if (int rc = launch_phase1(h, h->d_ctab, b0, b1)) return rc;
+      k_phase2_em<1024><<<h->G2 * h->P, 1024, lds2, h->stream>>>(h->P, h->Kp, h->R, b0, b1, h->G2, b0 > 0 ? 1 : 0,
+          h->N_amb_pad, h->d_sb_off, h->d_pval, h->d_prc, h->d_ctab, h->d_ypart, h->d_amb_wcode, h->d_lut, h->d_partial);
+    }
     TSEM_HIP(hipGetLastError());
   }
   if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
   h->em_launches += 1;
-  if (h->nb > 0) {
+  if (fused_done) {
+    k_colreduce<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_red, h->K);
+  } else if (h->nb > 0) {
     k_colreduce<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_red, h->K);
   } else {
     TSEM_HIP(hipMemsetAsync(h->d_red, 0, sizeof(double) * (h->K + 2), h->stream));
@@ -1226,6 +1320,16 @@ static int launch_update(tsem_ctx* h, double* d_diff_slot) {
   return TSEM_OK;
 }
 
+static int check_fused_error(tsem_ctx* h) {
+  if (!h->use_fused || !h->d_xflags || !h->fused_launched) return TSEM_OK;
+  uint32_t e = 0;
+  TSEM_HIP(hipMemcpyAsync(&e, h->d_xflags + 9, 4, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  if (e) TSEM_FAIL(TSEM_ERR_TIMEOUT, "fused EM kernel: hand-off watchdog fired (code " + std::to_string(e) +
+                   "): a team member was not co-resident or a flag never arrived");
+  return TSEM_OK;
+}
+
 int tsem_em_update(tsem_ctx* h, double* diff_est) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
@@ -1233,6 +1337,7 @@ int tsem_em_update(tsem_ctx* h, double* diff_est) {
   if (diff_est) {
     TSEM_HIP(hipMemcpyAsync(diff_est, h->d_diffs, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (int rc = check_fused_error(h)) return rc;
   }
   return TSEM_OK;
 }
@@ -1278,7 +1383,7 @@ int tsem_em_steps(tsem_ctx* h, int32_t n, double* diffs_out) {
     TSEM_HIP(hipMemcpyAsync(diffs_out, h->d_diffs, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
   }
-  return TSEM_OK;
+  return check_fused_error(h);
 }
 
 int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likelihood, int32_t* n_iter,
@@ -1518,11 +1623,18 @@ int tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launche
   return TSEM_OK;
 }
 
+int tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out /* 64*16 */) {
+  if (!h || !h->d_prof || !out) return TSEM_ERR_ARG;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  TSEM_HIP(hipMemcpy(out, h->d_prof, 64 * 16 * 8, hipMemcpyDeviceToHost));
+  return TSEM_OK;
+}
+
 int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   if (!h || !info) return TSEM_ERR_ARG;
   info[0] = h->P; info[1] = h->Kp; info[2] = h->R; info[3] = h->nb;
   info[4] = h->N_amb; info[5] = h->N_uni; info[6] = h->nnz_amb; info[7] = h->nnz_pad;
-  info[8] = h->n_twin_cols; info[9] = h->G1; info[10] = h->G2; info[11] = 0;
+  info[8] = h->n_twin_cols; info[9] = h->G1; info[10] = h->G2; info[11] = h->use_fused ? 1 : 0;
   return TSEM_OK;
 }
 

@@ -46,6 +46,7 @@ __host__ __device__ inline uint64_t ts_hash3(uint64_t seed, uint64_t row, uint64
 constexpr int TS_LDS_TABLE_BYTES = 120 * 1024;
 constexpr int TS_MAX_KP = TS_LDS_TABLE_BYTES / 16;   // 7680 columns per part
 constexpr int TS_LDS_MAX = 160 * 1024;
+constexpr int TS_STRANDS = 16;   // strand-transposed entry order inside a sub-block
 
 struct tsem_ctx {
   int device = 0;
@@ -95,7 +96,13 @@ struct tsem_ctx {
   double* d_partial = nullptr;      // [G2][Kpad]
   double* d_lnl_part = nullptr;     // [4096]
   int em_kernel = TSEM_EMK_AUTO;
-  int64_t opt_R = 0, opt_P = 0;
+  int64_t opt_R = 0, opt_P = 0, opt_chunk = 0, opt_xcd_local = 1, opt_poll_delay = 0, opt_dbg = 0;
+  bool use_fused = false;
+  int fz_grid = 0, fz_teams = 0;
+  double* d_fpartial = nullptr;     // [fz_teams][Kpad]
+  double* d_amb_w = nullptr;        // [N_amb_pad] fragment weights
+  bool fused_launched = false;
+  unsigned long long* d_prof = nullptr;
 
   // ---- parameters ----
   double *d_pi = nullptr, *d_theta = nullptr, *d_pi_prev = nullptr, *d_theta_prev = nullptr;

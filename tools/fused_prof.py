@@ -1,0 +1,27 @@
+"""Per-block timeline of the fused EM kernel (team 0, member 0): python tools/fused_prof.py [rows]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from telescope_amd import synthetic
+from telescope_amd._lib import Engine
+from telescope_amd.likelihood import TelescopeLikelihood
+
+class O: em_epsilon=0.0; max_iter=3; pi_prior=0; theta_prior=200000
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+eng = Engine(0)
+for kv in sys.argv[2:]:
+    k, v = kv.split('='); eng.set_option(k, int(v))
+eng.generate(0, rows, 30000, synthetic.poisson_cdf_u32(40), 42, 1, 0.0)
+tl = TelescopeLikelihood.from_engine(eng, O())
+eng.em_steps(2, False)
+eng.set_option('fused_prof', 1)
+eng.em_steps(1, False)
+t = eng.fused_prof().astype(np.int64)
+print(eng.layout_info())
+names = ['d:start', 'd:ph1 done', 'x:bar1', 'x:published', 'x:polled', 'x:combined', 'd:bar2', 'd:ph2 done', 'x:ldsread', 'x:wrowiss', 'x:1stpoll']
+base = t[4, 0]
+print('cycles relative to block start (blocks 4..11); clock ~2.1-2.4 GHz (shader clock / s_memtime)')
+print('%-6s' % 'blk' + ''.join('%13s' % n for n in names) + '%12s' % 'blk total')
+for i in range(4, 24):
+    row = t[i, :11] - t[i, 0]
+    print('%-6d' % i + ''.join('%13d' % v for v in row) + '%12d' % (t[i + 1, 0] - t[i, 0]) + '  spins=%d' % t[i, 11])

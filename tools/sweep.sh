@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage: tools/sweep.sh "<common bench args>" "<varying flag>" v1 v2 ...
+common="$1"; flag="$2"; shift 2
+for v in "$@"; do
+  python bench.py $common $flag $v 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('$flag $v: %.3f ms/step  kernel %.3f ms  frac %.4f  %.1f Gnnz/s' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'], d['nnz_per_sec']/1e9))"
+done
