@@ -166,6 +166,16 @@ def main():
         return
 
     info = eng.layout_info()
+    traffic = None
+    try:   # HBM bytes per launch from a separate rocprofv3 --pmc run of this same workload (profiles/)
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        w = tj['workload']
+        kern = 'fused' if info.get('fused') else 'twopass'
+        if (w['rows'], w['cols'], w['nnz_row'], w['dist'], w['em_kernel'], w['n_gpus']) == \
+                (total_rows, args.cols, args.nnz_row, args.dist, kern, world):
+            traffic = tj['traffic_bytes_per_launch'] / 1e9
+    except (OSError, KeyError, ValueError):
+        pass
     k_ms = ks['em_ms'] / max(1, ks['em_launches'])
     achieved = ks['algo_bytes_per_pass'] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     out = {
@@ -185,7 +195,7 @@ def main():
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC, profiles/pmc_traffic.json)',
             'kernel': 'EM pass (rank 0 shard)', 'kernel_ms': k_ms,
             'algo_bytes_per_launch': ks['algo_bytes_per_pass'],
         },
