@@ -65,6 +65,12 @@ def lib():
         raise EngineError(
             'libtelescope_em.so is not built (%s). Run `python -c "import __graft_entry__ as g; '
             'g.build()"`. There is no CPU fallback.' % LIB_PATH)
+    # torch ships its own libamdhip64; if it is going to be used in this process (multi-GPU
+    # plumbing), it must be loaded BEFORE ours so both share one HIP runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     L.tsem_create.argtypes = [C.POINTER(vp), C.c_int]

@@ -436,8 +436,8 @@ __global__ void k_colreduce(int Kpad, int G, const double* __restrict__ partial,
   red[col] = s;
 }
 
-// M-step closed forms (model.py:733-740) + diff_est (model.py:781); single WG
-__global__ __launch_bounds__(1024) void k_update(int K, const double* __restrict__ red,
+// M-step closed forms (model.py:733-740) + per-block partials of diff_est (model.py:781)
+__global__ __launch_bounds__(256) void k_update(int K, const double* __restrict__ red,
     const double* __restrict__ pisum0, double theta_pw, double theta_den, double pi_pw, double pi_den,
     double* __restrict__ pi, double* __restrict__ theta, double* __restrict__ pi_prev,
     double* __restrict__ theta_prev, const uint32_t* __restrict__ colmap, int Kp,
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(1024) void k_update(int K, const double* __restrict
     double* __restrict__ diff_out) {
   __shared__ double scratch[16];
   double d = 0.0;
-  for (int j = threadIdx.x; j < K; j += blockDim.x) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K; j += gridDim.x * blockDim.x) {
     // exact twin columns share one accumulation (see k_colsig) as long as their
     // sums agree to rounding, i.e. their parameters are still symmetric
     const int jr = twin_rep[j];
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(1024) void k_update(int K, const double* __restrict
     ctab[pc] = ph * th;
   }
   double t = block_sum(d, scratch);
-  if (threadIdx.x == 0) diff_out[0] = t;
+  if (threadIdx.x == 0) diff_out[blockIdx.x] = t;
 }
 
 __global__ void k_make_ctab(int K, const double* __restrict__ pi, const double* __restrict__ theta,
@@ -708,7 +708,7 @@ static int ensure_device(tsem_ctx* h) {
 
 static void free_layout(tsem_ctx* h) {
   dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_prc);
-  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fpartial); dfree(h->d_amb_w);
+  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fpartial); dfree(h->d_amb_w); dfree(h->d_sb_q32);
   h->fused_launched = false;
 }
 static void free_matrix(tsem_ctx* h) {
@@ -742,7 +742,7 @@ int tsem_create(tsem_ctx** out, int device) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
   if (hipMalloc((void**)&h->d_diffs, TS_DIFF_RING * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&h->d_lnl_part, 8192 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&h->d_lnl_part, 16384 * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&h->d_maxcode, 64) != hipSuccess ||
       hipMalloc((void**)&h->d_xerr, 64) != hipSuccess) {
     g_create_err = "hipMalloc failed in tsem_create";
@@ -1003,14 +1003,14 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     int Kp = (K + P - 1) / P;
     if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
     h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
-    h->use_fused = (h->em_kernel == TSEM_EMK_FUSED) && P <= 8;   // AUTO = two-pass until the fused kernel wins
+    h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= 4;   // AUTO: fused when the layout allows it
     int R = 2048;
     if (h->use_fused && na > 0) {
       // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
       double mean_len = (double)(h->nnz - nu) / (double)na;
-      double r = 0.85 * FZ_CAP * P / std::max(2.0, mean_len);
-      int rmax = (TS_LDS_MAX - 2048 - 2 * Kp * 8) / 32;
-      R = (int)std::min<double>(std::min<double>(r, rmax), 8192.0);
+      double r = 0.90 * FZ_CAP * P / std::max(2.0, mean_len);
+      int rmax = std::min(2 * 64 * FZ_RP * FZ_NXW, (TS_LDS_MAX - 2048 - 2 * Kp * 8) / 48);
+      R = (int)std::min<double>(r, rmax);
       R = std::max(64, R / 64 * 64);
     }
     if (h->opt_R > 0) R = (int)h->opt_R;
@@ -1075,6 +1075,12 @@ static int build_layout(tsem_ctx* h) {
     TSEM_HIP(hipStreamSynchronize(h->stream));
     (void)hipFree(d_cnt);
   }
+  if (h->use_fused) {
+    int64_t mx = 0;
+    for (int64_t i = 0; i < nb * P; ++i) mx = std::max(mx, sb[i]);
+    h->max_subblock = mx;
+    if (mx > FZ_CAP) h->use_fused = false;   // caller (set_model) retries with smaller blocks
+  }
   int64_t off = 0;
   for (int64_t i = 0; i < nb * P; ++i) {   // sub-blocks padded to TS_STRANDS*4 entries (strand-transposed order)
     h->nnz_amb += sb[i];
@@ -1085,6 +1091,14 @@ static int build_layout(tsem_ctx* h) {
   h->nnz_pad = off;
   TSEM_ALLOC(h->d_sb_off, nb * P + 1);
   TSEM_HIP(hipMemcpy(h->d_sb_off, sb.data(), sizeof(int64_t) * (nb * P + 1), hipMemcpyHostToDevice));
+  if (h->use_fused && (off >> 2) < 0xFFFFFFFFll) {
+    std::vector<uint32_t> q32(nb * P + 2, 0);
+    for (int64_t i = 0; i <= nb * P; ++i) q32[i] = (uint32_t)(sb[i] >> 2);
+    TSEM_ALLOC(h->d_sb_q32, nb * P + 2);
+    TSEM_HIP(hipMemcpy(h->d_sb_q32, q32.data(), sizeof(uint32_t) * (nb * P + 2), hipMemcpyHostToDevice));
+  } else if (h->use_fused) {
+    h->use_fused = false;
+  }
   TSEM_ALLOC(h->d_pval, off);
   TSEM_ALLOC(h->d_prc, off);
   TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
@@ -1104,20 +1118,20 @@ static int build_layout(tsem_ctx* h) {
   h->G2 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w2 / P));
   TSEM_ALLOC(h->d_partial, (int64_t)h->G2 * h->Kpad);
   if (h->use_fused) {
-    const size_t ldsf = (size_t)(2 * Kp + 4 * R) * 8 + 64;
-    if (ldsf > (size_t)TS_LDS_MAX - 1024) {
+    const size_t ldsf = (size_t)(2 * Kp + 6 * R) * 8 + 192;
+    if (ldsf > (size_t)TS_LDS_MAX - 1024 || R > 2 * 64 * FZ_RP * FZ_NXW || (R % (2 * FZ_NXW))) {
       h->use_fused = false;
     } else {
       h->fz_grid = h->n_cu;
       h->fz_teams = std::max(1, h->fz_grid / P);
       TSEM_ALLOC(h->d_fpartial, (int64_t)h->fz_teams * h->Kpad);
-      TSEM_ALLOC(h->d_xchg, (int64_t)h->fz_teams * 2 * P * R);
+      TSEM_ALLOC(h->d_xchg, (int64_t)h->fz_teams * FZ_XS * P * R);
       TSEM_ALLOC(h->d_xflags, FZ_SYNC_WORDS);
       TSEM_HIP(hipMemset(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS));
       TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
       k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
 #define FZ_ATTR(n) TSEM_HIP(hipFuncSetAttribute((const void*)k_em_fused<n>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
-      FZ_ATTR(1) FZ_ATTR(2) FZ_ATTR(3) FZ_ATTR(4) FZ_ATTR(5) FZ_ATTR(6) FZ_ATTR(7) FZ_ATTR(8)
+      FZ_ATTR(1) FZ_ATTR(2) FZ_ATTR(3) FZ_ATTR(4)
 #undef FZ_ATTR
     }
   }
@@ -1268,20 +1282,20 @@ int tsem_em_pass(tsem_ctx* h) {
     const size_t sync_bytes = sizeof(uint32_t) * FZ_SYNC_WORDS;
     TSEM_HIP(hipMemsetAsync(h->d_xflags, 0, sync_bytes, h->stream));
     TSEM_HIP(hipMemsetAsync(h->d_fpartial, 0, sizeof(double) * (size_t)h->fz_teams * h->Kpad, h->stream));
-    if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * 2 * h->P * h->R, h->stream));
+    if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * FZ_XS * h->P * h->R, h->stream));
     FusedArgs A;
     A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
-    A.sb_off = h->d_sb_off; A.pval = h->d_pval; A.prc = h->d_prc; A.ctab = h->d_ctab;
+    A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc; A.ctab = h->d_ctab;
     A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg;
     A.sync = h->d_xflags; A.xcd_local = h->opt_xcd_local ? 1 : 0;
     A.prof = h->d_prof; A.prof_blocks = h->d_prof ? 64 : 0; A.poll_delay = (int)h->opt_poll_delay; A.dbg = (int)h->opt_dbg;
-    const size_t ldsf = (size_t)(2 * h->Kp + 4 * h->R) * 8 + 64;
+    const size_t ldsf = (size_t)(2 * h->Kp + 6 * h->R) * 8 + 192;
     if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
     switch (h->P) {
 #define FZ_CASE(n) case n: k_em_fused<n><<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A); break;
-      FZ_CASE(1) FZ_CASE(2) FZ_CASE(3) FZ_CASE(4) FZ_CASE(5) FZ_CASE(6) FZ_CASE(7) FZ_CASE(8)
+      FZ_CASE(1) FZ_CASE(2) FZ_CASE(3) FZ_CASE(4)
 #undef FZ_CASE
-      default: TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
+      default: TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 4 column parts");
     }
     TSEM_HIP(hipGetLastError());
     h->fused_launched = true;
@@ -1313,9 +1327,12 @@ int tsem_em_pass(tsem_ctx* h) {
 static int launch_update(tsem_ctx* h, double* d_diff_slot) {
   const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;   // model.py:696-697
   const double tden = h->W_amb + tpw * h->K, pden = h->W_tot + ppw * h->K;      // model.py:732,738
-  k_update<<<1, 1024, 0, h->stream>>>(h->K, h->d_red, h->d_pisum0, tpw, tden, ppw, pden, h->d_pi, h->d_theta,
-                                      h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab, h->d_ctab_prev,
-                                      h->d_twin_rep, d_diff_slot);
+  const int nblk = std::min(1024, cdiv64(h->K, 256));
+  double* part = h->d_lnl_part + 10000;   // scratch for the per-block |pi_hat - pi| partials
+  k_update<<<nblk, 256, 0, h->stream>>>(h->K, h->d_red, h->d_pisum0, tpw, tden, ppw, pden, h->d_pi, h->d_theta,
+                                        h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab, h->d_ctab_prev,
+                                        h->d_twin_rep, part);
+  k_sum_parts<<<1, 256, 0, h->stream>>>(part, nblk, part, 0, d_diff_slot);   // fixed order -> deterministic
   TSEM_HIP(hipGetLastError());
   return TSEM_OK;
 }

@@ -98,9 +98,11 @@ struct tsem_ctx {
   int em_kernel = TSEM_EMK_AUTO;
   int64_t opt_R = 0, opt_P = 0, opt_chunk = 0, opt_xcd_local = 1, opt_poll_delay = 0, opt_dbg = 0;
   bool use_fused = false;
+  int64_t max_subblock = 0;
   int fz_grid = 0, fz_teams = 0;
   double* d_fpartial = nullptr;     // [fz_teams][Kpad]
   double* d_amb_w = nullptr;        // [N_amb_pad] fragment weights
+  uint32_t* d_sb_q32 = nullptr;     // [nb*P+2] sub-block offsets / 4
   bool fused_launched = false;
   unsigned long long* d_prof = nullptr;
 

@@ -110,8 +110,6 @@ class Comm(object):
             engine.set_stream(t.cuda.current_stream(self.tdev).cuda_stream)
 
     def allreduce_device(self, engine, offset=0, count=None):
-        if self.world == 1:
-            return
         red = self._red if count is None else self._red[offset:offset + count]
         self._dist.all_reduce(red, op=self._dist.ReduceOp.SUM, group=self.group)
 

@@ -249,3 +249,30 @@ def test_em_is_reproducible_and_blocksize_independent(gpu_device):
     b = run_case('mid_zipf_20k', block_rows=256)[2]
     assert np.allclose(a.pi, b.pi, rtol=1e-11, atol=0) and abs(a.lnl - b.lnl) <= 1e-11 * abs(a.lnl)
     assert a.n_iter == b.n_iter
+
+
+def test_rccl_comm_path_single_rank(gpu_device):
+    """The N > 1 plumbing on a real GPU with a 1-rank RCCL group: torch-owned reduce tensor bound
+    into the engine, launches on torch's stream, in-place all-reduce between pass and update."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from telescope_amd.distributed import Comm
+    from telescope_amd.likelihood import TelescopeLikelihood
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        comm = Comm(device=0)
+        for name in ('bundled', 'tiny_twins', 'mid_zipf_20k'):
+            c = load_case(name)
+            tl = TelescopeLikelihood(case_matrix(c), Opts(c), comm=comm)
+            tl.em()
+            assert tl.n_iter == int(c['n_iter'])
+            assert abs(tl.lnl - float(c['lnl'])) <= RTOL * abs(float(c['lnl']))
+            assert np.allclose(tl.pi, c['pi'], rtol=RTOL, atol=0)
+            np.random.seed(int(c['seed']))
+            assert np.array_equal(tl.reassign_colsums('choose'), c['ra_choose_0_colsum'])
+            assert np.array_equal(tl.reassign_colsums('exclude'), c['ra_exclude_0_colsum'])
+    finally:
+        dist.destroy_process_group()

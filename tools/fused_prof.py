@@ -9,6 +9,7 @@ from telescope_amd.likelihood import TelescopeLikelihood
 class O: em_epsilon=0.0; max_iter=3; pi_prior=0; theta_prior=200000
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 eng = Engine(0)
+eng.set_option('em_kernel', 2)
 for kv in sys.argv[2:]:
     k, v = kv.split('='); eng.set_option(k, int(v))
 eng.generate(0, rows, 30000, synthetic.poisson_cdf_u32(40), 42, 1, 0.0)
@@ -18,10 +19,10 @@ eng.set_option('fused_prof', 1)
 eng.em_steps(1, False)
 t = eng.fused_prof().astype(np.int64)
 print(eng.layout_info())
-names = ['d:start', 'd:ph1 done', 'x:bar1', 'x:published', 'x:polled', 'x:combined', 'd:bar2', 'd:ph2 done', 'x:ldsread', 'x:wrowiss', 'x:1stpoll']
+names = ['start', 'P2 done', 'burst issued', 'P1 done', 'barrier', 'xchg done']
 base = t[4, 0]
 print('cycles relative to block start (blocks 4..11); clock ~2.1-2.4 GHz (shader clock / s_memtime)')
 print('%-6s' % 'blk' + ''.join('%13s' % n for n in names) + '%12s' % 'blk total')
 for i in range(4, 24):
-    row = t[i, :11] - t[i, 0]
-    print('%-6d' % i + ''.join('%13d' % v for v in row) + '%12d' % (t[i + 1, 0] - t[i, 0]) + '  spins=%d' % t[i, 11])
+    row = t[i, :6] - t[i, 0]
+    print('%-6d' % i + ''.join('%13d' % v for v in row) + '%12d' % (t[i + 1, 0] - t[i, 0]))
