@@ -55,6 +55,7 @@ def parse():
     ap.add_argument('--xcd-local', type=int, default=1)
     ap.add_argument('--poll-delay', type=int, default=-1)
     ap.add_argument('--fused-dbg', type=int, default=0)
+    ap.add_argument('--fill-pct', type=int, default=0)
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
     ap.add_argument('--cpu-iters', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -124,6 +125,8 @@ def main():
     eng.set_option('xcd_local', args.xcd_local)
     if args.fused_dbg:
         eng.set_option('fused_dbg', args.fused_dbg)
+    if args.fill_pct:
+        eng.set_option('fill_pct', args.fill_pct)
     if args.poll_delay >= 0:
         eng.set_option('poll_delay', args.poll_delay)
     t_setup = time.perf_counter()

@@ -162,7 +162,7 @@ int  tsem_csr_binmax_rows(int device, int64_t n_rows, int32_t n_cols, const int6
  * last call with reset=1; algorithmic bytes one EM pass reads.  */
 int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launches,
                        int64_t* algo_bytes_per_pass);
-int  tsem_layout_info(tsem_ctx* h, int64_t* info12);
+int  tsem_layout_info(tsem_ctx* h, int64_t* info16);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
 

@@ -782,6 +782,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "chunk_blocks") h->opt_chunk = v;
   else if (k == "xcd_local") h->opt_xcd_local = v;
   else if (k == "poll_delay") h->opt_poll_delay = v;
+  else if (k == "fill_pct") h->fill_target = v / 100.0;
   else if (k == "fused_dbg") h->opt_dbg = v;
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
@@ -1008,10 +1009,10 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     if (h->use_fused && na > 0) {
       // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
       double mean_len = (double)(h->nnz - nu) / (double)na;
-      double r = 0.90 * FZ_CAP * P / std::max(2.0, mean_len);
-      int rmax = std::min(2 * 64 * FZ_RP * FZ_NXW, (TS_LDS_MAX - 2048 - 2 * Kp * 8) / 48);
+      double r = h->fill_target * FZ_CAP * P / std::max(2.0, mean_len);
+      int rmax = std::min(2 * 64 * FZ_RP * FZ_NXW, (TS_LDS_MAX - 2048 - 2 * Kp * 8) / ((FZ_YR + 2) * 8));
       R = (int)std::min<double>(r, rmax);
-      R = std::max(64, R / 64 * 64);
+      R = std::max(64, R / 8 * 8);
     }
     if (h->opt_R > 0) R = (int)h->opt_R;
     h->R = R;
@@ -1020,10 +1021,10 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   h->nb = (na + h->R - 1) / h->R;
   h->N_amb_pad = std::max<int64_t>(1, h->nb) * h->R;
   TSEM_ALLOC(h->d_amb_row, na);
-  TSEM_ALLOC(h->d_amb_wcode, h->N_amb_pad);
+  TSEM_ALLOC(h->d_amb_wcode, na + 65536 + 8);             // room for any block size chosen later
   TSEM_ALLOC(h->d_uni_col, nu);
   TSEM_ALLOC(h->d_uni_code, nu);
-  TSEM_HIP(hipMemsetAsync(h->d_amb_wcode, 0, sizeof(uint16_t) * h->N_amb_pad, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_amb_wcode, 0, sizeof(uint16_t) * (na + 65536 + 8), h->stream));
   if (N)
     k_compact_rows<<<cdiv64(N, 256), 256, 0, h->stream>>>(N, d_cls, d_fa, d_fu, h->d_indptr, h->d_indices, h->d_raw,
                                                          d_code, h->d_amb_row, h->d_amb_wcode, h->d_uni_col,
@@ -1118,8 +1119,8 @@ static int build_layout(tsem_ctx* h) {
   h->G2 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w2 / P));
   TSEM_ALLOC(h->d_partial, (int64_t)h->G2 * h->Kpad);
   if (h->use_fused) {
-    const size_t ldsf = (size_t)(2 * Kp + 6 * R) * 8 + 192;
-    if (ldsf > (size_t)TS_LDS_MAX - 1024 || R > 2 * 64 * FZ_RP * FZ_NXW || (R % (2 * FZ_NXW))) {
+    const size_t ldsf = (size_t)(2 * Kp + (FZ_YR + 2) * R) * 8 + 192;
+    if (ldsf > (size_t)TS_LDS_MAX - 1024 || R > 2 * 64 * FZ_RP * FZ_NXW || (R & 1)) {
       h->use_fused = false;
     } else {
       h->fz_grid = h->n_cu;
@@ -1179,7 +1180,19 @@ int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, cons
     }
     TSEM_HIP(hipMemcpy(h->d_pisum0, ps.data(), sizeof(double) * K, hipMemcpyHostToDevice));
   }
-  if (int rc = build_layout(h)) return rc;
+  const bool want_fused = h->use_fused;
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = build_layout(h)) return rc;
+    if (!want_fused || h->use_fused || h->opt_R > 0 || attempt >= 4 || h->max_subblock <= FZ_CAP) break;
+    // a sub-block outgrew the register tile: shrink the row blocks and lay out again
+    int R = (int)((double)h->R * FZ_CAP / (double)h->max_subblock * 0.985);
+    R = std::max(64, R / 8 * 8);
+    if (R >= h->R) break;
+    h->R = R;
+    h->nb = (h->N_amb + R - 1) / R;
+    h->N_amb_pad = std::max<int64_t>(1, h->nb) * R;
+    h->use_fused = true;
+  }
   TSEM_ALLOC(h->d_pi, K); TSEM_ALLOC(h->d_theta, K); TSEM_ALLOC(h->d_pi_prev, K); TSEM_ALLOC(h->d_theta_prev, K);
   TSEM_ALLOC(h->d_tmp_pi, K); TSEM_ALLOC(h->d_tmp_theta, K);
   TSEM_ALLOC(h->d_ctab, h->Kpad); TSEM_ALLOC(h->d_ctab_prev, h->Kpad);
@@ -1289,7 +1302,7 @@ int tsem_em_pass(tsem_ctx* h) {
     A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg;
     A.sync = h->d_xflags; A.xcd_local = h->opt_xcd_local ? 1 : 0;
     A.prof = h->d_prof; A.prof_blocks = h->d_prof ? 64 : 0; A.poll_delay = (int)h->opt_poll_delay; A.dbg = (int)h->opt_dbg;
-    const size_t ldsf = (size_t)(2 * h->Kp + 6 * h->R) * 8 + 192;
+    const size_t ldsf = (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192;
     if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
     switch (h->P) {
 #define FZ_CASE(n) case n: k_em_fused<n><<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A); break;
@@ -1339,9 +1352,11 @@ static int launch_update(tsem_ctx* h, double* d_diff_slot) {
 
 static int check_fused_error(tsem_ctx* h) {
   if (!h->use_fused || !h->d_xflags || !h->fused_launched) return TSEM_OK;
-  uint32_t e = 0;
-  TSEM_HIP(hipMemcpyAsync(&e, h->d_xflags + 9, 4, hipMemcpyDeviceToHost, h->stream));
+  uint32_t ee[2] = {0, 0};
+  TSEM_HIP(hipMemcpyAsync(ee, h->d_xflags + 9, 8, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
+  const uint32_t e = ee[0];
+  h->last_slow_path = ee[1];
   if (e) TSEM_FAIL(TSEM_ERR_TIMEOUT, "fused EM kernel: hand-off watchdog fired (code " + std::to_string(e) +
                    "): a team member was not co-resident or a flag never arrived");
   return TSEM_OK;
@@ -1652,6 +1667,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[0] = h->P; info[1] = h->Kp; info[2] = h->R; info[3] = h->nb;
   info[4] = h->N_amb; info[5] = h->N_uni; info[6] = h->nnz_amb; info[7] = h->nnz_pad;
   info[8] = h->n_twin_cols; info[9] = h->G1; info[10] = h->G2; info[11] = h->use_fused ? 1 : 0;
+  info[12] = h->last_slow_path; info[13] = h->max_subblock; info[14] = 0; info[15] = 0;
   return TSEM_OK;
 }
 

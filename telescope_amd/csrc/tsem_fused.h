@@ -35,9 +35,11 @@ constexpr int FZ_NXW = 2;              // exchange waves (the last FZ_NXW waves)
 constexpr int FZ_DT = FZ_NT - 64 * FZ_NXW;   // data threads
 constexpr int FZ_CAP = FZ_DT * 4;      // register-resident entries per sub-block (one 16-B index load per thread)
 constexpr int FZ_RP = 2;               // row pairs per exchange-wave lane  ->  R <= 2*64*FZ_RP*FZ_NXW = 512
+constexpr int FZ_GAP = 1;              // steps between a block's publish and the partner loads
 constexpr int FZ_NS = 6;               // register sets: block k lives in set k % 6
 constexpr int FZ_DL = 2;               // prefetch distance (steps)
-constexpr int FZ_LAG = 4;              // scatter lag (steps) = FZ_NS - FZ_DL
+constexpr int FZ_LAG = 3 + FZ_GAP;     // scatter lag (steps) = FZ_NS - FZ_DL
+constexpr int FZ_YR = 8;               // y ring (row sums live from step k to k+2+GAP)
 constexpr int FZ_XS = 8;               // exchange slots per team (ring)
 constexpr unsigned FZ_SPIN_LIMIT = 2000000u;
 constexpr int FZ_PROF_SLOTS = 16;
@@ -89,7 +91,9 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   unsigned long long* const xbase = X.xbase;
   const int R = X.R, team = X.team, T = X.T, lane = X.lane;
   const int64_t nblk = X.nblk, nsteps = X.nsteps;
-  const int rlo = X.xw * (R / FZ_NXW), rhi = rlo + R / FZ_NXW;   // rows served by this exchange wave
+  // rows served by this exchange wave: wave 0 fills its 16-byte x 64-lane instructions completely
+  const int rlo = X.xw * (128 * FZ_RP), rhi = min(R, rlo + 128 * FZ_RP);
+  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, FZ_XS * P * R * 8, 0x00027000);
   const bool offw = X.xw == 0;                                  // wave that also ferries the sub-block offsets
   auto slot_of = [&](int64_t k, int q) -> unsigned long long* {
     return xbase + ((int64_t)(k & (FZ_XS - 1)) * P + q) * R;
@@ -114,8 +118,14 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
 #pragma unroll
             for (int q = 0; q < P; ++q) {
               if (q == p) continue;
-              g.pv[q < p ? q : q - 1][j] =
-                  __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(slot_of(k, q) + r));
+              // one 16-byte agent-scope (sc1, L1-bypassing) load per row pair and partner: a raw
+              // buffer load, because plain HIP offers sc1 only on <= 8-byte atomics and an `nt`
+              // load was measured to return stale lines
+              const unsigned boff = (unsigned)((((k & (FZ_XS - 1)) * P + q) * R + r) * 8);
+              typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+              u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, boff, 0, 16);
+              g.pv[q < p ? q : q - 1][j].x = ((unsigned long long)t.y << 32) | t.x;
+              g.pv[q < p ? q : q - 1][j].y = ((unsigned long long)t.w << 32) | t.z;
             }
           }
         }
@@ -130,7 +140,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       for (int j = 0; j < FZ_RP; ++j) {
         const int r = rlo + 2 * (lane + 64 * j);
         if (r < rhi) {
-          u64x2 own = *reinterpret_cast<const u64x2*>(&y[(k & 3) * R + r]);
+          u64x2 own = *reinterpret_cast<const u64x2*>(&y[(k & (FZ_YR - 1)) * R + r]);
           if (P > 1 && !(A.dbg & 1)) {
             unsigned spins = 0;
             for (;;) {                                    // normally true at once: published 2 steps ago
@@ -138,6 +148,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
 #pragma unroll
               for (int i = 0; i < NPART; ++i) ok &= ((g.pv[i][j].x & 1ull) == tag) & ((g.pv[i][j].y & 1ull) == tag);
               if (ok) break;
+              if (spins == 0) atomicAdd(err + 1, 1u);     // statistics: granules that were not there yet
 #pragma unroll
               for (int q = 0; q < P; ++q) {               // slow path: agent-scope (sc1) reloads
                 if (q == p) continue;
@@ -159,7 +170,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
           }
           // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730)
           *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(recip0(ys0) * g.w[j].x, recip0(ys1) * g.w[j].y);
-          *reinterpret_cast<double2*>(&y[(k & 3) * R + r]) = make_double2(0.0, 0.0);
+          *reinterpret_cast<double2*>(&y[(k & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
         }
       }
     };
@@ -174,15 +185,15 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
         for (int j = 0; j < FZ_RP; ++j) {
           const int r = rlo + 2 * (lane + 64 * j);
           if (r < rhi) {
-            u64x2 yv = *reinterpret_cast<const u64x2*>(&y[((i - 1) & 3) * R + r]);
+            u64x2 yv = *reinterpret_cast<const u64x2*>(&y[((i - 1) & (FZ_YR - 1)) * R + r]);
             u64x2 gq = {(yv.x & ~1ull) | tag, (yv.y & ~1ull) | tag};
             *reinterpret_cast<u64x2*>(slot_of(i - 1, p) + r) = gq;
           }
         }
       }
-      issue(gnew, i - 2, i + FZ_DL + 2);                  // ahead of the data waves' burst(i+2)
+      issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 2);         // ahead of the data waves' burst(i+2)
       if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
-      combine(gold, i - 3, i + FZ_DL + 1);                // issued one step ago, behind burst(i)
+      combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 1);       // issued one step ago, behind burst(i)
       if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
       __syncthreads();
       ++i;
@@ -201,8 +212,8 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   const int Kp = A.Kp, R = A.R;
   double* c = reinterpret_cast<double*>(smem);
   double* acc = c + Kp;
-  double* y = acc + Kp;                            // y[4][R]  partial row sums (ring)
-  double* s = y + 4 * R;                           // s[2][R]  w_i / rowsum_i   (ring)
+  double* y = acc + Kp;                            // y[FZ_YR][R]  partial row sums (ring)
+  double* s = y + FZ_YR * R;                       // s[2][R]      w_i / rowsum_i   (ring)
   int* ibox = reinterpret_cast<int*>(s + 2 * R);   // [0]=ticket [1..8]=xcd counts
   const int tid = threadIdx.x;
   uint32_t* const sync = A.sync;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     for (int x = 0; x < 8; ++x) ibox[1 + x] = (int)fz_ld_u32(&sync[x]);
   }
   for (int t = tid; t < Kp; t += FZ_NT) acc[t] = 0.0;
-  for (int t = tid; t < 4 * R; t += FZ_NT) y[t] = 0.0;
+  for (int t = tid; t < FZ_YR * R; t += FZ_NT) y[t] = 0.0;
   for (int t = tid; t < 2 * R; t += FZ_NT) s[t] = 0.0;
   __syncthreads();
   const int ticket = ibox[0];
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     // phase 1: numerators n = Q * (pi*theta) kept in the registers, partial row sums into y(k)
     auto phase1 = [&](FzRegs& rr, int64_t k) {
       if (k < 0 || k >= nblk) return;
-      double* yb = y + (k & 3) * R;
+      double* yb = y + (k & (FZ_YR - 1)) * R;
       rr.v0.x *= c[rr.rc.x & 0xFFFF]; lds_add(&yb[rr.rc.x >> 16], rr.v0.x);
       rr.v0.y *= c[rr.rc.y & 0xFFFF]; lds_add(&yb[rr.rc.y >> 16], rr.v0.y);
       rr.v1.x *= c[rr.rc.z & 0xFFFF]; lds_add(&yb[rr.rc.z >> 16], rr.v1.x);
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     };
     FzRegs r0, r1, r2, r3, r4, r5;
     int64_t i = 0;
-    // step i: `rs` is the set of block i-4 (scattered, then refilled with block i+2); `rp` the set of block i
+    // step i: `rs` is the set of block i-LAG (scattered, then refilled with block i+2); `rp` the set of block i
     auto step = [&](FzRegs& rs, FzRegs& rp) {
       const bool pr = A.prof && team == 0 && p == 0 && tid == 0 && (int)i < A.prof_blocks;
       if (pr) A.prof[i * FZ_PROF_SLOTS + 0] = clock64();
@@ -340,6 +351,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     };
     load_blk(r0, offs[0], offs[1], 0);
     load_blk(r1, offs[2], offs[3], 1);
+    static_assert(FZ_NS == 6 && FZ_LAG == 4 && FZ_DL == 2, "ring unrolling below assumes 6 sets");
     while (i < nsteps) {                                  // block k lives in set k % 6; (i-4) % 6 == (i+2) % 6
       step(r2, r0); if (i >= nsteps) break;               // i % 6 == 0
       step(r3, r1); if (i >= nsteps) break;

@@ -116,17 +116,14 @@ int main() {
   gen<<<8192, 256>>>(rc, val, n, R, Kp);
   CK(hipDeviceSynchronize());
   const int G = 256;
-  run<1024, 2, 3, 2, 1>(rc, val, n, R, Kp, out, G);
-  run<1024, 1, 3, 2, 1>(rc, val, n, R, Kp, out, G);
-  run<1024, 1, 4, 2, 2>(rc, val, n, R, Kp, out, G);
-  run<1024, 1, 5, 2, 3>(rc, val, n, R, Kp, out, G);
-  run<1024, 1, 6, 2, 4>(rc, val, n, R, Kp, out, G);
-  run<1024, 1, 7, 2, 5>(rc, val, n, R, Kp, out, G);
-  run<1024, 1, 8, 2, 6>(rc, val, n, R, Kp, out, G);
-  run<1024, 1, 6, 3, 3>(rc, val, n, R, Kp, out, G);
-  run<1024, 2, 4, 2, 2>(rc, val, n, R, Kp, out, G);
-  run<1024, 2, 5, 2, 3>(rc, val, n, R, Kp, out, G);
-  run<896, 1, 6, 2, 4>(rc, val, n, R, Kp, out, G);
-  run<896, 1, 7, 2, 5>(rc, val, n, R, Kp, out, G);
+  for (int RR : {640, 320, 160}) {
+    R = RR;
+    gen<<<8192, 256>>>(rc, val, n, R, Kp);
+    CK(hipDeviceSynchronize());
+    printf("R=%d\n", R);
+    run<896, 1, 6, 2, 4>(rc, val, n, R, Kp, out, G);
+    run<896, 1, 7, 2, 5>(rc, val, n, R, Kp, out, G);
+    run<1024, 1, 6, 2, 4>(rc, val, n, R, Kp, out, G);
+  }
   return 0;
 }
