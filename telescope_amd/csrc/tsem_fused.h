@@ -176,6 +176,10 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     };
     int64_t i = 0;
     auto xstep = [&](Gen& gnew, Gen& gold) {
+      if (A.dbg & 8) {                                  // timing experiment: exchange waves only keep the barriers
+        if (offw && lane < 2) { const int64_t ko = i + FZ_DL + 1; if (ko >= 4 && ko < nblk) offs[(ko & 7) * 2 + lane] = A.sb_q32[(team + ko * T) * P + p + lane]; }
+        __syncthreads(); ++i; return;
+      }
       const bool pr = A.prof && team == 0 && p == 0 && lane == 0 && offw && (int)i < A.prof_blocks;
       if (pr) A.prof[i * FZ_PROF_SLOTS + 6] = clock64();
       // publish y(i-1): tagged granules, 16-byte stores (a tear between halves is harmless)
@@ -308,14 +312,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
         rr.v0 = reinterpret_cast<const double2*>(A.pval)[2 * q];
         rr.v1 = reinterpret_cast<const double2*>(A.pval)[2 * q + 1];
       } else {
-        rr.rc = make_uint4(0, 0, 0, 0);
-        rr.v0 = make_double2(0.0, 0.0);
-        rr.v1 = make_double2(0.0, 0.0);
+        rr.rc = make_uint4(0xFFFFFFFFu, 0, 0, 0);         // no entries in this lane: both phases skip it
+        rr.v0 = make_double2(0.0, 0.0);                    // (zeros added to y[0] / acc[0] by every idle
+        rr.v1 = make_double2(0.0, 0.0);                    //  lane would serialise on one LDS address)
       }
     };
     // phase 1: numerators n = Q * (pi*theta) kept in the registers, partial row sums into y(k)
     auto phase1 = [&](FzRegs& rr, int64_t k) {
-      if (k < 0 || k >= nblk) return;
+      if (k < 0 || k >= nblk || rr.rc.x == 0xFFFFFFFFu) return;
       double* yb = y + (k & (FZ_YR - 1)) * R;
       rr.v0.x *= c[rr.rc.x & 0xFFFF]; lds_add(&yb[rr.rc.x >> 16], rr.v0.x);
       rr.v0.y *= c[rr.rc.y & 0xFFFF]; lds_add(&yb[rr.rc.y >> 16], rr.v0.y);
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     };
     // phase 2: scatter w * z into the part's column accumulators
     auto phase2 = [&](FzRegs& rr, int64_t k) {
-      if (k < 0 || k >= nblk) return;
+      if (k < 0 || k >= nblk || rr.rc.x == 0xFFFFFFFFu) return;
       const double* sb = s + (k & 1) * R;
       lds_add(&acc[rr.rc.x & 0xFFFF], rr.v0.x * sb[rr.rc.x >> 16]);
       lds_add(&acc[rr.rc.y & 0xFFFF], rr.v0.y * sb[rr.rc.y >> 16]);
