@@ -1,0 +1,53 @@
+"""`telescope resume` end to end: checkpoint -> EM on the GPU -> the two TSVs,
+byte-compared with files written by the reference itself (tools/make_golden_resume.py)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT
+
+
+def test_checkpoint_roundtrip_and_seed(tmp_path):
+    """Checkpoint schema written by the reference's Telescope.save (model.py:108-121)."""
+    from telescope_amd.run_container import Telescope
+    ts = Telescope.load(os.path.join(GOLD, 'resume_checkpoint.npz'))
+    assert ts.shape == (1000, 59) and ts.raw_scores.nnz == 18471 and ts.raw_scores.dtype == np.uint16
+    assert ts.run_info['total_fragments'] == 1000 and ts.run_info['version'] == '1.0.3.1'
+    assert ts.get_random_seed() == 0
+    assert list(ts.feat_index)[0] == '__no_feature' and ts.feature_length['HML2_1q22'] == 9085
+    out = tmp_path / 'again.npz'
+    ts.save(str(out))
+    a, b = np.load(os.path.join(GOLD, 'resume_checkpoint.npz')), np.load(str(out))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    ts.run_info['total_fragments'] = 123456789
+    assert ts.get_random_seed() == (123456789 % 1000 * 59) % 4294967295
+
+
+def test_cli_options_match_reference_defaults():
+    from telescope_amd.cli import build_parser
+    a = build_parser().parse_args(['resume', 'x.npz'])
+    assert (a.reassign_mode, a.conf_prob, a.pi_prior, a.theta_prior, a.em_epsilon, a.max_iter,
+            a.use_likelihood, a.outdir, a.exp_tag) == ('exclude', 0.9, 0, 200000, 1e-7, 100, False, '.', 'telescope')
+    with pytest.raises(SystemExit):
+        build_parser().parse_args(['resume', 'x.npz', '--reassign_mode', 'best'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['exclude', 'choose', 'average', 'conf', 'unique'])
+def test_resume_writes_reference_reports(gpu_device, tmp_path, mode):
+    cmd = [sys.executable, '-m', 'telescope_amd', 'resume', os.path.join(GOLD, 'resume_checkpoint.npz'),
+           '--outdir', str(tmp_path), '--exp_tag', 'run', '--reassign_mode', mode]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'EM converged after 16 iterations.' in r.stderr
+    assert 'Final log-likelihood: 95252.596293.' in r.stderr
+    for suffix in ('run_stats.tsv', 'TE_counts.tsv'):
+        got = open(os.path.join(str(tmp_path), 'run-' + suffix)).read()
+        want = open(os.path.join(GOLD, 'resume_%s-%s' % (mode, suffix))).read()
+        if got != want:   # rows of equal final_prop may come in any order (unstable sort, model.py:449)
+            assert sorted(got.splitlines()) == sorted(want.splitlines()), suffix
