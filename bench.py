@@ -59,6 +59,8 @@ def parse():
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
     ap.add_argument('--cpu-iters', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-comm', action='store_true',
+                    help='use the multi-rank code path (RCCL group, per-iteration all-reduce) even at world size 1')
     return ap.parse_args()
 
 
@@ -107,7 +109,7 @@ def main():
     from telescope_amd.distributed import init_from_env, shard_bounds
     from telescope_amd.likelihood import TelescopeLikelihood
 
-    comm = init_from_env('nccl') if world > 1 else None
+    comm = init_from_env('nccl', force=args.force_comm) if (world > 1 or args.force_comm) else None
     rank = comm.rank if comm else 0
     local = comm.device if comm else 0
     total_rows = args.rows * (world if args.scaling == 'weak' else 1)
@@ -166,6 +168,7 @@ def main():
         elapsed = float(comm.max_array(np.array([elapsed]))[0])
         nnz_total = int(comm.sum_array(np.array([float(nnz_local)]))[0])
     if rank != 0:
+        _shutdown(comm)
         return
 
     info = eng.layout_info()
@@ -218,7 +221,22 @@ def main():
         out['speedup_vs_cpu'] = out['nnz_per_sec'] / cb['nnz_per_sec']
         out['parity_on_sample'] = {k: cb[k] for k in ('lnl_ref', 'lnl_gpu', 'lnl_rel_delta',
                                                       'pi_max_rel_delta', 'sample_rows', 'iters')}
-    print(json.dumps(out))
+    _shutdown(comm)
+    try:   # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def _shutdown(comm):
+    if comm is not None:
+        import torch.distributed as dist
+        try:
+            dist.destroy_process_group()
+        except Exception:   # noqa: BLE001 — never let teardown hide the result line
+            pass
 
 
 if __name__ == '__main__':

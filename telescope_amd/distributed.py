@@ -114,12 +114,19 @@ class Comm(object):
         self._dist.all_reduce(red, op=self._dist.ReduceOp.SUM, group=self.group)
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from torchrun's environment (RANK, WORLD_SIZE,
-    LOCAL_RANK, MASTER_ADDR/PORT) and return a Comm; None when single-process."""
+    LOCAL_RANK, MASTER_ADDR/PORT) and return a Comm; None when single-process
+    (unless `force`, which builds a 1-rank group — used to exercise the N > 1 code path)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and not force:
         return None
+    if world <= 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('LOCAL_RANK', '0')
     import torch
     import torch.distributed as dist
     if backend is None:
