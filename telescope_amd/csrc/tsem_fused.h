@@ -35,8 +35,11 @@ constexpr int FZ_NXW = 2;              // exchange waves (the last FZ_NXW waves)
 constexpr int FZ_DT = FZ_NT - 64 * FZ_NXW;   // data threads
 constexpr int FZ_CAP = FZ_DT * 4;      // register-resident entries per sub-block (one 16-B index load per thread)
 constexpr int FZ_RP = 2;               // row pairs per exchange-wave lane  ->  R <= 2*64*FZ_RP*FZ_NXW = 512
-constexpr int FZ_GAP = 1;              // steps between a block's publish and the partner loads
-constexpr int FZ_NS = 6;               // register sets: block k lives in set k % 6
+#ifndef FZ_GAP_STEPS
+#define FZ_GAP_STEPS 1
+#endif
+constexpr int FZ_GAP = FZ_GAP_STEPS;   // steps between a block's publish and the partner loads
+constexpr int FZ_NS = 5 + FZ_GAP;      // register sets: block k lives in set k % FZ_NS
 constexpr int FZ_DL = 2;               // prefetch distance (steps)
 constexpr int FZ_LAG = 3 + FZ_GAP;     // scatter lag (steps) = FZ_NS - FZ_DL
 constexpr int FZ_YR = 8;               // y ring (row sums live from step k to k+2+GAP)
@@ -101,6 +104,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   auto tag_of = [&](int64_t k) -> unsigned long long {
     return (unsigned long long)((((k / FZ_XS) & 1) ^ 1));
   };
+  if (!(A.dbg & 16)) __builtin_amdgcn_s_setprio(3);   // few instructions, all on the critical path of the step
     struct Gen { u64x2 pv[NPART][FZ_RP]; double2 w[FZ_RP]; uint32_t off; };
     Gen ga, gb;
     ga.off = gb.off = 0;
@@ -336,6 +340,9 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       lds_add(&acc[rr.rc.w & 0xFFFF], rr.v1.y * sb[rr.rc.w >> 16]);
     };
     FzRegs r0, r1, r2, r3, r4, r5;
+#if FZ_GAP_STEPS == 2
+    FzRegs r6;
+#endif
     int64_t i = 0;
     // step i: `rs` is the set of block i-LAG (scattered, then refilled with block i+2); `rp` the set of block i
     auto step = [&](FzRegs& rs, FzRegs& rp) {
@@ -355,6 +362,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     };
     load_blk(r0, offs[0], offs[1], 0);
     load_blk(r1, offs[2], offs[3], 1);
+#if FZ_GAP_STEPS == 1
     static_assert(FZ_NS == 6 && FZ_LAG == 4 && FZ_DL == 2, "ring unrolling below assumes 6 sets");
     while (i < nsteps) {                                  // block k lives in set k % 6; (i-4) % 6 == (i+2) % 6
       step(r2, r0); if (i >= nsteps) break;               // i % 6 == 0
@@ -364,6 +372,18 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       step(r0, r4); if (i >= nsteps) break;
       step(r1, r5);
     }
+#else
+    static_assert(FZ_NS == 7 && FZ_LAG == 5 && FZ_DL == 2, "ring unrolling below assumes 7 sets");
+    while (i < nsteps) {                                  // block k lives in set k % 7; (i-5) % 7 == (i+2) % 7
+      step(r2, r0); if (i >= nsteps) break;               // i % 7 == 0
+      step(r3, r1); if (i >= nsteps) break;
+      step(r4, r2); if (i >= nsteps) break;
+      step(r5, r3); if (i >= nsteps) break;
+      step(r6, r4); if (i >= nsteps) break;
+      step(r0, r5); if (i >= nsteps) break;
+      step(r1, r6);
+    }
+#endif
   }
   __syncthreads();
   double* out = A.partial + (int64_t)team * (P * Kp) + p * Kp;
