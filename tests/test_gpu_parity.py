@@ -276,3 +276,65 @@ def test_rccl_comm_path_single_rank(gpu_device):
             assert np.array_equal(tl.reassign_colsums('exclude'), c['ra_exclude_0_colsum'])
     finally:
         dist.destroy_process_group()
+
+
+def _oracle_vs_gpu(raw, iters=4, options=(), rtol=RTOL):
+    """EM for `iters` fixed iterations on the GPU and in the oracle; returns the layout used."""
+    from oracle.telescope_oracle import OracleModel
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+    raw = sp.csr_matrix(raw)
+    eng = _lib.Engine(0)
+    for k, v in options:
+        eng.set_option(k, v)
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), raw.shape[1], score_lut(int(raw.data.max())))
+    tl = TelescopeLikelihood.from_engine(eng, Opts(max_iter=iters, em_epsilon=0.0))
+    tl._raw = raw
+    tl.em()
+    om = OracleModel(raw)
+    om.em(0.0, iters)
+    assert abs(tl.lnl - om.lnl) <= rtol * abs(om.lnl)
+    assert np.allclose(tl.pi, om.pi, rtol=rtol, atol=0) and np.allclose(tl.theta, om.theta, rtol=rtol, atol=0)
+    assert np.array_equal(tl.reassign_colsums('exclude'), np.asarray(om.reassign('exclude').sum(0)).ravel())
+    z = sp.csr_matrix(tl.z)
+    assert np.allclose(z.data, sp.csr_matrix(om.z).data, rtol=rtol, atol=1e-300)
+    return eng.layout_info()
+
+
+@pytest.mark.parametrize('cols,expect_parts', [(9000, 2), (20000, 3), (30000, 4), (40000, 6)])
+def test_column_part_counts(gpu_device, cols, expect_parts):
+    """P = 2, 3, 4 run the fused kernel; P = 6 (K > 30720) falls back to the two-pass kernels."""
+    from telescope_amd import synthetic
+    ip, ix, rw = synthetic.generate(60000, cols, 24, seed=11, dist='zipf', uniq_frac=0.05)
+    info = _oracle_vs_gpu(sp.csr_matrix((rw, ix, ip), shape=(60000, cols)))
+    assert info['P'] == expect_parts
+    assert info['fused'] == (1 if expect_parts <= 4 else 0)
+
+
+def test_ragged_rows_and_kernel_variants(gpu_device):
+    """Very uneven row lengths (1 .. 3000 entries, a few rows longer than the register tile of a
+    fused sub-block) — exercises the block-size retry / two-pass fallback — and both EM kernels on
+    the same matrix."""
+    rng = np.random.RandomState(5)
+    n, k = 30000, 12000
+    lens = np.where(rng.rand(n) < 0.002, rng.randint(1500, 3000, n), rng.randint(1, 30, n))
+    lens[::97] = 1
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.randint(100, 400, indptr[-1]).astype(np.uint16)
+    raw = sp.csr_matrix((data, indices, indptr), shape=(n, k))
+    a = _oracle_vs_gpu(raw, options=(('em_kernel', 2),))
+    b = _oracle_vs_gpu(raw, options=(('em_kernel', 1),))
+    assert b['fused'] == 0 and a['P'] == b['P'] == 2
+
+
+def test_fused_and_twopass_agree_at_scale(gpu_device):
+    """5M x 30k x 40: the two EM kernels give the same parameters (summation order aside)."""
+    res = []
+    for kern in (1, 2):
+        tl = _synthetic_tl(5_000_000, 30000, 40, 'zipf', options=(('em_kernel', kern),))
+        tl.em()
+        res.append((tl.pi.copy(), tl.lnl, tl._eng.layout_info()['fused']))
+    assert res[0][2] == 0 and res[1][2] == 1
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-10, atol=0)
+    assert abs(res[0][1] - res[1][1]) <= 1e-11 * abs(res[0][1])
