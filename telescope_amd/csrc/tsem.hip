@@ -233,6 +233,39 @@ __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, 
     }
 }
 
+// entries of each ambiguous row per column part, packed 4 x 16 bit (fused layout, P <= 4)
+__global__ __launch_bounds__(256) void k_row_partcounts(int64_t N_amb, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap,
+    unsigned long long* __restrict__ out) {
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int64_t a = (int64_t)blockIdx.x * subs + sub; a < N_amb; a += (int64_t)gridDim.x * subs) {
+    int64_t i = amb_row[a];
+    int64_t s = indptr[i], e = indptr[i + 1];
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int64_t k = s + lane; k < e; k += RS_SUB) {
+      uint32_t p = colmap[indices[k]] >> 16;
+      c0 += p == 0; c1 += p == 1; c2 += p == 2; c3 += p == 3;
+    }
+    c0 = sg_sum_i<RS_SUB>(c0); c1 = sg_sum_i<RS_SUB>(c1); c2 = sg_sum_i<RS_SUB>(c2); c3 = sg_sum_i<RS_SUB>(c3);
+    if (lane == 0)
+      out[a] = (unsigned long long)min(c0, 65535) | ((unsigned long long)min(c1, 65535) << 16) |
+               ((unsigned long long)min(c2, 65535) << 32) | ((unsigned long long)min(c3, 65535) << 48);
+  }
+}
+
+// rows of block b are the compact ambiguous rows [bstart[b], bstart[b+1]); the rest of its R slots are holes
+__global__ __launch_bounds__(256) void k_make_slots(int64_t nb, int R, const int64_t* __restrict__ bstart,
+    const int32_t* __restrict__ amb_row, const uint16_t* __restrict__ wcode_c, int32_t* __restrict__ slot_row,
+    uint16_t* __restrict__ slot_wcode) {
+  int64_t b = blockIdx.x;
+  const int64_t a0 = bstart[b], n = bstart[b + 1] - a0;
+  for (int lr = threadIdx.x; lr < R; lr += blockDim.x) {
+    const bool v = lr < n;
+    slot_row[b * R + lr] = v ? amb_row[a0 + lr] : -1;
+    slot_wcode[b * R + lr] = v ? wcode_c[a0 + lr] : (uint16_t)0;
+  }
+}
+
 // per (row block, part) entry counts — one WG per block
 __global__ __launch_bounds__(256) void k_sb_count(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap,
@@ -243,9 +276,8 @@ __global__ __launch_bounds__(256) void k_sb_count(int64_t N_amb, int R, int P, c
   int64_t b = blockIdx.x;
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
   for (int lr = sub; lr < R; lr += subs) {
-    int64_t a = b * R + lr;
-    if (a >= N_amb) break;
-    int64_t i = amb_row[a];
+    int64_t i = amb_row[b * R + lr];                  // row slot -> CSR row, -1 = hole
+    if (i < 0) continue;
     int64_t s = indptr[i], e = indptr[i + 1];
     for (int64_t k = s + lane; k < e; k += RS_SUB) atomicAdd(&cnt[colmap[indices[k]] >> 16], 1u);
   }
@@ -263,9 +295,8 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
   int64_t b = blockIdx.x;
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
   for (int lr = sub; lr < R; lr += subs) {
-    int64_t a = b * R + lr;
-    if (a >= N_amb) break;
-    int64_t i = amb_row[a];
+    int64_t i = amb_row[b * R + lr];
+    if (i < 0) continue;
     int64_t s = indptr[i], e = indptr[i + 1];
     for (int64_t k = s + lane; k < e; k += RS_SUB) {
       uint32_t cm = colmap[indices[k]];
@@ -713,7 +744,7 @@ static void free_layout(tsem_ctx* h) {
 }
 static void free_matrix(tsem_ctx* h) {
   dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_raw); dfree(h->d_lut);
-  dfree(h->d_amb_row); dfree(h->d_amb_wcode); dfree(h->d_uni_col); dfree(h->d_uni_code);
+  dfree(h->d_amb_row); dfree(h->d_amb_wcode); dfree(h->d_amb_wcode_c); dfree(h->d_slot_row); dfree(h->d_uni_col); dfree(h->d_uni_code);
   dfree(h->d_pisum0); dfree(h->d_twin_rep);
   free_layout(h);
   dfree(h->d_pi); dfree(h->d_theta); dfree(h->d_pi_prev); dfree(h->d_theta_prev);
@@ -1009,10 +1040,13 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     if (h->use_fused && na > 0) {
       // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
       double mean_len = (double)(h->nnz - nu) / (double)na;
-      double r = h->fill_target * FZ_CAP * P / std::max(2.0, mean_len);
+      // row SLOTS per block: ~7 % above the average a register tile takes, so blocks end on the
+      // tile's capacity, not on R (the exchange cost depends on R, hence not more than needed)
+      double r = 1.07 * FZ_CAP * P / std::max(2.0, mean_len);
       int rmax = std::min(2 * 64 * FZ_RP * FZ_NXW, (TS_LDS_MAX - 2048 - 2 * Kp * 8) / ((FZ_YR + 2) * 8));
       R = (int)std::min<double>(r, rmax);
-      R = std::max(64, R / 8 * 8);
+      R = std::max(64, (R + 63) / 64 * 64);
+      R = std::min(R, rmax / 8 * 8);
     }
     if (h->opt_R > 0) R = (int)h->opt_R;
     h->R = R;
@@ -1021,13 +1055,12 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   h->nb = (na + h->R - 1) / h->R;
   h->N_amb_pad = std::max<int64_t>(1, h->nb) * h->R;
   TSEM_ALLOC(h->d_amb_row, na);
-  TSEM_ALLOC(h->d_amb_wcode, na + 65536 + 8);             // room for any block size chosen later
+  TSEM_ALLOC(h->d_amb_wcode_c, na);                       // per compact row; build_layout makes the slot copy
   TSEM_ALLOC(h->d_uni_col, nu);
   TSEM_ALLOC(h->d_uni_code, nu);
-  TSEM_HIP(hipMemsetAsync(h->d_amb_wcode, 0, sizeof(uint16_t) * (na + 65536 + 8), h->stream));
   if (N)
     k_compact_rows<<<cdiv64(N, 256), 256, 0, h->stream>>>(N, d_cls, d_fa, d_fu, h->d_indptr, h->d_indices, h->d_raw,
-                                                         d_code, h->d_amb_row, h->d_amb_wcode, h->d_uni_col,
+                                                         d_code, h->d_amb_row, h->d_amb_wcode_c, h->d_uni_col,
                                                          h->d_uni_code);
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipStreamSynchronize(h->stream));
@@ -1063,14 +1096,64 @@ static int build_layout(tsem_ctx* h) {
   TSEM_ALLOC(h->d_col_of_pc, h->Kpad);
   TSEM_HIP(hipMemcpy(h->d_colmap, colmap.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice));
   TSEM_HIP(hipMemcpy(h->d_col_of_pc, col_of_pc.data(), sizeof(int32_t) * h->Kpad, hipMemcpyHostToDevice));
-  // 3. sub-block sizes -> offsets (each padded to a multiple of 4 entries)
-  const int64_t nb = h->nb;
+  // 3. row blocks.  Two-pass layout: R rows each.  Fused layout: as many consecutive rows as the
+  //    register tile takes (no part may exceed FZ_CAP entries, at most R rows) — rows per block vary,
+  //    every block still owns R row SLOTS (holes at the end), so all kernels keep b*R+lr indexing.
   const int R = h->R;
+  std::vector<int64_t> bstart;
+  if (h->use_fused && na > 0 && P <= 4) {
+    unsigned long long* d_pc = nullptr;
+    TSEM_ALLOC(d_pc, na);
+    k_row_partcounts<<<(unsigned)std::min<int64_t>(65535, (na + 15) / 16), 256, 0, h->stream>>>(
+        na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc);
+    TSEM_HIP(hipGetLastError());
+    std::vector<unsigned long long> pc(na);
+    TSEM_HIP(hipMemcpyAsync(pc.data(), d_pc, sizeof(unsigned long long) * na, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_pc);
+    const int cap = (int)(FZ_CAP - TS_STRANDS * 4);      // sub-blocks are padded to TS_STRANDS*4 entries
+    int c[4] = {0, 0, 0, 0}, rows = 0;
+    bstart.push_back(0);
+    for (int64_t a = 0; a < na; ++a) {
+      const unsigned long long v = pc[a];
+      const int r0 = (int)(v & 0xFFFF), r1 = (int)((v >> 16) & 0xFFFF), r2 = (int)((v >> 32) & 0xFFFF), r3 = (int)(v >> 48);
+      if (r0 > cap || r1 > cap || r2 > cap || r3 > cap) { h->use_fused = false; break; }   // one row overflows the tile
+      if (rows == R || c[0] + r0 > cap || c[1] + r1 > cap || c[2] + r2 > cap || c[3] + r3 > cap) {
+        bstart.push_back(a);
+        c[0] = c[1] = c[2] = c[3] = 0; rows = 0;
+      }
+      c[0] += r0; c[1] += r1; c[2] += r2; c[3] += r3; ++rows;
+    }
+    bstart.push_back(na);
+  }
+  if (!h->use_fused || bstart.empty()) {
+    bstart.clear();
+    for (int64_t a = 0; a < na; a += R) bstart.push_back(a);
+    bstart.push_back(na);
+    if (na == 0) bstart.assign(1, 0);
+  }
+  const int64_t nb = (int64_t)bstart.size() - 1;
+  h->nb = nb;
+  h->N_amb_pad = std::max<int64_t>(1, nb) * R;
+  {
+    int64_t* d_bs = nullptr;
+    TSEM_ALLOC(d_bs, nb + 1);
+    TSEM_HIP(hipMemcpy(d_bs, bstart.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice));
+    TSEM_ALLOC(h->d_slot_row, h->N_amb_pad);
+    TSEM_ALLOC(h->d_amb_wcode, h->N_amb_pad);
+    if (nb) k_make_slots<<<(unsigned)nb, 256, 0, h->stream>>>(nb, R, d_bs, h->d_amb_row, h->d_amb_wcode_c,
+                                                             h->d_slot_row, h->d_amb_wcode);
+    else TSEM_HIP(hipMemsetAsync(h->d_amb_wcode, 0, sizeof(uint16_t) * h->N_amb_pad, h->stream));
+    TSEM_HIP(hipGetLastError());
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_bs);
+  }
+  // 4. sub-block sizes -> offsets
   std::vector<int64_t> sb(nb * P + 1, 0);
   if (nb) {
     int64_t* d_cnt = nullptr;
     TSEM_ALLOC(d_cnt, nb * P);
-    k_sb_count<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_cnt);
+    k_sb_count<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_colmap, d_cnt);
     TSEM_HIP(hipGetLastError());
     TSEM_HIP(hipMemcpyAsync(sb.data(), d_cnt, sizeof(int64_t) * nb * P, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
@@ -1105,7 +1188,7 @@ static int build_layout(tsem_ctx* h) {
   TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
   TSEM_HIP(hipMemsetAsync(h->d_prc, 0, sizeof(uint32_t) * std::max<int64_t>(1, off), h->stream));
   if (nb) {
-    k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_amb_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
+    k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                   h->d_colmap, h->d_sb_off, h->d_pval, h->d_prc);
     TSEM_HIP(hipGetLastError());
   }
@@ -1180,19 +1263,7 @@ int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, cons
     }
     TSEM_HIP(hipMemcpy(h->d_pisum0, ps.data(), sizeof(double) * K, hipMemcpyHostToDevice));
   }
-  const bool want_fused = h->use_fused;
-  for (int attempt = 0;; ++attempt) {
-    if (int rc = build_layout(h)) return rc;
-    if (!want_fused || h->use_fused || h->opt_R > 0 || attempt >= 4 || h->max_subblock <= FZ_CAP) break;
-    // a sub-block outgrew the register tile: shrink the row blocks and lay out again
-    int R = (int)((double)h->R * FZ_CAP / (double)h->max_subblock * 0.985);
-    R = std::max(64, R / 8 * 8);
-    if (R >= h->R) break;
-    h->R = R;
-    h->nb = (h->N_amb + R - 1) / R;
-    h->N_amb_pad = std::max<int64_t>(1, h->nb) * R;
-    h->use_fused = true;
-  }
+  if (int rc = build_layout(h)) return rc;
   TSEM_ALLOC(h->d_pi, K); TSEM_ALLOC(h->d_theta, K); TSEM_ALLOC(h->d_pi_prev, K); TSEM_ALLOC(h->d_theta_prev, K);
   TSEM_ALLOC(h->d_tmp_pi, K); TSEM_ALLOC(h->d_tmp_theta, K);
   TSEM_ALLOC(h->d_ctab, h->Kpad); TSEM_ALLOC(h->d_ctab_prev, h->Kpad);

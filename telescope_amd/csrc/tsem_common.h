@@ -67,7 +67,9 @@ struct tsem_ctx {
   // ---- row classes ----
   int64_t N_amb = 0, N_uni = 0, nnz_amb = 0;
   int32_t* d_amb_row = nullptr;     // [N_amb]  compact ambiguous row -> CSR row
-  uint16_t* d_amb_wcode = nullptr;  // [N_amb_pad] max raw code of the row (w = lut[code])
+  uint16_t* d_amb_wcode = nullptr;  // [N_amb_pad] per row SLOT: max raw code of the row (w = lut[code]), 0 = hole
+  uint16_t* d_amb_wcode_c = nullptr;  // [N_amb]   same, per compact ambiguous row
+  int32_t* d_slot_row = nullptr;    // [N_amb_pad] row slot -> CSR row, -1 = hole
   int32_t* d_uni_col = nullptr;     // [N_uni]
   uint16_t* d_uni_code = nullptr;   // [N_uni]
   uint32_t* d_maxcode = nullptr;    // [1]

@@ -195,10 +195,15 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
           if (r < rhi) {
             u64x2 yv = *reinterpret_cast<const u64x2*>(&y[((i - 1) & (FZ_YR - 1)) * R + r]);
             u64x2 gq = {(yv.x & ~1ull) | tag, (yv.y & ~1ull) | tag};
+            // PLAIN store: the line stays in the XCD's L2, where the partners' sc1 loads find it (a
+            // write-through sc1 store drops it from L2: measured 14 M tag misses per pass vs 0.14 M)
             *reinterpret_cast<u64x2*>(slot_of(i - 1, p) + r) = gq;
           }
         }
       }
+      // the publish must enter the memory pipe BEFORE this step's loads (partners read it a step later)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 2);         // ahead of the data waves' burst(i+2)
       if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
       combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 1);       // issued one step ago, behind burst(i)
