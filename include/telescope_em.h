@@ -156,6 +156,9 @@ int  tsem_csr_norm_rows(int device, int64_t n_rows, const int64_t* indptr,
                         const double* data, double* out);            /* norm(1)  :46-52  */
 int  tsem_csr_binmax_rows(int device, int64_t n_rows, int32_t n_cols, const int64_t* indptr,
                           const double* data, int8_t* out);          /* binmax(1):117-129 */
+/* mode 0: norm() :47-48   mode 1: scale() :94-95   mode 2: scale(1) :96-97 */
+int  tsem_csr_scale(int device, int mode, int64_t n_rows, int32_t n_cols, const int64_t* indptr,
+                    const double* data, double* out);
 
 /* ---- instrumentation ------------------------------------------------------ */
 /* HIP-event time (ms) and launch count of the dominant EM kernel(s) since the

@@ -108,6 +108,7 @@ def lib():
     L.tsem_reassign.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, vp]
     L.tsem_csr_norm_rows.argtypes = [C.c_int, i64, vp, vp, vp]
     L.tsem_csr_binmax_rows.argtypes = [C.c_int, i64, i32, vp, vp, vp]
+    L.tsem_csr_scale.argtypes = [C.c_int, C.c_int, i64, i32, vp, vp, vp]
     L.tsem_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
     L.tsem_layout_info.argtypes = [vp, vp]
     L.tsem_debug_fused_prof.argtypes = [vp, vp]
@@ -347,4 +348,15 @@ def csr_binmax_rows(indptr, data, n_cols, device=0):
     rc = lib().tsem_csr_binmax_rows(device, len(indptr) - 1, int(n_cols), ptr(indptr), ptr(data), ptr(out))
     if rc != OK:
         raise EngineError('tsem_csr_binmax_rows failed (%d): %s' % (rc, lib().tsem_last_error(None).decode()))
+    return out
+
+
+def csr_scale(mode, indptr, data, n_cols, device=0):
+    """mode 0: norm(); 1: scale(); 2: scale(1)  (sparse_plus.py:46-52, 93-97)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    out = np.empty_like(data)
+    rc = lib().tsem_csr_scale(device, int(mode), len(indptr) - 1, int(n_cols), ptr(indptr), ptr(data), ptr(out))
+    if rc != OK:
+        raise EngineError('tsem_csr_scale failed (%d): %s' % (rc, lib().tsem_last_error(None).decode()))
     return out

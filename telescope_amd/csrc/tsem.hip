@@ -711,6 +711,42 @@ __global__ __launch_bounds__(256) void k_binmax_rows(int64_t N, int32_t K, const
   }
 }
 
+// whole-matrix reductions for csr_matrix_plus.norm() / scale() (sparse_plus.py:46-48, 93-95)
+__global__ __launch_bounds__(256) void k_reduce_all(const double* __restrict__ v, int64_t n, int want_max,
+                                                    double* __restrict__ part) {
+  __shared__ double scratch[16];
+  double acc = want_max ? -INFINITY : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    acc = want_max ? fmax(acc, v[i]) : acc + v[i];
+  if (want_max) {
+    acc = sg_max<64>(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { double m = scratch[0]; for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmax(m, scratch[i]); part[blockIdx.x] = m; }
+  } else {
+    double t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+  }
+}
+__global__ void k_scale_all(const double* __restrict__ v, int64_t n, double f, double* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = v[i] * f;
+}
+__global__ __launch_bounds__(256) void k_scale_rows(int64_t N, int32_t K, const int64_t* __restrict__ indptr,
+                                                    const double* __restrict__ data, double* __restrict__ out) {
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
+    int64_t s = indptr[row], e = indptr[row + 1];
+    double m = -INFINITY;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) m = fmax(m, data[k]);
+    m = sg_max<RP_SUB>(m);
+    if ((e - s) < K) m = fmax(m, 0.0);                 // implicit zeros take part in max(1)
+    double r = recip0(m);
+    for (int64_t k = s + lane; k < e; k += RP_SUB) out[k] = data[k] * r;
+  }
+}
+
 // ============================================================================
 // host side
 // ============================================================================
@@ -1694,6 +1730,48 @@ static int csr_prim(int device, int64_t n_rows, int32_t n_cols, const int64_t* i
   if (d_in) (void)hipFree(d_in);
   if (d_od) (void)hipFree(d_od);
   if (d_ob) (void)hipFree(d_ob);
+  return rc;
+}
+
+// mode 0: out = data * (1 / sum(data))   norm()   sparse_plus.py:47-48
+// mode 1: out = data * (1 / max(data))   scale()  sparse_plus.py:94-95   (max over the matrix incl. implicit zeros)
+// mode 2: out = data * recip0(row max)   scale(1) sparse_plus.py:96-97
+int tsem_csr_scale(int device, int mode, int64_t n_rows, int32_t n_cols, const int64_t* indptr, const double* data,
+                   double* out) {
+  if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed (no usable HIP device)"; return TSEM_ERR_HIP; }
+  if (n_rows < 0 || !indptr || mode < 0 || mode > 2) return TSEM_ERR_ARG;
+  const int64_t nnz = indptr[n_rows];
+  int64_t* d_ip = nullptr; double *d_in = nullptr, *d_out = nullptr, *d_part = nullptr;
+  const int G = 512;
+  bool ok = hipMalloc((void**)&d_ip, sizeof(int64_t) * (n_rows + 1)) == hipSuccess &&
+            hipMalloc((void**)&d_in, sizeof(double) * std::max<int64_t>(1, nnz)) == hipSuccess &&
+            hipMalloc((void**)&d_out, sizeof(double) * std::max<int64_t>(1, nnz)) == hipSuccess &&
+            hipMalloc((void**)&d_part, sizeof(double) * G) == hipSuccess;
+  int rc = TSEM_OK;
+  if (!ok) { g_create_err = "hipMalloc failed"; rc = TSEM_ERR_NOMEM; }
+  if (ok) {
+    (void)hipMemcpy(d_ip, indptr, sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice);
+    if (nnz) (void)hipMemcpy(d_in, data, sizeof(double) * nnz, hipMemcpyHostToDevice);
+    if (mode == 2) {
+      int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n_rows + 15) / 16));
+      if (n_rows) k_scale_rows<<<grid, 256>>>(n_rows, n_cols, d_ip, d_in, d_out);
+    } else if (nnz) {
+      k_reduce_all<<<G, 256>>>(d_in, nnz, mode == 1, d_part);
+      std::vector<double> part(G);
+      (void)hipMemcpy(part.data(), d_part, sizeof(double) * G, hipMemcpyDeviceToHost);
+      double r = mode == 1 ? -INFINITY : 0.0;
+      for (int i = 0; i < G; ++i) r = mode == 1 ? std::max(r, part[i]) : r + part[i];
+      if (mode == 1 && nnz < n_rows * (int64_t)n_cols) r = std::max(r, 0.0);
+      k_scale_all<<<cdiv64(nnz, 256), 256>>>(d_in, nnz, 1.0 / r, d_out);
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { g_create_err = hipGetErrorString(e); rc = TSEM_ERR_HIP; }
+    if (rc == TSEM_OK && nnz) (void)hipMemcpy(out, d_out, sizeof(double) * nnz, hipMemcpyDeviceToHost);
+  }
+  if (d_ip) (void)hipFree(d_ip);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (d_part) (void)hipFree(d_part);
   return rc;
 }
 
