@@ -4,7 +4,10 @@ telescope/__main__.py:49-92).  Same option names and defaults, same log lines, s
 
     python -m telescope_amd resume <checkpoint.npz> [--reassign_mode exclude] [--outdir .] ...
 
-`assign` needs the BAM/GTF loader, which is outside the accelerated path.
+    python -m telescope_amd assign <alignments.bam> <annotation.gtf> [...]
+
+`assign` (telescope/telescope_assign.py:372-451) uses telescope_amd/loader.py, a pysam-free
+restatement of the reference's sequential loader; `--updated_sam` and `--ncpu > 1` are not offered.
 """
 import argparse
 import logging as lg
@@ -50,7 +53,44 @@ def build_parser():
     g.add_argument('--skip_em', action='store_true', help='Exits after loading the checkpoint.')
     g = rs.add_argument_group('Device')
     g.add_argument('--device', type=int, default=0, help='GPU index (single-process runs).')
-    sub.add_parser('assign', help='(not available: needs the BAM/GTF loader of the reference)')
+    asg = sub.add_parser('assign', help='Load alignments + annotation, checkpoint, EM, reports')
+    g = asg.add_argument_group('Input Options')
+    g.add_argument('samfile', help='Path to alignment file (BAM, collated by read name).')
+    g.add_argument('gtffile', help='Path to annotation file (GTF format)')
+    g.add_argument('--attribute', default='locus',
+                   help='GTF attribute that defines a transposable element locus.')
+    g.add_argument('--no_feature_key', default='__no_feature',
+                   help='Used internally to represent alignments that do not overlap any feature.')
+    g.add_argument('--ncpu', type=int, default=1, help='Only 1 is supported (sequential loader).')
+    g = asg.add_argument_group('Reporting Options')
+    g.add_argument('--quiet', action='store_true', help='Silence (most) output.')
+    g.add_argument('--debug', action='store_true', help='Print debug messages.')
+    g.add_argument('--logfile', type=argparse.FileType('a'), help='Log output to this file.')
+    g.add_argument('--outdir', default='.', help='Output directory.')
+    g.add_argument('--exp_tag', default='telescope', help='Experiment tag')
+    g.add_argument('--updated_sam', action='store_true', help='(not available in this engine)')
+    g = asg.add_argument_group('Run Modes')
+    g.add_argument('--reassign_mode', default='exclude',
+                   choices=['exclude', 'choose', 'average', 'conf', 'unique'],
+                   help='Reassignment mode for the final counts.')
+    g.add_argument('--conf_prob', type=float, default=0.9,
+                   help='Minimum probability for high confidence assignment.')
+    g.add_argument('--overlap_mode', default='threshold', choices=['threshold', 'intersection-strict', 'union'],
+                   help='Overlap mode (only "threshold" is implemented, as in the reference).')
+    g.add_argument('--overlap_threshold', type=float, default=0.2,
+                   help='Fraction of fragment that must be contained within a feature.')
+    g.add_argument('--stranded_mode', default='None', choices=['None', 'RF', 'R', 'FR', 'F'],
+                   help='Stranded library orientation.')
+    g = asg.add_argument_group('Model Parameters')
+    g.add_argument('--pi_prior', type=int, default=0, help='Prior on pi.')
+    g.add_argument('--theta_prior', type=int, default=200000, help='Prior on theta.')
+    g.add_argument('--em_epsilon', type=float, default=1e-7, help='EM Algorithm Epsilon cutoff')
+    g.add_argument('--max_iter', type=int, default=100, help='EM Algorithm maximum iterations')
+    g.add_argument('--use_likelihood', action='store_true',
+                   help='Use difference in log-likelihood as convergence criteria.')
+    g.add_argument('--skip_em', action='store_true', help='Exits after loading alignment and saving checkpoint file.')
+    g = asg.add_argument_group('Device')
+    g.add_argument('--device', type=int, default=0, help='GPU index (single-process runs).')
     return ap
 
 
@@ -65,10 +105,11 @@ class ResumeOptions(object):
         return os.path.join(self.outdir, '%s-%s' % (self.exp_tag, suffix))
 
     def __str__(self):
-        keys = ('checkpoint', 'quiet', 'debug', 'outdir', 'exp_tag', 'reassign_mode', 'conf_prob',
-                'pi_prior', 'theta_prior', 'em_epsilon', 'max_iter', 'use_likelihood')
+        keys = ('checkpoint', 'samfile', 'gtffile', 'attribute', 'quiet', 'debug', 'outdir', 'exp_tag',
+                'reassign_mode', 'conf_prob', 'overlap_mode', 'overlap_threshold', 'stranded_mode',
+                'pi_prior', 'theta_prior', 'em_epsilon', 'max_iter', 'use_likelihood', 'skip_em')
         lines = ['{:34}{}'.format('Version:', self.version)]
-        lines += ['    {:30}{}'.format(k + ':', getattr(self, k)) for k in keys]
+        lines += ['    {:30}{}'.format(k + ':', getattr(self, k)) for k in keys if hasattr(self, k)]
         return '\n'.join(lines)
 
 
@@ -109,14 +150,60 @@ def run_resume(args):
     return 0
 
 
+def run_assign(args):
+    """telescope_assign.py:372-451."""
+    from .likelihood import TelescopeLikelihood
+    from .loader import Annotation
+    from .run_container import Telescope
+    opts = ResumeOptions(args)
+    configure_logging(opts)
+    if opts.updated_sam or opts.ncpu != 1:
+        raise SystemExit('--updated_sam and --ncpu > 1 are not available in this engine')
+    lg.info('\n{}\n'.format(opts))
+    total_time = time()
+    ts = Telescope(opts)
+    ts.run_info['version'] = opts.version
+    lg.info('Loading annotation...')
+    stime = time()
+    annot = Annotation(opts.gtffile, opts.attribute, opts.stranded_mode)
+    lg.info('Loaded annotation in {}'.format(format_minutes(time() - stime)))
+    lg.info('Loaded {} features.'.format(len(annot.loci)))
+    lg.info('Loading alignments...')
+    stime = time()
+    ts.load_alignment(annot)
+    lg.info('Loaded alignment in {}'.format(format_minutes(time() - stime)))
+    ts.print_summary(lg.INFO)
+    if ts.run_info['overlap_unique'] + ts.run_info['overlap_ambig'] == 0:
+        lg.info('No alignments overlapping annotation')
+        lg.info('telescope assign complete (%s)' % format_minutes(time() - total_time))
+        return 0
+    os.makedirs(opts.outdir, exist_ok=True)
+    ts.save(opts.outfile_path('checkpoint'))
+    if opts.skip_em:
+        lg.info('Skipping EM...')
+        lg.info('telescope assign complete (%s)' % format_minutes(time() - total_time))
+        return 0
+    seed = ts.get_random_seed()
+    lg.debug('Random seed: {}'.format(seed))
+    np.random.seed(seed)
+    ts_model = TelescopeLikelihood(ts.raw_scores, opts, device=opts.device)
+    lg.info('Running Expectation-Maximization...')
+    stime = time()
+    ts_model.em(use_likelihood=opts.use_likelihood, loglev=lg.INFO)
+    lg.info('EM completed in %s' % format_minutes(time() - stime))
+    lg.info('Generating Report...')
+    ts.output_report(ts_model, opts.outfile_path('run_stats.tsv'), opts.outfile_path('TE_counts.tsv'))
+    lg.info('telescope assign complete (%s)' % format_minutes(time() - total_time))
+    return 0
+
+
 def main(argv=None):
     ap = build_parser()
     args = ap.parse_args(argv)
     if args.command == 'resume':
         return run_resume(args)
     if args.command == 'assign':
-        ap.error('`assign` needs the BAM/GTF loader, which is outside this engine; run the reference '
-                 '`telescope assign --skip_em` to write a checkpoint, then `resume` it here.')
+        return run_assign(args)
     ap.print_help()
     return 2
 

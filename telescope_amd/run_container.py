@@ -34,6 +34,20 @@ class Telescope(object):
         self.shape = None
         self.raw_scores = None
 
+    # ---- alignment loading (model.py:155-173, via telescope_amd/loader.py) --------
+    def load_alignment(self, annotation):
+        from . import loader
+        o = self.opts
+        self.run_info['annotated_features'] = len(annotation.loci)
+        r = loader.load_alignment(o.samfile, annotation, o.no_feature_key, o.overlap_mode,
+                                  o.overlap_threshold, o.stranded_mode)
+        self.feature_length = r['feature_length']
+        self.read_index, self.feat_index = r['read_index'], r['feat_index']
+        self.raw_scores = r['raw_scores']
+        self.shape = self.raw_scores.shape
+        for k, v in r['run_info'].items():
+            self.run_info[k] = v
+
     # ---- checkpoint (model.py:108-148) -------------------------------------
     def save(self, filename):
         feats = sorted(self.feat_index, key=self.feat_index.get)

@@ -51,3 +51,54 @@ def test_resume_writes_reference_reports(gpu_device, tmp_path, mode):
         want = open(os.path.join(GOLD, 'resume_%s-%s' % (mode, suffix))).read()
         if got != want:   # rows of equal final_prop may come in any order (unstable sort, model.py:449)
             assert sorted(got.splitlines()) == sorted(want.splitlines()), suffix
+
+
+def test_loader_reproduces_bundled_matrix():
+    """BAM + GTF -> the score matrix the reference's loader builds for its `telescope test` data
+    (validated through the README log-likelihood and the golden report, tools/make_golden.py)."""
+    from telescope_amd import loader
+    ann = loader.Annotation(os.path.join(GOLD, 'bundled_annotation.gtf'))
+    assert len(ann.loci) == 99
+    r = loader.load_alignment(os.path.join(GOLD, 'bundled_alignment.bam'), ann)
+    f = np.load(os.path.join(GOLD, 'bundled_raw_scores.npz'))
+    m = r['raw_scores']
+    assert m.shape == (1000, 59) and m.dtype == np.uint16
+    assert np.array_equal(m.data, f['data']) and np.array_equal(m.indices, f['indices']) \
+        and np.array_equal(m.indptr, f['indptr'])
+    assert list(r['feat_index']) == list(f['feat_names']) and list(r['read_index']) == list(f['read_names'])
+    assert r['score_range'] == (240, 300)
+    assert dict(r['run_info']) == dict(total_fragments=1000, pair_mapped=1000, pair_mixed=0, single_mapped=0,
+                                       unmapped=0, unique=0, ambig=1000, overlap_unique=0, overlap_ambig=1000)
+
+
+def test_assign_skip_em_writes_reference_checkpoint(tmp_path):
+    """`assign --skip_em` needs no GPU: BAM + GTF -> checkpoint with the reference's schema."""
+    cmd = [sys.executable, '-m', 'telescope_amd', 'assign', os.path.join(GOLD, 'bundled_alignment.bam'),
+           os.path.join(GOLD, 'bundled_annotation.gtf'), '--outdir', str(tmp_path), '--exp_tag', 'run', '--skip_em']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = np.load(os.path.join(GOLD, 'resume_checkpoint.npz'))
+    b = np.load(os.path.join(str(tmp_path), 'run-checkpoint.npz'))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        if k == '_run_info':      # the version string differs, everything else is equal
+            da, db = dict(a[k]), dict(b[k])
+            da.pop('version'); db.pop('version')
+            assert da == db
+        else:
+            assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_assign_end_to_end(gpu_device, tmp_path):
+    """`telescope test`-equivalent run (README.md:52-74): expect 95252.596293 and the reports."""
+    cmd = [sys.executable, '-m', 'telescope_amd', 'assign', os.path.join(GOLD, 'bundled_alignment.bam'),
+           os.path.join(GOLD, 'bundled_annotation.gtf'), '--outdir', str(tmp_path), '--exp_tag', 'run']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'Final log-likelihood: 95252.596293.' in r.stderr
+    got = open(os.path.join(str(tmp_path), 'run-TE_counts.tsv')).read()
+    assert got == open(os.path.join(GOLD, 'resume_exclude-TE_counts.tsv')).read()
+    got = open(os.path.join(str(tmp_path), 'run-run_stats.tsv')).read().replace('1.0.3.1-mi355x', '1.0.3.1')
+    want = open(os.path.join(GOLD, 'resume_exclude-run_stats.tsv')).read()
+    assert sorted(got.splitlines()) == sorted(want.splitlines())
