@@ -233,23 +233,27 @@ __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, 
     }
 }
 
-// entries of each ambiguous row per column part, packed 4 x 16 bit (fused layout, P <= 4)
+// entries of each ambiguous row per column part, packed 8 x 16 bit in two words (fused layout, P <= 8)
 __global__ __launch_bounds__(256) void k_row_partcounts(int64_t N_amb, const int32_t* __restrict__ amb_row,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap,
-    unsigned long long* __restrict__ out) {
+    unsigned long long* __restrict__ out /* [N_amb][2] */) {
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
   for (int64_t a = (int64_t)blockIdx.x * subs + sub; a < N_amb; a += (int64_t)gridDim.x * subs) {
     int64_t i = amb_row[a];
     int64_t s = indptr[i], e = indptr[i + 1];
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t k = s + lane; k < e; k += RS_SUB) {
       uint32_t p = colmap[indices[k]] >> 16;
-      c0 += p == 0; c1 += p == 1; c2 += p == 2; c3 += p == 3;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) c[q] += p == (uint32_t)q;
     }
-    c0 = sg_sum_i<RS_SUB>(c0); c1 = sg_sum_i<RS_SUB>(c1); c2 = sg_sum_i<RS_SUB>(c2); c3 = sg_sum_i<RS_SUB>(c3);
-    if (lane == 0)
-      out[a] = (unsigned long long)min(c0, 65535) | ((unsigned long long)min(c1, 65535) << 16) |
-               ((unsigned long long)min(c2, 65535) << 32) | ((unsigned long long)min(c3, 65535) << 48);
+    unsigned long long lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      int v = min(sg_sum_i<RS_SUB>(c[q]), 65535);
+      if (q < 4) lo |= (unsigned long long)v << (16 * q); else hi |= (unsigned long long)v << (16 * (q - 4));
+    }
+    if (lane == 0) { out[2 * a] = lo; out[2 * a + 1] = hi; }
   }
 }
 
@@ -1071,15 +1075,15 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     int Kp = (K + P - 1) / P;
     if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
     h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
-    h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= 4;   // AUTO: fused when the layout allows it
+    h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
     int R = 2048;
     if (h->use_fused && na > 0) {
       // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
       double mean_len = (double)(h->nnz - nu) / (double)na;
       // row SLOTS per block: ~7 % above the average a register tile takes, so blocks end on the
       // tile's capacity, not on R (the exchange cost depends on R, hence not more than needed)
-      double r = 1.07 * FZ_CAP * P / std::max(2.0, mean_len);
-      int rmax = std::min(2 * 64 * FZ_RP * FZ_NXW, (TS_LDS_MAX - 2048 - 2 * Kp * 8) / ((FZ_YR + 2) * 8));
+      double r = 1.07 * fz_cap(P) * P / std::max(2.0, mean_len);
+      int rmax = std::min(fz_rmax(P), (TS_LDS_MAX - 2048 - 2 * Kp * 8) / ((FZ_YR + 2) * 8));
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
       R = std::min(R, rmax / 8 * 8);
@@ -1137,28 +1141,32 @@ static int build_layout(tsem_ctx* h) {
   //    every block still owns R row SLOTS (holes at the end), so all kernels keep b*R+lr indexing.
   const int R = h->R;
   std::vector<int64_t> bstart;
-  if (h->use_fused && na > 0 && P <= 4) {
+  if (h->use_fused && na > 0 && P <= FZ_MAX_P) {
     unsigned long long* d_pc = nullptr;
-    TSEM_ALLOC(d_pc, na);
+    TSEM_ALLOC(d_pc, 2 * na);
     k_row_partcounts<<<(unsigned)std::min<int64_t>(65535, (na + 15) / 16), 256, 0, h->stream>>>(
         na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc);
     TSEM_HIP(hipGetLastError());
-    std::vector<unsigned long long> pc(na);
-    TSEM_HIP(hipMemcpyAsync(pc.data(), d_pc, sizeof(unsigned long long) * na, hipMemcpyDeviceToHost, h->stream));
+    std::vector<unsigned long long> pc(2 * na);
+    TSEM_HIP(hipMemcpyAsync(pc.data(), d_pc, sizeof(unsigned long long) * 2 * na, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
     (void)hipFree(d_pc);
-    const int cap = (int)(FZ_CAP - TS_STRANDS * 4);      // sub-blocks are padded to TS_STRANDS*4 entries
-    int c[4] = {0, 0, 0, 0}, rows = 0;
+    const int cap = fz_cap(P) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
+    int c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rows = 0;
     bstart.push_back(0);
     for (int64_t a = 0; a < na; ++a) {
-      const unsigned long long v = pc[a];
-      const int r0 = (int)(v & 0xFFFF), r1 = (int)((v >> 16) & 0xFFFF), r2 = (int)((v >> 32) & 0xFFFF), r3 = (int)(v >> 48);
-      if (r0 > cap || r1 > cap || r2 > cap || r3 > cap) { h->use_fused = false; break; }   // one row overflows the tile
-      if (rows == R || c[0] + r0 > cap || c[1] + r1 > cap || c[2] + r2 > cap || c[3] + r3 > cap) {
+      int r[8];
+      for (int q = 0; q < 8; ++q) r[q] = (int)((pc[2 * a + (q >> 2)] >> (16 * (q & 3))) & 0xFFFF);
+      bool too_big = false, full = rows == R;
+      for (int q = 0; q < P; ++q) { too_big |= r[q] > cap; full |= c[q] + r[q] > cap; }
+      if (too_big) { h->use_fused = false; break; }       // one row overflows the register tile
+      if (full) {
         bstart.push_back(a);
-        c[0] = c[1] = c[2] = c[3] = 0; rows = 0;
+        for (int q = 0; q < 8; ++q) c[q] = 0;
+        rows = 0;
       }
-      c[0] += r0; c[1] += r1; c[2] += r2; c[3] += r3; ++rows;
+      for (int q = 0; q < P; ++q) c[q] += r[q];
+      ++rows;
     }
     bstart.push_back(na);
   }
@@ -1199,7 +1207,7 @@ static int build_layout(tsem_ctx* h) {
     int64_t mx = 0;
     for (int64_t i = 0; i < nb * P; ++i) mx = std::max(mx, sb[i]);
     h->max_subblock = mx;
-    if (mx > FZ_CAP) h->use_fused = false;   // caller (set_model) retries with smaller blocks
+    if (mx > fz_cap(P)) h->use_fused = false;
   }
   int64_t off = 0;
   for (int64_t i = 0; i < nb * P; ++i) {   // sub-blocks padded to TS_STRANDS*4 entries (strand-transposed order)
@@ -1239,7 +1247,7 @@ static int build_layout(tsem_ctx* h) {
   TSEM_ALLOC(h->d_partial, (int64_t)h->G2 * h->Kpad);
   if (h->use_fused) {
     const size_t ldsf = (size_t)(2 * Kp + (FZ_YR + 2) * R) * 8 + 192;
-    if (ldsf > (size_t)TS_LDS_MAX - 1024 || R > 2 * 64 * FZ_RP * FZ_NXW || (R & 1)) {
+    if (ldsf > (size_t)TS_LDS_MAX - 1024 || R > fz_rmax(P) || (R & 1)) {
       h->use_fused = false;
     } else {
       h->fz_grid = h->n_cu;
@@ -1251,7 +1259,7 @@ static int build_layout(tsem_ctx* h) {
       TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
       k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
 #define FZ_ATTR(n) TSEM_HIP(hipFuncSetAttribute((const void*)k_em_fused<n>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
-      FZ_ATTR(1) FZ_ATTR(2) FZ_ATTR(3) FZ_ATTR(4)
+      FZ_ATTR(1) FZ_ATTR(2) FZ_ATTR(3) FZ_ATTR(4) FZ_ATTR(5) FZ_ATTR(6) FZ_ATTR(7) FZ_ATTR(8)
 #undef FZ_ATTR
     }
   }
@@ -1413,9 +1421,9 @@ int tsem_em_pass(tsem_ctx* h) {
     if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
     switch (h->P) {
 #define FZ_CASE(n) case n: k_em_fused<n><<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A); break;
-      FZ_CASE(1) FZ_CASE(2) FZ_CASE(3) FZ_CASE(4)
+      FZ_CASE(1) FZ_CASE(2) FZ_CASE(3) FZ_CASE(4) FZ_CASE(5) FZ_CASE(6) FZ_CASE(7) FZ_CASE(8)
 #undef FZ_CASE
-      default: TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 4 column parts");
+      default: TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
     }
     TSEM_HIP(hipGetLastError());
     h->fused_launched = true;

@@ -31,10 +31,16 @@
 #pragma once
 
 constexpr int FZ_NT = 1024;            // threads per workgroup
-constexpr int FZ_NXW = 2;              // exchange waves (the last FZ_NXW waves), each serving R / FZ_NXW rows
-constexpr int FZ_DT = FZ_NT - 64 * FZ_NXW;   // data threads
-constexpr int FZ_CAP = FZ_DT * 4;      // register-resident entries per sub-block (one 16-B index load per thread)
-constexpr int FZ_RP = 2;               // row pairs per exchange-wave lane  ->  R <= 2*64*FZ_RP*FZ_NXW = 512
+// Geometry by team size: the exchange waves keep two generations of (P-1) partner values per
+// row pair in registers, so larger teams use more exchange waves with fewer row pairs per lane.
+//   P <= 4 : 2 exchange waves x 2 row pairs per lane (R <= 512), 14 data waves
+//   P <= 8 : 3 exchange waves x 1 row pair  per lane (R <= 384), 13 data waves
+__host__ __device__ constexpr int fz_nxw(int P) { return P <= 4 ? 2 : 3; }          // exchange waves
+__host__ __device__ constexpr int fz_rp(int P) { return P <= 4 ? 2 : 1; }           // row pairs per lane
+__host__ __device__ constexpr int fz_dt(int P) { return FZ_NT - 64 * fz_nxw(P); }   // data threads
+__host__ __device__ constexpr int fz_cap(int P) { return fz_dt(P) * 4; }            // entries per register tile
+__host__ __device__ constexpr int fz_rmax(int P) { return 2 * 64 * fz_rp(P) * fz_nxw(P); }
+constexpr int FZ_MAX_P = 8;
 #ifndef FZ_GAP_STEPS
 #define FZ_GAP_STEPS 1
 #endif
@@ -89,6 +95,7 @@ template <int P, int PP>
 __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   constexpr int p = PP;
+  constexpr int FZ_RP = fz_rp(P);
   constexpr int NPART = P > 1 ? P - 1 : 1;
   double* const y = X.y; double* const s = X.s; uint32_t* const offs = X.offs; uint32_t* const err = X.err;
   unsigned long long* const xbase = X.xbase;
@@ -221,7 +228,7 @@ template <int PT>
 __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int P = PT;
-  constexpr int NPART = P > 1 ? P - 1 : 1;
+  constexpr int FZ_DT = fz_dt(P);
   const int Kp = A.Kp, R = A.R;
   double* c = reinterpret_cast<double*>(smem);
   double* acc = c + Kp;
@@ -309,6 +316,10 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       case 1: if (P > 1) fz_xchg<P, (P > 1 ? 1 : 0)>(A, X); break;
       case 2: if (P > 2) fz_xchg<P, (P > 2 ? 2 : 0)>(A, X); break;
       case 3: if (P > 3) fz_xchg<P, (P > 3 ? 3 : 0)>(A, X); break;
+      case 4: if (P > 4) fz_xchg<P, (P > 4 ? 4 : 0)>(A, X); break;
+      case 5: if (P > 5) fz_xchg<P, (P > 5 ? 5 : 0)>(A, X); break;
+      case 6: if (P > 6) fz_xchg<P, (P > 6 ? 6 : 0)>(A, X); break;
+      case 7: if (P > 7) fz_xchg<P, (P > 7 ? 7 : 0)>(A, X); break;
       default: break;
     }
   } else {

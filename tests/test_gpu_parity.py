@@ -301,14 +301,14 @@ def _oracle_vs_gpu(raw, iters=4, options=(), rtol=RTOL):
     return eng.layout_info()
 
 
-@pytest.mark.parametrize('cols,expect_parts', [(9000, 2), (20000, 3), (30000, 4), (40000, 6)])
+@pytest.mark.parametrize('cols,expect_parts', [(9000, 2), (20000, 3), (30000, 4), (36000, 5), (40000, 6), (50000, 7), (60000, 8)])
 def test_column_part_counts(gpu_device, cols, expect_parts):
-    """P = 2, 3, 4 run the fused kernel; P = 6 (K > 30720) falls back to the two-pass kernels."""
+    """Teams of P = 2, 3, 4 (two exchange waves) and P = 6 (three exchange waves) run the fused kernel."""
     from telescope_amd import synthetic
     ip, ix, rw = synthetic.generate(60000, cols, 24, seed=11, dist='zipf', uniq_frac=0.05)
     info = _oracle_vs_gpu(sp.csr_matrix((rw, ix, ip), shape=(60000, cols)))
     assert info['P'] == expect_parts
-    assert info['fused'] == (1 if expect_parts <= 4 else 0)
+    assert info['fused'] == 1
 
 
 def test_ragged_rows_and_kernel_variants(gpu_device):
