@@ -1258,7 +1258,8 @@ static int build_layout(tsem_ctx* h) {
       TSEM_HIP(hipMemset(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS));
       TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
       k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
-#define FZ_ATTR(n) TSEM_HIP(hipFuncSetAttribute((const void*)k_em_fused<n>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+#define FZ_ATTR(n) TSEM_HIP(hipFuncSetAttribute((const void*)k_em_fused<n, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024)); \
+                   TSEM_HIP(hipFuncSetAttribute((const void*)k_em_fused<n, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
       FZ_ATTR(1) FZ_ATTR(2) FZ_ATTR(3) FZ_ATTR(4) FZ_ATTR(5) FZ_ATTR(6) FZ_ATTR(7) FZ_ATTR(8)
 #undef FZ_ATTR
     }
@@ -1400,6 +1401,36 @@ static int begin_timing(tsem_ctx* h, hipEvent_t** pair) {
   return TSEM_OK;
 }
 
+// One launch of the persistent fused kernel.  mode 0: EM pass (column sums of w*z into d_fpartial);
+// mode 1: log-likelihood of the ambiguous rows (one partial per workgroup into d_lnl_part).
+static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
+  const size_t sync_bytes = sizeof(uint32_t) * FZ_SYNC_WORDS;
+  TSEM_HIP(hipMemsetAsync(h->d_xflags, 0, sync_bytes, h->stream));
+  if (mode == 0) TSEM_HIP(hipMemsetAsync(h->d_fpartial, 0, sizeof(double) * (size_t)h->fz_teams * h->Kpad, h->stream));
+  else TSEM_HIP(hipMemsetAsync(h->d_lnl_part, 0, sizeof(double) * (size_t)h->fz_grid, h->stream));   // teams that do not form write nothing
+  if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * FZ_XS * h->P * h->R, h->stream));
+  FusedArgs A;
+  A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
+  A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc;
+  A.ctab = mode ? h->d_ctab_prev : h->d_ctab; A.ctab2 = h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = mode;
+  A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg;
+  A.sync = h->d_xflags; A.xcd_local = h->opt_xcd_local ? 1 : 0;
+  A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.poll_delay = (int)h->opt_poll_delay; A.dbg = (int)h->opt_dbg;
+  const size_t ldsf = (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192;
+  if (mode && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
+  if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
+  switch (h->P * 2 + mode) {
+#define FZ_CASE(n) case 2 * n: k_em_fused<n, 0><<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A); break; \
+                   case 2 * n + 1: k_em_fused<n, 1><<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A); break;
+    FZ_CASE(1) FZ_CASE(2) FZ_CASE(3) FZ_CASE(4) FZ_CASE(5) FZ_CASE(6) FZ_CASE(7) FZ_CASE(8)
+#undef FZ_CASE
+    default: TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
+  }
+  TSEM_HIP(hipGetLastError());
+  h->fused_launched = true;
+  return TSEM_OK;
+}
+
 int tsem_em_pass(tsem_ctx* h) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
@@ -1407,26 +1438,7 @@ int tsem_em_pass(tsem_ctx* h) {
   if (int rc = begin_timing(h, &pair)) return rc;
   bool fused_done = false;
   if (h->nb > 0 && h->use_fused) {
-    const size_t sync_bytes = sizeof(uint32_t) * FZ_SYNC_WORDS;
-    TSEM_HIP(hipMemsetAsync(h->d_xflags, 0, sync_bytes, h->stream));
-    TSEM_HIP(hipMemsetAsync(h->d_fpartial, 0, sizeof(double) * (size_t)h->fz_teams * h->Kpad, h->stream));
-    if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * FZ_XS * h->P * h->R, h->stream));
-    FusedArgs A;
-    A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
-    A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc; A.ctab = h->d_ctab;
-    A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg;
-    A.sync = h->d_xflags; A.xcd_local = h->opt_xcd_local ? 1 : 0;
-    A.prof = h->d_prof; A.prof_blocks = h->d_prof ? 64 : 0; A.poll_delay = (int)h->opt_poll_delay; A.dbg = (int)h->opt_dbg;
-    const size_t ldsf = (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192;
-    if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
-    switch (h->P) {
-#define FZ_CASE(n) case n: k_em_fused<n><<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A); break;
-      FZ_CASE(1) FZ_CASE(2) FZ_CASE(3) FZ_CASE(4) FZ_CASE(5) FZ_CASE(6) FZ_CASE(7) FZ_CASE(8)
-#undef FZ_CASE
-      default: TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
-    }
-    TSEM_HIP(hipGetLastError());
-    h->fused_launched = true;
+    if (int rc = launch_fused(h, 0, pair)) return rc;
     fused_done = true;
   } else if (h->nb > 0) {
     const size_t lds2 = (size_t)(2 * h->Kp + h->R) * 8;
@@ -1493,7 +1505,10 @@ int tsem_lnl_pass(tsem_ctx* h) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
   int na = 0, nu = 0;
-  if (h->nb > 0) {
+  if (h->nb > 0 && h->use_fused) {
+    if (int rc = launch_fused(h, 1, nullptr)) return rc;
+    na = h->fz_grid;
+  } else if (h->nb > 0) {
     if (int rc = launch_phase1(h, h->d_ctab_prev)) return rc;
     const size_t lds2 = (size_t)(2 * h->Kp + h->R) * 8;
     na = h->G2 * h->P;

@@ -64,6 +64,9 @@ struct FusedArgs {
   const double* pval;
   const uint32_t* prc;
   const double* ctab;
+  const double* ctab2;  // lnl mode: pi*theta of the CURRENT params (ctab then holds the previous ones)
+  double* lnl_out;      // lnl mode: one partial sum per workgroup [grid]
+  int lnl_mode;         // 0: EM pass (scatter w*z); 1: sum z(prev) * log1p(Q * c_cur)  (model.py:744-760)
   const double* wrow;   // [N_amb_pad] fragment weight w_i = max_j Q_ij (0 in the padding)
   double* partial;      // [team slots][P*Kp], zero-filled before launch
   double* xchg;         // [team][FZ_XS][P][R] tagged granules, zero-filled before launch
@@ -124,7 +127,8 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       for (int j = 0; j < FZ_RP; ++j) {
         const int r = rlo + 2 * (lane + 64 * j);
         if (r < rhi) {
-          g.w[j] = *reinterpret_cast<const double2*>(&A.wrow[(team + k * T) * R + r]);
+          g.w[j] = A.lnl_mode ? make_double2(1.0, 1.0)
+                              : *reinterpret_cast<const double2*>(&A.wrow[(team + k * T) * R + r]);
           if (P > 1 && !(A.dbg & 1)) {
 #pragma unroll
             for (int q = 0; q < P; ++q) {
@@ -224,7 +228,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     }
 }
 
-template <int PT>
+template <int PT, int MODE>
 __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int P = PT;
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     }
     for (int x = 0; x < 8; ++x) ibox[1 + x] = (int)fz_ld_u32(&sync[x]);
   }
-  for (int t = tid; t < Kp; t += FZ_NT) acc[t] = 0.0;
+  for (int t = tid; t < Kp; t += FZ_NT) acc[t] = 0.0;   // (lnl mode: overwritten with ctab2 below)
   for (int t = tid; t < FZ_YR * R; t += FZ_NT) y[t] = 0.0;
   for (int t = tid; t < 2 * R; t += FZ_NT) s[t] = 0.0;
   __syncthreads();
@@ -271,6 +275,8 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   if (!valid || T == 0) return;                          // leftover workgroup of an incomplete team
   const int team = tbase + u;                            // 0..T-1
   for (int t = tid; t < Kp; t += FZ_NT) c[t] = A.ctab[p * Kp + t];
+  if (A.lnl_mode)
+    for (int t = tid; t < Kp; t += FZ_NT) acc[t] = A.ctab2[p * Kp + t];
   unsigned long long* const xbase = reinterpret_cast<unsigned long long*>(A.xchg) + (int64_t)team * FZ_XS * P * R;
   __syncthreads();
 
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   }
   __syncthreads();
 
+  double lsum = 0.0;                                      // lnl mode: this thread's share of the sum
   if (tid >= FZ_DT) {
     // ============================ exchange wave ===============================
     // dispatched on the member index so every register array is statically indexed
@@ -338,9 +345,17 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       }
     };
     // phase 1: numerators n = Q * (pi*theta) kept in the registers, partial row sums into y(k)
+    constexpr bool lnl = MODE == 1;
     auto phase1 = [&](FzRegs& rr, int64_t k) {
       if (k < 0 || k >= nblk || rr.rc.x == 0xFFFFFFFFu) return;
       double* yb = y + (k & (FZ_YR - 1)) * R;
+      if (lnl) {                                          // the registers keep Q: phase 2 needs it twice
+        lds_add(&yb[rr.rc.x >> 16], rr.v0.x * c[rr.rc.x & 0xFFFF]);
+        lds_add(&yb[rr.rc.y >> 16], rr.v0.y * c[rr.rc.y & 0xFFFF]);
+        lds_add(&yb[rr.rc.z >> 16], rr.v1.x * c[rr.rc.z & 0xFFFF]);
+        lds_add(&yb[rr.rc.w >> 16], rr.v1.y * c[rr.rc.w & 0xFFFF]);
+        return;
+      }
       rr.v0.x *= c[rr.rc.x & 0xFFFF]; lds_add(&yb[rr.rc.x >> 16], rr.v0.x);
       rr.v0.y *= c[rr.rc.y & 0xFFFF]; lds_add(&yb[rr.rc.y >> 16], rr.v0.y);
       rr.v1.x *= c[rr.rc.z & 0xFFFF]; lds_add(&yb[rr.rc.z >> 16], rr.v1.x);
@@ -350,6 +365,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     auto phase2 = [&](FzRegs& rr, int64_t k) {
       if (k < 0 || k >= nblk || rr.rc.x == 0xFFFFFFFFu) return;
       const double* sb = s + (k & 1) * R;
+      if (lnl) {                                          // z = (Q c_prev) * recip0(rowsum);  acc[] holds c_cur
+        auto term = [&](double q, uint32_t rc) {
+          const double z = (q * c[rc & 0xFFFF]) * sb[rc >> 16];
+          if (z != 0.0) lsum += z * log1p(q * acc[rc & 0xFFFF]);
+        };
+        term(rr.v0.x, rr.rc.x); term(rr.v0.y, rr.rc.y); term(rr.v1.x, rr.rc.z); term(rr.v1.y, rr.rc.w);
+        return;
+      }
       lds_add(&acc[rr.rc.x & 0xFFFF], rr.v0.x * sb[rr.rc.x >> 16]);
       lds_add(&acc[rr.rc.y & 0xFFFF], rr.v0.y * sb[rr.rc.y >> 16]);
       lds_add(&acc[rr.rc.z & 0xFFFF], rr.v1.x * sb[rr.rc.z >> 16]);
@@ -402,6 +425,18 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
 #endif
   }
   __syncthreads();
+  if (MODE == 1) {                                        // one partial per workgroup, summed by k_sum_parts
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
+    double* wsum = y;                                     // the y ring is idle now
+    if ((tid & 63) == 0) wsum[tid >> 6] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < FZ_NT / 64; ++w) t += wsum[w];
+      A.lnl_out[team * P + p] = t;
+    }
+    return;
+  }
   double* out = A.partial + (int64_t)team * (P * Kp) + p * Kp;
   for (int t = tid; t < Kp; t += FZ_NT) out[t] = acc[t];
 }
