@@ -50,12 +50,16 @@ def parse():
     ap.add_argument('--seed', type=int, default=42)
     ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')
     ap.add_argument('--em-kernel', choices=('auto', 'twopass', 'fused'), default='auto')
+    ap.add_argument('--value-format', choices=('auto', 'f64', 'code16'), default='auto',
+                    help='entry format of the blocked layout: fp64 Q values (12 B/nnz) or uint16 score codes + '
+                         'LDS score table (6 B/nnz, the same fp64 arithmetic bit for bit)')
     ap.add_argument('--block-rows', type=int, default=0)
     ap.add_argument('--chunk-blocks', type=int, default=0)
     ap.add_argument('--xcd-local', type=int, default=1)
     ap.add_argument('--poll-delay', type=int, default=-1)
     ap.add_argument('--fused-dbg', type=int, default=0)
     ap.add_argument('--fill-pct', type=int, default=0)
+    ap.add_argument('--hot-split', type=int, default=1, help='0: one accumulator slot per column (experiments)')
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
     ap.add_argument('--cpu-iters', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -120,6 +124,7 @@ def main():
     eng = Engine(local)
     eng.set_option('row_offset', r0)
     eng.set_option('em_kernel', {'auto': EMK_AUTO, 'twopass': EMK_TWOPASS, 'fused': EMK_FUSED}[args.em_kernel])
+    eng.set_option('value_format', {'auto': 0, 'f64': 1, 'code16': 2}[args.value_format])
     if args.block_rows:
         eng.set_option('block_rows', args.block_rows)
     if args.chunk_blocks:
@@ -129,6 +134,7 @@ def main():
         eng.set_option('fused_dbg', args.fused_dbg)
     if args.fill_pct:
         eng.set_option('fill_pct', args.fill_pct)
+    eng.set_option('hot_split', args.hot_split)
     if args.poll_delay >= 0:
         eng.set_option('poll_delay', args.poll_delay)
     t_setup = time.perf_counter()
@@ -177,8 +183,8 @@ def main():
         tj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
         w = tj['workload']
         kern = 'fused' if info.get('fused') else 'twopass'
-        if (w['rows'], w['cols'], w['nnz_row'], w['dist'], w['em_kernel'], w['n_gpus']) == \
-                (total_rows, args.cols, args.nnz_row, args.dist, kern, world):
+        if (w['rows'], w['cols'], w['nnz_row'], w['dist'], w['em_kernel'], w['n_gpus'], w.get('value_bytes', 8)) == \
+                (total_rows, args.cols, args.nnz_row, args.dist, kern, world, info.get('value_bytes', 8)):
             traffic = tj['traffic_bytes_per_launch'] / 1e9
     except (OSError, KeyError, ValueError):
         pass
@@ -192,12 +198,13 @@ def main():
         'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'nnz_per_sec': nnz_total * args.steps / elapsed,
         'config': {
-            'workload': 'synthetic %dM fragments x %dk loci, ~%g nnz/row, %s columns, fp64 values, '
+            'workload': 'synthetic %dM fragments x %dk loci, ~%g nnz/row, %s columns, fp64 arithmetic, '
                         'pi_prior=0 theta_prior=200000, em_epsilon=0 (fixed iterations)'
                         % (total_rows // 1_000_000, args.cols // 1000, args.nnz_row, args.dist),
             'rows': total_rows, 'cols': args.cols, 'nnz': nnz_total, 'dist': args.dist, 'seed': args.seed,
             'parallelism': 'row-sharded x%d, 1 all-reduce(K f64)/iter' % world if world > 1 else 'single GPU',
-            'em_kernel': args.em_kernel, 'layout': info, 'setup_s': round(t_setup, 3),
+            'em_kernel': args.em_kernel, 'layout': info,
+            'value_format': 'code16+lut (6 B/nnz stored)' if info.get('value_bytes') == 2 else 'f64 (12 B/nnz stored)', 'setup_s': round(t_setup, 3),
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

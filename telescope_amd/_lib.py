@@ -328,7 +328,7 @@ class Engine(object):
         info = np.zeros(16, np.int64)
         self._ck(self._L.tsem_layout_info(self._h, ptr(info)))
         return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad', 'twin_cols',
-                         'G1', 'G2', 'fused', 'slow_path', 'max_subblock'), info.tolist()))
+                         'G1', 'G2', 'fused', 'slow_path', 'max_subblock', 'value_bytes', 'hot_cols'), info.tolist()))
 
 
 def csr_norm_rows(indptr, data, device=0):

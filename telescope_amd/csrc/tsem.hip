@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_sb_count(int64_t N_amb, int R, int P, c
 __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
     const double* __restrict__ lut, const uint32_t* __restrict__ colmap, const int64_t* __restrict__ sb_off,
-    double* __restrict__ pval, uint32_t* __restrict__ prc) {
+    double* __restrict__ pval, uint16_t* __restrict__ pcode, uint32_t* __restrict__ prc) {
   __shared__ uint32_t cur[64];
   if (threadIdx.x < 64) cur[threadIdx.x] = 0;
   __syncthreads();
@@ -313,8 +313,9 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
       const uint32_t L = (uint32_t)((sb_off[b * P + p + 1] - base) / TS_STRANDS);
       const uint32_t t = atomicAdd(&cur[p], 1u);
       int64_t pos = base + (int64_t)(t % TS_STRANDS) * L + t / TS_STRANDS;
-      pval[pos] = lut[raw[k]];
-      prc[pos] = ((uint32_t)lr << 16) | (cm & 0xFFFFu);
+      if (pcode) pcode[pos] = raw[k];
+      else pval[pos] = lut[raw[k]];
+      prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
     }
   }
 }
@@ -459,15 +460,17 @@ __global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ a,
 }
 
 // red[col] = sum_g partial[g][pc]   (fixed order -> deterministic given partials)
-__global__ void k_colreduce(int Kpad, int G, const double* __restrict__ partial,
-                            const int32_t* __restrict__ col_of_pc, double* __restrict__ red, int K) {
+__global__ void k_colreduce(int Kpad, int G, const double* __restrict__ partial, const int32_t* __restrict__ col_of_pc,
+                            const uint32_t* __restrict__ colmap, double* __restrict__ red, int K) {
   int pc = blockIdx.x * blockDim.x + threadIdx.x;
   if (pc == 0) { red[K] = 0.0; red[K + 1] = 0.0; }
   if (pc >= Kpad) return;
   int col = col_of_pc[pc];
-  if (col < 0) return;
+  if (col < 0) return;                                   // padding, or a secondary slot of a split column
+  const int copies = 1 << ((colmap[col] >> 13) & 7u);
   double s = 0.0;
-  for (int g = 0; g < G; ++g) s += partial[(int64_t)g * Kpad + pc];
+  for (int g = 0; g < G; ++g)
+    for (int c = 0; c < copies; ++c) s += partial[(int64_t)g * Kpad + pc + c];
   red[col] = s;
 }
 
@@ -496,10 +499,10 @@ __global__ __launch_bounds__(256) void k_update(int K, const double* __restrict_
     d += fabs(ph - po);
     pi_prev[j] = po; theta_prev[j] = to;
     pi[j] = ph; theta[j] = th;
-    uint32_t cm = colmap[j];
-    int pc = (int)(cm >> 16) * Kp + (int)(cm & 0xFFFF);
-    ctab_prev[pc] = ctab[pc];
-    ctab[pc] = ph * th;
+    const uint32_t cm = colmap[j];
+    const int pc = (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu), copies = 1 << ((cm >> 13) & 7u);
+    const double cold = ctab[pc], cnew = ph * th;
+    for (int c = 0; c < copies; ++c) { ctab_prev[pc + c] = cold; ctab[pc + c] = cnew; }
   }
   double t = block_sum(d, scratch);
   if (threadIdx.x == 0) diff_out[blockIdx.x] = t;
@@ -509,8 +512,9 @@ __global__ void k_make_ctab(int K, const double* __restrict__ pi, const double* 
                             const uint32_t* __restrict__ colmap, int Kp, double* __restrict__ ctab) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= K) return;
-  uint32_t cm = colmap[j];
-  ctab[(int)(cm >> 16) * Kp + (int)(cm & 0xFFFF)] = pi[j] * theta[j];
+  const uint32_t cm = colmap[j];
+  const int pc = (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu), copies = 1 << ((cm >> 13) & 7u);
+  for (int c = 0; c < copies; ++c) ctab[pc + c] = pi[j] * theta[j];
 }
 
 __global__ void k_row_weights(int64_t n, const uint16_t* __restrict__ code, const double* __restrict__ lut,
@@ -777,8 +781,32 @@ static int ensure_device(tsem_ctx* h) {
   return TSEM_OK;
 }
 
+typedef void (*fz_fn)(FusedArgs);
+template <int P> static fz_fn fz_pick(int mode, int fmt) {
+  if (fmt) return mode ? k_em_fused<P, 1, 1> : k_em_fused<P, 0, 1>;
+  return mode ? k_em_fused<P, 1, 0> : k_em_fused<P, 0, 0>;
+}
+static fz_fn fz_kernel(int P, int mode, int fmt) {
+  switch (P) {
+    case 1: return fz_pick<1>(mode, fmt); case 2: return fz_pick<2>(mode, fmt);
+    case 3: return fz_pick<3>(mode, fmt); case 4: return fz_pick<4>(mode, fmt);
+    case 5: return fz_pick<5>(mode, fmt); case 6: return fz_pick<6>(mode, fmt);
+    case 7: return fz_pick<7>(mode, fmt); case 8: return fz_pick<8>(mode, fmt);
+    default: return nullptr;
+  }
+}
+
+// code16 entry format: only with the fused kernel, and only while the score table is small enough to
+// sit in LDS beside the column tables (uint16 scores allow 65536 entries; alignments give a few hundred)
+static bool fz_wants_codes(const tsem_ctx* h) {
+  return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048;
+}
+static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
+  return (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192 + (codes ? (size_t)h->lut_len * 8 : 0);
+}
+
 static void free_layout(tsem_ctx* h) {
-  dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_prc);
+  dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_pcode); dfree(h->d_prc);
   dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fpartial); dfree(h->d_amb_w); dfree(h->d_sb_q32);
   h->fused_launched = false;
 }
@@ -855,6 +883,8 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "poll_delay") h->opt_poll_delay = v;
   else if (k == "fill_pct") h->fill_target = v / 100.0;
   else if (k == "fused_dbg") h->opt_dbg = v;
+  else if (k == "value_format") h->opt_format = v;
+  else if (k == "hot_split") h->opt_hot_split = v;
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
     if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
@@ -1074,6 +1104,9 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
     int Kp = (K + P - 1) / P;
     if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
+    // spare accumulator slots per part for very popular columns (build_layout splits them)
+    h->hot_extra = h->opt_hot_split ? std::min(64, TS_MAX_KP - Kp) : 0;
+    Kp += h->hot_extra;
     h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
     h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
     int R = 2048;
@@ -1083,7 +1116,8 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
       // row SLOTS per block: ~7 % above the average a register tile takes, so blocks end on the
       // tile's capacity, not on R (the exchange cost depends on R, hence not more than needed)
       double r = 1.07 * fz_cap(P) * P / std::max(2.0, mean_len);
-      int rmax = std::min(fz_rmax(P), (TS_LDS_MAX - 2048 - 2 * Kp * 8) / ((FZ_YR + 2) * 8));
+      const int lut_bytes = fz_wants_codes(h) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
+      int rmax = std::min(fz_rmax(P), (TS_LDS_MAX - 2048 - 2 * Kp * 8 - lut_bytes) / ((FZ_YR + 2) * 8));
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
       R = std::min(R, rmax / 8 * 8);
@@ -1124,13 +1158,38 @@ static int build_layout(tsem_ctx* h) {
   std::vector<int> order(K);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return counts[a] > counts[b]; });
+  // colmap[j] = part << 16 | log2(copies) << 13 | first slot.  A column that holds a large share of its
+  // part's entries would serialise the LDS scatter (64 f lanes of every ds_add_f64 on ONE address:
+  // the hottest column of a Zipf-like matrix, or Telescope's `__no_feature`, reaches 8-way), so it
+  // gets 2..16 consecutive slots; k_sb_fill deals its entries over them, k_colreduce adds them up.
   std::vector<uint32_t> colmap(K);
   std::vector<int32_t> col_of_pc(h->Kpad, -1);
+  // Columns go, most popular first, to the part that holds the fewest entries so far (and still has
+  // a free slot): every member of a team then streams the same number of entries per row block, so
+  // the register tiles of all parts fill evenly and no member waits for a heavier one.
+  std::vector<double> part_nnz(P, 0.0);
+  std::vector<int> part_of(K), ncols(P, 0);
+  const int percap = h->Kp - h->hot_extra;                 // plain columns per part
   for (int rank = 0; rank < K; ++rank) {
-    int j = order[rank];
-    int p = rank % P, l = rank / P;
-    colmap[j] = ((uint32_t)p << 16) | (uint32_t)l;
-    col_of_pc[p * Kp + l] = j;
+    int best = -1;
+    for (int p = 0; p < P; ++p)
+      if (ncols[p] < percap && (best < 0 || part_nnz[p] < part_nnz[best])) best = p;
+    part_of[rank] = best;
+    ncols[best] += 1;
+    part_nnz[best] += (double)counts[order[rank]];
+  }
+  std::vector<int> cursor(P, 0), spare(P, h->hot_extra);
+  h->n_hot_cols = 0;
+  for (int rank = 0; rank < K; ++rank) {
+    const int j = order[rank], p = part_of[rank];
+    const double lanes = 64.0 * (double)counts[j] / std::max(1.0, part_nnz[p]);
+    int lg = 0;
+    while (lg < 4 && lanes / (1 << lg) > 1.5 && (2 << lg) - 1 <= spare[p]) ++lg;
+    spare[p] -= (1 << lg) - 1;
+    if (lg) h->n_hot_cols += 1;
+    colmap[j] = ((uint32_t)p << 16) | ((uint32_t)lg << 13) | (uint32_t)cursor[p];
+    col_of_pc[p * Kp + cursor[p]] = j;                     // the first slot owns the column; the others stay -1
+    cursor[p] += 1 << lg;
   }
   TSEM_ALLOC(h->d_colmap, K);
   TSEM_ALLOC(h->d_col_of_pc, h->Kpad);
@@ -1227,13 +1286,22 @@ static int build_layout(tsem_ctx* h) {
   } else if (h->use_fused) {
     h->use_fused = false;
   }
-  TSEM_ALLOC(h->d_pval, off);
+  if (h->use_fused && (R > fz_rmax(P) || (R & 1) || fz_lds_bytes(h, false) > (size_t)TS_LDS_MAX - 1024)) h->use_fused = false;
+  h->fmt_code = h->use_fused && fz_wants_codes(h) && fz_lds_bytes(h, true) <= (size_t)TS_LDS_MAX - 1024;
+  if (h->opt_format == 2 && !h->fmt_code)
+    TSEM_FAIL(TSEM_ERR_ARG, "value_format=codes needs the fused kernel and a score table of at most 2048 entries");
   TSEM_ALLOC(h->d_prc, off);
-  TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
   TSEM_HIP(hipMemsetAsync(h->d_prc, 0, sizeof(uint32_t) * std::max<int64_t>(1, off), h->stream));
+  if (h->fmt_code) {
+    TSEM_ALLOC(h->d_pcode, off);
+    TSEM_HIP(hipMemsetAsync(h->d_pcode, 0, sizeof(uint16_t) * std::max<int64_t>(1, off), h->stream));   // code 0 -> Q = 0
+  } else {
+    TSEM_ALLOC(h->d_pval, off);
+    TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
+  }
   if (nb) {
     k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
-                                                  h->d_colmap, h->d_sb_off, h->d_pval, h->d_prc);
+                                                  h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc);
     TSEM_HIP(hipGetLastError());
   }
   TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad);
@@ -1246,22 +1314,20 @@ static int build_layout(tsem_ctx* h) {
   h->G2 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w2 / P));
   TSEM_ALLOC(h->d_partial, (int64_t)h->G2 * h->Kpad);
   if (h->use_fused) {
-    const size_t ldsf = (size_t)(2 * Kp + (FZ_YR + 2) * R) * 8 + 192;
-    if (ldsf > (size_t)TS_LDS_MAX - 1024 || R > fz_rmax(P) || (R & 1)) {
-      h->use_fused = false;
-    } else {
+    {
       h->fz_grid = h->n_cu;
       h->fz_teams = std::max(1, h->fz_grid / P);
       TSEM_ALLOC(h->d_fpartial, (int64_t)h->fz_teams * h->Kpad);
       TSEM_ALLOC(h->d_xchg, (int64_t)h->fz_teams * FZ_XS * P * R);
       TSEM_ALLOC(h->d_xflags, FZ_SYNC_WORDS);
       TSEM_HIP(hipMemset(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS));
-      TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
-      k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
-#define FZ_ATTR(n) TSEM_HIP(hipFuncSetAttribute((const void*)k_em_fused<n, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024)); \
-                   TSEM_HIP(hipFuncSetAttribute((const void*)k_em_fused<n, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
-      FZ_ATTR(1) FZ_ATTR(2) FZ_ATTR(3) FZ_ATTR(4) FZ_ATTR(5) FZ_ATTR(6) FZ_ATTR(7) FZ_ATTR(8)
-#undef FZ_ATTR
+      if (!h->fmt_code) {                                  // fp64 row weights; the code format reads d_amb_wcode
+        TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
+        k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
+      }
+      for (int mode = 0; mode < 2; ++mode)
+        TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, h->fmt_code ? 1 : 0),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
     }
   }
   TSEM_HIP(hipFuncSetAttribute((const void*)k_phase1<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
@@ -1416,16 +1482,13 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
   A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg;
   A.sync = h->d_xflags; A.xcd_local = h->opt_xcd_local ? 1 : 0;
   A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.poll_delay = (int)h->opt_poll_delay; A.dbg = (int)h->opt_dbg;
-  const size_t ldsf = (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192;
+  A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = h->fmt_code ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
+  const size_t ldsf = fz_lds_bytes(h, h->fmt_code);
   if (mode && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
+  fz_fn fn = fz_kernel(h->P, mode, h->fmt_code ? 1 : 0);
+  if (!fn) TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
   if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
-  switch (h->P * 2 + mode) {
-#define FZ_CASE(n) case 2 * n: k_em_fused<n, 0><<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A); break; \
-                   case 2 * n + 1: k_em_fused<n, 1><<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A); break;
-    FZ_CASE(1) FZ_CASE(2) FZ_CASE(3) FZ_CASE(4) FZ_CASE(5) FZ_CASE(6) FZ_CASE(7) FZ_CASE(8)
-#undef FZ_CASE
-    default: TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
-  }
+  fn<<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
   h->fused_launched = true;
   return TSEM_OK;
@@ -1454,9 +1517,9 @@ int tsem_em_pass(tsem_ctx* h) {
   if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
   h->em_launches += 1;
   if (fused_done) {
-    k_colreduce<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_red, h->K);
+    k_colreduce<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K);
   } else if (h->nb > 0) {
-    k_colreduce<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_red, h->K);
+    k_colreduce<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K);
   } else {
     TSEM_HIP(hipMemsetAsync(h->d_red, 0, sizeof(double) * (h->K + 2), h->stream));
   }
@@ -1821,8 +1884,9 @@ int tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launche
   if (em_ms) *em_ms = h->em_ms_acc;
   if (em_launches) *em_launches = h->em_launches;
   // one EM pass must read every stored entry of the ambiguous rows once:
-  // 12 B per entry (fp64 Q + packed local row/col) + 2 B row weight code per row
-  if (algo_bytes) *algo_bytes = h->nnz_amb * 12 + h->N_amb * 2;
+  // 4 B packed local row/col + the value AS STORED (8 B fp64 Q, or a 2 B score code) per entry,
+  // + 2 B row weight code per row
+  if (algo_bytes) *algo_bytes = h->nnz_amb * (h->fmt_code ? 6 : 12) + h->N_amb * 2;
   if (reset) { h->em_ms_acc = 0; h->em_launches = 0; }
   return TSEM_OK;
 }
@@ -1839,7 +1903,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[0] = h->P; info[1] = h->Kp; info[2] = h->R; info[3] = h->nb;
   info[4] = h->N_amb; info[5] = h->N_uni; info[6] = h->nnz_amb; info[7] = h->nnz_pad;
   info[8] = h->n_twin_cols; info[9] = h->G1; info[10] = h->G2; info[11] = h->use_fused ? 1 : 0;
-  info[12] = h->last_slow_path; info[13] = h->max_subblock; info[14] = 0; info[15] = 0;
+  info[12] = h->last_slow_path; info[13] = h->max_subblock; info[14] = h->fmt_code ? 2 : 8; info[15] = h->n_hot_cols;
   return TSEM_OK;
 }
 

@@ -91,7 +91,13 @@ struct tsem_ctx {
   uint32_t* d_colmap = nullptr;     // [K]    col -> (part<<16 | lcol)
   int32_t* d_col_of_pc = nullptr;   // [Kpad] part*Kp+lcol -> col or -1
   int64_t* d_sb_off = nullptr;      // [nb*P+1] entry offsets (multiples of 4)
-  double* d_pval = nullptr;         // [nnz_pad]  Q values
+  double* d_pval = nullptr;         // [nnz_pad]  Q values (fp64 entry format)
+  uint16_t* d_pcode = nullptr;      // [nnz_pad]  raw score codes (code16 entry format: Q = lut[code])
+  bool fmt_code = false;            // entry format of the blocked layout: false = fp64 values, true = 2-byte codes
+  int64_t opt_hot_split = 1;        // 1: very popular columns get several accumulator slots (see build_layout)
+  int hot_extra = 0;                // spare slots per part reserved for them
+  int n_hot_cols = 0;               // columns that were split
+  int64_t opt_format = 0;           // 0 auto (codes when the fused kernel runs and the table fits LDS), 1 fp64, 2 codes
   uint32_t* d_prc = nullptr;        // [nnz_pad]  lrow<<16 | lcol
   double* d_ypart = nullptr;        // [P][N_amb_pad] partial row sums
   int G1 = 1, G2 = 1, T1 = 512, T2 = 1024;

@@ -61,7 +61,11 @@ struct FusedArgs {
   int64_t nb, N_amb_pad;
   const int64_t* sb_off;
   const uint32_t* sb_q32;   // sb_off / 4 as 32-bit quad indices (fused kernel only)
-  const double* pval;
+  const double* pval;       // FMT 0: Q values (fp64), 8 B per entry
+  const uint16_t* pcode;    // FMT 1: raw score codes, 2 B per entry; Q = lut[code] bit for bit (sparse_plus.py:89-91)
+  const double* lut;        // FMT 1: the score table, copied to LDS [lut_len]
+  int lut_len;
+  const uint16_t* wcode;    // FMT 1: [N_amb_pad] row weight as a code, w_i = lut[max code of the row]
   const uint32_t* prc;
   const double* ctab;
   const double* ctab2;  // lnl mode: pi*theta of the CURRENT params (ctab then holds the previous ones)
@@ -82,19 +86,39 @@ __device__ __forceinline__ uint32_t fz_ld_u32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: bypasses L1
 }
 
-struct FzRegs {            // 4 entries per thread: 12 VGPRs
+// Every vector-memory access of the steady-state loop is an UNCONDITIONAL raw buffer access: lanes
+// (or whole steps) with nothing to do use an out-of-range offset / an empty resource, for which the
+// hardware returns zeros (loads) or drops the write (stores).  With no branch around a load the
+// compiler can count: a use of block i's registers waits with `s_waitcnt vmcnt(n)`, n = the loads
+// issued since — with exec-masked or skipped loads it has to assume vmcnt(0), which drains the
+// memory pipe every step (measured: 5600 -> see profiles/r01_fused_timeline.txt).
+typedef unsigned int fz_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int fz_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int FZ_RSRC_FLAGS = 0x00027000;
+constexpr unsigned FZ_OOB = 0x7FFFFF00u;                 // beyond num_records of every resource used here
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fz_rsrc(const void* base, uint64_t byte_off, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(base) + byte_off), 0, (int)bytes,
+                                           FZ_RSRC_FLAGS);
+}
+__device__ __forceinline__ double2 fz_as_double2(fz_u32x4 t) {
+  return make_double2(__hiloint2double((int)t.y, (int)t.x), __hiloint2double((int)t.w, (int)t.z));
+}
+
+struct FzRegs {            // 4 entries per thread: 12 VGPRs (FMT 1: 6 until phase 1 turns the codes into numerators)
   uint4 rc;
   double2 v0, v1;
+  uint2 cd;
 };
 
 struct FzX {                 // context handed to the exchange wave
+  const double* lut;
   double* y; double* s; uint32_t* offs; unsigned long long* xbase; uint32_t* err;
   int R, team, T, lane, xw;
   int64_t nblk, nsteps;
 };
 
 // Exchange wave of member PP of a P-member team (see k_em_fused for the schedule).
-template <int P, int PP>
+template <int P, int PP, int MODE, int FMT>
 __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   constexpr int p = PP;
@@ -106,8 +130,10 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   const int64_t nblk = X.nblk, nsteps = X.nsteps;
   // rows served by this exchange wave: wave 0 fills its 16-byte x 64-lane instructions completely
   const int rlo = X.xw * (128 * FZ_RP), rhi = min(R, rlo + 128 * FZ_RP);
-  __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, FZ_XS * P * R * 8, 0x00027000);
+  __amdgpu_buffer_rsrc_t xrsrc = fz_rsrc(xbase, 0, (unsigned)(FZ_XS * P * R * 8));
+  __amdgpu_buffer_rsrc_t qrsrc = fz_rsrc(A.sb_q32, 0, (unsigned)((A.nb * P + 2) * 4));
   const bool offw = X.xw == 0;                                  // wave that also ferries the sub-block offsets
+  const bool nopart = (A.dbg & 1) != 0;                         // timing experiment: partner loads go out of range
   auto slot_of = [&](int64_t k, int q) -> unsigned long long* {
     return xbase + ((int64_t)(k & (FZ_XS - 1)) * P + q) * R;
   };
@@ -115,120 +141,138 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     return (unsigned long long)((((k / FZ_XS) & 1) ^ 1));
   };
   if (!(A.dbg & 16)) __builtin_amdgcn_s_setprio(3);   // few instructions, all on the critical path of the step
-    struct Gen { u64x2 pv[NPART][FZ_RP]; double2 w[FZ_RP]; uint32_t off; };
-    Gen ga, gb;
-    ga.off = gb.off = 0;
-    // issue the partner / weight loads of block k and the offset fetch of block ko
-    auto issue = [&](Gen& g, int64_t k, int64_t ko) {
-      if (offw && lane < 2 && ko >= 4 && ko < nblk)
-        g.off = __builtin_nontemporal_load(A.sb_q32 + (team + ko * T) * P + p + lane);
-      if (k < 0 || k >= nblk) return;
-#pragma unroll
-      for (int j = 0; j < FZ_RP; ++j) {
-        const int r = rlo + 2 * (lane + 64 * j);
-        if (r < rhi) {
-          g.w[j] = A.lnl_mode ? make_double2(1.0, 1.0)
-                              : *reinterpret_cast<const double2*>(&A.wrow[(team + k * T) * R + r]);
-          if (P > 1 && !(A.dbg & 1)) {
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-              if (q == p) continue;
-              // one 16-byte agent-scope (sc1, L1-bypassing) load per row pair and partner: a raw
-              // buffer load, because plain HIP offers sc1 only on <= 8-byte atomics and an `nt`
-              // load was measured to return stale lines
-              const unsigned boff = (unsigned)((((k & (FZ_XS - 1)) * P + q) * R + r) * 8);
-              typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-              u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, boff, 0, 16);
-              g.pv[q < p ? q : q - 1][j].x = ((unsigned long long)t.y << 32) | t.x;
-              g.pv[q < p ? q : q - 1][j].y = ((unsigned long long)t.w << 32) | t.z;
-            }
-          }
-        }
-      }
-    };
-    // combine block k from generation g: s = w * recip0(sum of the P partials), fixed order
-    auto combine = [&](Gen& g, int64_t k, int64_t ko) {
-      if (offw && lane < 2 && ko >= 4 && ko < nblk) offs[(ko & 7) * 2 + lane] = g.off;   // blocks 0..3: prologue
-      if (k < 0 || k >= nblk) return;
-      const unsigned long long tag = tag_of(k);
-#pragma unroll
-      for (int j = 0; j < FZ_RP; ++j) {
-        const int r = rlo + 2 * (lane + 64 * j);
-        if (r < rhi) {
-          u64x2 own = *reinterpret_cast<const u64x2*>(&y[(k & (FZ_YR - 1)) * R + r]);
-          if (P > 1 && !(A.dbg & 1)) {
-            unsigned spins = 0;
-            for (;;) {                                    // normally true at once: published 2 steps ago
-              bool ok = true;
-#pragma unroll
-              for (int i = 0; i < NPART; ++i) ok &= ((g.pv[i][j].x & 1ull) == tag) & ((g.pv[i][j].y & 1ull) == tag);
-              if (ok) break;
-              if (spins == 0) atomicAdd(err + 1, 1u);     // statistics: granules that were not there yet
-#pragma unroll
-              for (int q = 0; q < P; ++q) {               // slow path: agent-scope (sc1) reloads
-                if (q == p) continue;
-                const unsigned long long* src = slot_of(k, q) + r;
-                g.pv[q < p ? q : q - 1][j].x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g.pv[q < p ? q : q - 1][j].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-              if (++spins > FZ_SPIN_LIMIT) { atomicOr(err, 2u); break; }
-              if ((spins & 255u) == 0 && fz_ld_u32(err)) break;
-            }
-          }
-          double ys0 = 0.0, ys1 = 0.0;
-#pragma unroll
-          for (int q = 0; q < P; ++q) {                   // fixed order: every member computes the same bits
-            u64x2 v = (q == p || (A.dbg & 1)) ? own : g.pv[q < p ? q : (q > 0 ? q - 1 : 0)][j];
-            if (P > 1) { v.x &= ~1ull; v.y &= ~1ull; }
-            ys0 += __longlong_as_double((long long)v.x);
-            ys1 += __longlong_as_double((long long)v.y);
-          }
-          // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730)
-          *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(recip0(ys0) * g.w[j].x, recip0(ys1) * g.w[j].y);
-          *reinterpret_cast<double2*>(&y[(k & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
-        }
-      }
-    };
-    int64_t i = 0;
-    auto xstep = [&](Gen& gnew, Gen& gold) {
-      if (A.dbg & 8) {                                  // timing experiment: exchange waves only keep the barriers
-        if (offw && lane < 2) { const int64_t ko = i + FZ_DL + 1; if (ko >= 4 && ko < nblk) offs[(ko & 7) * 2 + lane] = A.sb_q32[(team + ko * T) * P + p + lane]; }
-        __syncthreads(); ++i; return;
-      }
-      const bool pr = A.prof && team == 0 && p == 0 && lane == 0 && offw && (int)i < A.prof_blocks;
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 6] = clock64();
-      // publish y(i-1): tagged granules, 16-byte stores (a tear between halves is harmless)
-      if (P > 1 && i - 1 >= 0 && i - 1 < nblk) {
-        const unsigned long long tag = tag_of(i - 1);
-#pragma unroll
-        for (int j = 0; j < FZ_RP; ++j) {
-          const int r = rlo + 2 * (lane + 64 * j);
-          if (r < rhi) {
-            u64x2 yv = *reinterpret_cast<const u64x2*>(&y[((i - 1) & (FZ_YR - 1)) * R + r]);
-            u64x2 gq = {(yv.x & ~1ull) | tag, (yv.y & ~1ull) | tag};
-            // PLAIN store: the line stays in the XCD's L2, where the partners' sc1 loads find it (a
-            // write-through sc1 store drops it from L2: measured 14 M tag misses per pass vs 0.14 M)
-            *reinterpret_cast<u64x2*>(slot_of(i - 1, p) + r) = gq;
-          }
-        }
-      }
-      // the publish must enter the memory pipe BEFORE this step's loads (partners read it a step later)
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 2);         // ahead of the data waves' burst(i+2)
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
-      combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 1);       // issued one step ago, behind burst(i)
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
-      __syncthreads();
-      ++i;
-    };
-    while (i < nsteps) {
-      xstep(ga, gb); if (i >= nsteps) break;
-      xstep(gb, ga);
+  struct Gen { u64x2 pv[NPART][FZ_RP]; double2 w[FZ_RP]; uint32_t wc[FZ_RP]; uint32_t off; };
+  Gen ga, gb;
+  ga.off = gb.off = 0;
+  // issue the partner / weight loads of block k and the offset fetch of block ko (never branched around)
+  auto issue = [&](Gen& g, int64_t k, int64_t ko) {
+    {
+      const bool ok = offw && lane < 2 && ko >= 4 && ko < nblk;
+      g.off = __builtin_amdgcn_raw_buffer_load_b32(qrsrc, ok ? (unsigned)(((team + ko * T) * P + p + lane) * 4) : FZ_OOB, 0, 0);
     }
+    const bool kv = k >= 0 && k < nblk;
+    const uint64_t blk = kv ? (uint64_t)(team + k * T) : 0;
+    if (MODE == 0) {                                            // row weights (the lnl pass uses w = 1)
+      if (FMT == 1) {
+        __amdgpu_buffer_rsrc_t wr = fz_rsrc(A.wcode, blk * R * 2, kv ? (unsigned)R * 2 : 0);
+#pragma unroll
+        for (int j = 0; j < FZ_RP; ++j)
+          g.wc[j] = __builtin_amdgcn_raw_buffer_load_b32(wr, (unsigned)(rlo + 2 * (lane + 64 * j)) * 2, 0, 0);   // 2 codes
+      } else {
+        __amdgpu_buffer_rsrc_t wr = fz_rsrc(A.wrow, blk * R * 8, kv ? (unsigned)R * 8 : 0);
+#pragma unroll
+        for (int j = 0; j < FZ_RP; ++j)
+          g.w[j] = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)(rlo + 2 * (lane + 64 * j)) * 8, 0, 0));
+      }
+    }
+    if (P > 1) {
+#pragma unroll
+      for (int j = 0; j < FZ_RP; ++j) {
+        const int r = rlo + 2 * (lane + 64 * j);
+        const bool ok = kv && r < rhi && !nopart;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          if (q == p) continue;
+          // one 16-byte agent-scope (sc1, L1-bypassing) load per row pair and partner
+          const unsigned boff = ok ? (unsigned)((((k & (FZ_XS - 1)) * P + q) * R + r) * 8) : FZ_OOB;
+          fz_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, boff, 0, 16);
+          g.pv[q < p ? q : q - 1][j].x = ((unsigned long long)t.y << 32) | t.x;
+          g.pv[q < p ? q : q - 1][j].y = ((unsigned long long)t.w << 32) | t.z;
+        }
+      }
+    }
+  };
+  // combine block k from generation g: s = w * recip0(sum of the P partials), fixed order
+  auto combine = [&](Gen& g, int64_t k, int64_t ko) {
+    if (offw && lane < 2 && ko >= 4 && ko < nblk) offs[(ko & 7) * 2 + lane] = g.off;   // blocks 0..3: prologue
+    if (k < 0 || k >= nblk) return;
+    const unsigned long long tag = tag_of(k);
+#pragma unroll
+    for (int j = 0; j < FZ_RP; ++j) {
+      const int r = rlo + 2 * (lane + 64 * j);
+      if (r < rhi) {
+        u64x2 own = *reinterpret_cast<const u64x2*>(&y[(k & (FZ_YR - 1)) * R + r]);
+        if (P > 1 && !nopart) {
+          unsigned spins = 0;
+          for (;;) {                                    // normally true at once: published 2 steps ago
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < NPART; ++i) ok &= ((g.pv[i][j].x & 1ull) == tag) & ((g.pv[i][j].y & 1ull) == tag);
+            if (ok) break;
+            if (spins == 0) atomicAdd(err + 1, 1u);     // statistics: granules that were not there yet
+#pragma unroll
+            for (int q = 0; q < P; ++q) {               // slow path: agent-scope (sc1) reloads
+              if (q == p) continue;
+              const unsigned long long* src = slot_of(k, q) + r;
+              g.pv[q < p ? q : q - 1][j].x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              g.pv[q < p ? q : q - 1][j].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (++spins > FZ_SPIN_LIMIT) { atomicOr(err, 2u); break; }
+            if ((spins & 255u) == 0 && fz_ld_u32(err)) break;
+          }
+        }
+        double ys0 = 0.0, ys1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {                   // fixed order: every member computes the same bits
+          u64x2 v = (q == p || nopart) ? own : g.pv[q < p ? q : (q > 0 ? q - 1 : 0)][j];
+          if (P > 1) { v.x &= ~1ull; v.y &= ~1ull; }
+          ys0 += __longlong_as_double((long long)v.x);
+          ys1 += __longlong_as_double((long long)v.y);
+        }
+        double2 w = make_double2(1.0, 1.0);
+        if (MODE == 0) w = FMT == 1 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
+        // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730)
+        *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(recip0(ys0) * w.x, recip0(ys1) * w.y);
+        *reinterpret_cast<double2*>(&y[(k & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
+      }
+    }
+  };
+  int64_t i = 0;
+  if (A.dbg & 8) {                                      // timing experiment: exchange waves only keep the barriers
+    for (; i < nsteps; ++i) {
+      if (offw && lane < 2) { const int64_t ko = i + FZ_DL + 1; if (ko >= 4 && ko < nblk) offs[(ko & 7) * 2 + lane] = A.sb_q32[(team + ko * T) * P + p + lane]; }
+      __syncthreads();
+    }
+    return;
+  }
+  auto xstep = [&](Gen& gnew, Gen& gold) {
+    const bool pr = A.prof && team == 0 && p == 0 && lane == 0 && offw && (int)i < A.prof_blocks;
+    if (pr) A.prof[i * FZ_PROF_SLOTS + 6] = clock64();
+    // publish y(i-1): tagged granules, 16-byte stores (a tear between halves is harmless).  PLAIN
+    // stores: the line stays in the XCD's L2, where the partners' sc1 loads find it (a write-through
+    // sc1 store drops it from L2: measured 14 M tag misses per pass vs 0.14 M)
+    if (P > 1) {
+      const int64_t kp = i - 1;
+      const bool pv = kp >= 0 && kp < nblk;
+      const unsigned long long tag = tag_of(kp);
+#pragma unroll
+      for (int j = 0; j < FZ_RP; ++j) {
+        const int r = rlo + 2 * (lane + 64 * j);
+        u64x2 yv = *reinterpret_cast<const u64x2*>(&y[(kp & (FZ_YR - 1)) * R + min(r, R - 2)]);
+        fz_u32x4 gq;
+        gq.x = ((unsigned)yv.x & ~1u) | (unsigned)tag; gq.y = (unsigned)(yv.x >> 32);
+        gq.z = ((unsigned)yv.y & ~1u) | (unsigned)tag; gq.w = (unsigned)(yv.y >> 32);
+        const unsigned boff = (pv && r < rhi) ? (unsigned)((((kp & (FZ_XS - 1)) * P + p) * R + r) * 8) : FZ_OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(gq, xrsrc, boff, 0, 0);
+      }
+    }
+    // the publish must enter the memory pipe BEFORE this step's loads (partners read it a step later)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 2);         // ahead of the data waves' burst(i+2)
+    if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
+    combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 1);       // issued one step ago, behind burst(i)
+    if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
+    __syncthreads();
+    ++i;
+  };
+  while (i < nsteps) {
+    xstep(ga, gb); if (i >= nsteps) break;
+    xstep(gb, ga);
+  }
 }
 
-template <int PT, int MODE>
+template <int PT, int MODE, int FMT>
 __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int P = PT;
@@ -263,19 +307,19 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   for (int t = tid; t < FZ_YR * R; t += FZ_NT) y[t] = 0.0;
   for (int t = tid; t < 2 * R; t += FZ_NT) s[t] = 0.0;
   __syncthreads();
-  const int ticket = ibox[0];
+  const int ticket = __builtin_amdgcn_readfirstlane(ibox[0]);   // LDS broadcasts: tell the compiler they are uniform
   const int u = ticket / P, p = ticket % P;
   int T = 0, tbase = 0;
   for (int x = 0; x < 8; ++x) {
-    int teams = ibox[1 + x] / P;
+    int teams = __builtin_amdgcn_readfirstlane(ibox[1 + x]) / P;
     if (x < (int)xcc) tbase += teams;
     T += teams;
   }
-  const bool valid = (u + 1) * P <= ibox[1 + xcc] && fz_ld_u32(err) == 0;
+  const bool valid = (u + 1) * P <= __builtin_amdgcn_readfirstlane(ibox[1 + xcc]) && fz_ld_u32(err) == 0;
   if (!valid || T == 0) return;                          // leftover workgroup of an incomplete team
   const int team = tbase + u;                            // 0..T-1
   for (int t = tid; t < Kp; t += FZ_NT) c[t] = A.ctab[p * Kp + t];
-  if (A.lnl_mode)
+  if (MODE == 1)
     for (int t = tid; t < Kp; t += FZ_NT) acc[t] = A.ctab2[p * Kp + t];
   unsigned long long* const xbase = reinterpret_cast<unsigned long long*>(A.xchg) + (int64_t)team * FZ_XS * P * R;
   __syncthreads();
@@ -303,6 +347,9 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     return (unsigned long long)((((k / FZ_XS) & 1) ^ 1));
   };
   uint32_t* offs = reinterpret_cast<uint32_t*>(ibox + 16);   // [8][2] sub-block quad ranges (ring), LDS
+  double* lutS = reinterpret_cast<double*>(ibox + 32);       // FMT 1: score table [lut_len]
+  if (FMT == 1)
+    for (int t = tid; t < A.lut_len; t += FZ_NT) lutS[t] = A.lut[t];
   const int64_t nsteps = nblk + FZ_LAG + 1;               // last scatter is block nblk-1 at step nblk+3
   // prologue: offsets of blocks 0..3 straight into LDS
   if (tid < 8) {
@@ -316,39 +363,51 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     // ============================ exchange wave ===============================
     // dispatched on the member index so every register array is statically indexed
     FzX X;
-    X.y = y; X.s = s; X.offs = offs; X.xbase = xbase; X.err = err; X.R = R; X.team = team; X.T = T;
+    X.lut = lutS; X.y = y; X.s = s; X.offs = offs; X.xbase = xbase; X.err = err; X.R = R; X.team = team; X.T = T;
     X.nblk = nblk; X.nsteps = nsteps; X.lane = (tid - FZ_DT) & 63; X.xw = (tid - FZ_DT) >> 6;
     switch (p) {
-      case 0: fz_xchg<P, 0>(A, X); break;
-      case 1: if (P > 1) fz_xchg<P, (P > 1 ? 1 : 0)>(A, X); break;
-      case 2: if (P > 2) fz_xchg<P, (P > 2 ? 2 : 0)>(A, X); break;
-      case 3: if (P > 3) fz_xchg<P, (P > 3 ? 3 : 0)>(A, X); break;
-      case 4: if (P > 4) fz_xchg<P, (P > 4 ? 4 : 0)>(A, X); break;
-      case 5: if (P > 5) fz_xchg<P, (P > 5 ? 5 : 0)>(A, X); break;
-      case 6: if (P > 6) fz_xchg<P, (P > 6 ? 6 : 0)>(A, X); break;
-      case 7: if (P > 7) fz_xchg<P, (P > 7 ? 7 : 0)>(A, X); break;
+      case 0: fz_xchg<P, 0, MODE, FMT>(A, X); break;
+      case 1: if (P > 1) fz_xchg<P, (P > 1 ? 1 : 0), MODE, FMT>(A, X); break;
+      case 2: if (P > 2) fz_xchg<P, (P > 2 ? 2 : 0), MODE, FMT>(A, X); break;
+      case 3: if (P > 3) fz_xchg<P, (P > 3 ? 3 : 0), MODE, FMT>(A, X); break;
+      case 4: if (P > 4) fz_xchg<P, (P > 4 ? 4 : 0), MODE, FMT>(A, X); break;
+      case 5: if (P > 5) fz_xchg<P, (P > 5 ? 5 : 0), MODE, FMT>(A, X); break;
+      case 6: if (P > 6) fz_xchg<P, (P > 6 ? 6 : 0), MODE, FMT>(A, X); break;
+      case 7: if (P > 7) fz_xchg<P, (P > 7 ? 7 : 0), MODE, FMT>(A, X); break;
       default: break;
     }
   } else {
     // ============================== data waves ================================
-    auto load_blk = [&](FzRegs& rr, uint32_t oq0, uint32_t oq1, int64_t k) {
-      if (k < 0 || k >= nblk) return;
-      const int64_t q = (int64_t)oq0 + tid;
-      if (q < (int64_t)oq1) {
-        rr.rc = reinterpret_cast<const uint4*>(A.prc)[q];
-        rr.v0 = reinterpret_cast<const double2*>(A.pval)[2 * q];
-        rr.v1 = reinterpret_cast<const double2*>(A.pval)[2 * q + 1];
+    // Loads of block k: resources rebased to the sub-block, so thread t reads quad t at a constant
+    // offset and every lane past the sub-block's end (or a whole step past the last block) reads zeros.
+    auto load_blk = [&](FzRegs& rr, uint32_t oq0v, uint32_t oq1v, int64_t k) {
+      const uint32_t oq0 = __builtin_amdgcn_readfirstlane(oq0v);
+      const uint32_t nq = (k >= 0 && k < nblk) ? __builtin_amdgcn_readfirstlane(oq1v) - oq0 : 0u;
+      fz_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(fz_rsrc(A.prc, (uint64_t)oq0 * 16, nq * 16), (unsigned)tid * 16, 0, 0);
+      rr.rc = make_uint4(t.x, t.y, t.z, t.w);
+      if (FMT == 1) {
+        fz_u32x2 cd = __builtin_amdgcn_raw_buffer_load_b64(fz_rsrc(A.pcode, (uint64_t)oq0 * 8, nq * 8), (unsigned)tid * 8, 0, 0);
+        rr.cd = make_uint2(cd.x, cd.y);
       } else {
-        rr.rc = make_uint4(0xFFFFFFFFu, 0, 0, 0);         // no entries in this lane: both phases skip it
-        rr.v0 = make_double2(0.0, 0.0);                    // (zeros added to y[0] / acc[0] by every idle
-        rr.v1 = make_double2(0.0, 0.0);                    //  lane would serialise on one LDS address)
+        __amdgpu_buffer_rsrc_t vr = fz_rsrc(A.pval, (uint64_t)oq0 * 32, nq * 32);
+        rr.v0 = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(vr, (unsigned)tid * 32, 0, 0));
+        rr.v1 = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(vr, (unsigned)tid * 32 + 16, 0, 0));
       }
     };
-    // phase 1: numerators n = Q * (pi*theta) kept in the registers, partial row sums into y(k)
+    // phase 1: numerators n = Q * (pi*theta) kept in the registers, partial row sums into y(k).
+    // A lane whose quad is all zeros (past the end of the sub-block, or a step without a block) marks
+    // itself idle in rc.x and skips both phases: zeros added to y[0] / acc[0] by every idle lane
+    // would serialise on one LDS address.
     constexpr bool lnl = MODE == 1;
     auto phase1 = [&](FzRegs& rr, int64_t k) {
-      if (k < 0 || k >= nblk || rr.rc.x == 0xFFFFFFFFu) return;
+      const bool idle = FMT == 1 ? (rr.cd.x | rr.cd.y) == 0u
+                                 : (rr.v0.x == 0.0) & (rr.v0.y == 0.0) & (rr.v1.x == 0.0) & (rr.v1.y == 0.0);
+      if (idle) { rr.rc.x = 0xFFFFFFFFu; return; }
       double* yb = y + (k & (FZ_YR - 1)) * R;
+      if (FMT == 1) {                                     // Q from the score table: the same fp64 the fp64 layout stores
+        rr.v0 = make_double2(lutS[rr.cd.x & 0xFFFFu], lutS[rr.cd.x >> 16]);
+        rr.v1 = make_double2(lutS[rr.cd.y & 0xFFFFu], lutS[rr.cd.y >> 16]);
+      }
       if (lnl) {                                          // the registers keep Q: phase 2 needs it twice
         lds_add(&yb[rr.rc.x >> 16], rr.v0.x * c[rr.rc.x & 0xFFFF]);
         lds_add(&yb[rr.rc.y >> 16], rr.v0.y * c[rr.rc.y & 0xFFFF]);
@@ -363,7 +422,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     };
     // phase 2: scatter w * z into the part's column accumulators
     auto phase2 = [&](FzRegs& rr, int64_t k) {
-      if (k < 0 || k >= nblk || rr.rc.x == 0xFFFFFFFFu) return;
+      if (rr.rc.x == 0xFFFFFFFFu) return;
       const double* sb = s + (k & 1) * R;
       if (lnl) {                                          // z = (Q c_prev) * recip0(rowsum);  acc[] holds c_cur
         auto term = [&](double q, uint32_t rc) {
@@ -379,8 +438,13 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       lds_add(&acc[rr.rc.w & 0xFFFF], rr.v1.y * sb[rr.rc.w >> 16]);
     };
     FzRegs r0, r1, r2, r3, r4, r5;
+    {
+      FzRegs z;                                           // sets that hold no block yet are idle
+      z.rc = make_uint4(0xFFFFFFFFu, 0, 0, 0); z.v0 = z.v1 = make_double2(0.0, 0.0); z.cd = make_uint2(0, 0);
+      r0 = r1 = r2 = r3 = r4 = r5 = z;
+    }
 #if FZ_GAP_STEPS == 2
-    FzRegs r6;
+    FzRegs r6 = r0;
 #endif
     int64_t i = 0;
     // step i: `rs` is the set of block i-LAG (scattered, then refilled with block i+2); `rp` the set of block i
