@@ -63,6 +63,8 @@ def parse():
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
     ap.add_argument('--cpu-iters', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt-layout', action='store_true',
+                    help='skip the second measurement with fp64 entries (N=1, --value-format auto only)')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the multi-rank code path (RCCL group, per-iteration all-reduce) even at world size 1')
     return ap.parse_args()
@@ -178,16 +180,7 @@ def main():
         return
 
     info = eng.layout_info()
-    traffic = None
-    try:   # HBM bytes per launch from a separate rocprofv3 --pmc run of this same workload (profiles/)
-        tj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-        w = tj['workload']
-        kern = 'fused' if info.get('fused') else 'twopass'
-        if (w['rows'], w['cols'], w['nnz_row'], w['dist'], w['em_kernel'], w['n_gpus'], w.get('value_bytes', 8)) == \
-                (total_rows, args.cols, args.nnz_row, args.dist, kern, world, info.get('value_bytes', 8)):
-            traffic = tj['traffic_bytes_per_launch'] / 1e9
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic = _pmc_traffic(total_rows, args, world, info.get('value_bytes', 8)) if info.get('fused') else None
     k_ms = ks['em_ms'] / max(1, ks['em_launches'])
     achieved = ks['algo_bytes_per_pass'] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     out = {
@@ -209,10 +202,40 @@ def main():
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC, profiles/pmc_traffic.json)',
-            'kernel': 'EM pass (rank 0 shard)', 'kernel_ms': k_ms,
+            'kernel': 'EM pass k_em_fused (rank 0 shard)', 'kernel_ms': k_ms,
+            'limiter': ('LDS atomics/gathers (code16 entries halve the HBM bytes; see f64_layout for the HBM-bound form)'
+                        if info.get('value_bytes') == 2 else 'HBM stream + exchange traffic'),
             'algo_bytes_per_launch': ks['algo_bytes_per_pass'],
         },
     }
+    if world == 1 and args.value_format == 'auto' and info.get('value_bytes') == 2 and not args.no_alt_layout:
+        # the same workload with fp64 entries (the reference's own storage, 12 B/nnz): the HBM-bound form
+        # of the kernel, reported beside the default layout; not part of `value`
+        eng.close()
+        del tl
+        eng2 = Engine(local)
+        eng2.set_option('value_format', 1)
+        eng2.generate(r0, r1, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
+        tl2 = TelescopeLikelihood.from_engine(eng2, Opts(args.steps), None)
+        eng2.em_steps(args.warmup, want_diffs=False)
+        eng2.kernel_stats(reset=True)
+        eng2.synchronize()
+        t0 = time.perf_counter()
+        eng2.em_steps(args.steps, want_diffs=False)
+        eng2.synchronize()
+        el2 = time.perf_counter() - t0
+        ks2 = eng2.kernel_stats()
+        k2 = ks2['em_ms'] / max(1, ks2['em_launches'])
+        a2 = ks2['algo_bytes_per_pass'] / (k2 * 1e-3) / 1e9
+        out['f64_layout'] = {
+            'value_format': 'f64 (12 B/nnz stored)', 'ms_per_step': el2 / args.steps * 1e3,
+            'nnz_per_sec': nnz_total * args.steps / el2,
+            'roofline': {'bound': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a2 / HBM_PEAK_GBS,
+                         'kernel_ms': k2, 'algo_bytes_per_launch': ks2['algo_bytes_per_pass'],
+                         'traffic': _pmc_traffic(total_rows, args, world, 8)},
+        }
+        eng2.close()
+        del tl2
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(args, dist_code, cdf)
         out['cpu_baseline'] = {
@@ -235,6 +258,19 @@ def main():
     except Exception:   # noqa: BLE001
         pass
     print(json.dumps(out), flush=True)
+
+
+def _pmc_traffic(total_rows, args, world, value_bytes):
+    """HBM bytes per launch (GB) from a separate rocprofv3 --pmc run of this same workload (profiles/)."""
+    try:
+        for tj in json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))['runs']:
+            w = tj['workload']
+            if (w['rows'], w['cols'], w['nnz_row'], w['dist'], w['n_gpus'], w['value_bytes']) == \
+                    (total_rows, args.cols, args.nnz_row, args.dist, world, value_bytes):
+                return tj['traffic_bytes_per_launch'] / 1e9
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    return None
 
 
 def _shutdown(comm):

@@ -12,7 +12,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, 'libtelescope_em.so')
+# TSEM_LIB: kernel experiments (A/B builds of the same source); the product always uses the in-tree build
+LIB_PATH = os.environ.get('TSEM_LIB') or os.path.join(HERE, 'libtelescope_em.so')
 SRC = os.path.join(HERE, 'csrc', 'tsem.hip')
 
 OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_TIMEOUT = 0, -1, -2, -3, -4

@@ -320,6 +320,56 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
   }
 }
 
+// Fused layout: the entries of a sub-block are stored densely in ROW order (any order inside a row), so
+// a thread's four consecutive entries and its neighbours' mostly share a row and the row sums can be
+// reduced in registers / across lanes instead of one LDS atomic per entry (tsem_fused.h, phase 1).
+// The padding at the end of a sub-block repeats the last row with value 0.
+__global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
+    const double* __restrict__ lut, const uint32_t* __restrict__ colmap, const int64_t* __restrict__ sb_off,
+    double* __restrict__ pval, uint16_t* __restrict__ pcode, uint32_t* __restrict__ prc) {
+  __shared__ uint32_t cnt[512 * 8];                        // [row slot][part]: counts, then write cursors
+  __shared__ uint32_t total[8], lastrow[8];
+  const int64_t b = blockIdx.x;
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int t = threadIdx.x; t < R * P; t += blockDim.x) cnt[t] = 0;
+  __syncthreads();
+  for (int lr = sub; lr < R; lr += subs) {
+    const int64_t i = amb_row[b * R + lr];
+    if (i < 0) continue;
+    for (int64_t k = indptr[i] + lane; k < indptr[i + 1]; k += RS_SUB) atomicAdd(&cnt[lr * P + (colmap[indices[k]] >> 16)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < P) {                                   // exclusive scan down the rows, one thread per part
+    uint32_t run = 0, last = 0;
+    for (int lr = 0; lr < R; ++lr) {
+      const uint32_t c = cnt[lr * P + threadIdx.x];
+      cnt[lr * P + threadIdx.x] = run;
+      if (c) last = (uint32_t)lr;
+      run += c;
+    }
+    total[threadIdx.x] = run; lastrow[threadIdx.x] = last;
+  }
+  __syncthreads();
+  for (int lr = sub; lr < R; lr += subs) {
+    const int64_t i = amb_row[b * R + lr];
+    if (i < 0) continue;
+    for (int64_t k = indptr[i] + lane; k < indptr[i + 1]; k += RS_SUB) {
+      const uint32_t cm = colmap[indices[k]];
+      const uint32_t p = cm >> 16;
+      const uint32_t t = atomicAdd(&cnt[lr * P + p], 1u);
+      const int64_t pos = sb_off[b * P + p] + t;
+      if (pcode) pcode[pos] = raw[k];
+      else pval[pos] = lut[raw[k]];
+      prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
+    }
+  }
+  for (int p = 0; p < P; ++p) {                            // padding: value 0 (buffers are zero-filled), row = last row
+    const int64_t base = sb_off[b * P + p], end = sb_off[b * P + p + 1];
+    for (int64_t pos = base + total[p] + threadIdx.x; pos < end; pos += blockDim.x) prc[pos] = lastrow[p] << 16;
+  }
+}
+
 // ============================================================================
 // EM hot loop — two-pass form (phase 1: partial row sums; phase 2: scatter)
 // ============================================================================
@@ -1299,7 +1349,11 @@ static int build_layout(tsem_ctx* h) {
     TSEM_ALLOC(h->d_pval, off);
     TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
   }
-  if (nb) {
+  if (nb && h->use_fused && R <= 512 && P <= 8) {
+    k_sb_fill_sorted<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
+                                                         h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc);
+    TSEM_HIP(hipGetLastError());
+  } else if (nb) {
     k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                   h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc);
     TSEM_HIP(hipGetLastError());

@@ -24,7 +24,13 @@
 //     phase (step k) and scatter phase (step k+4): a ring of 6 register sets, prefetch
 //     distance 2 steps, so every stored entry is read from HBM exactly once and the
 //     memory pipe never drains (data-path ceiling of this schedule: 6.2 TB/s,
-//     tools/ubench/ring.hip).
+//     tools/ubench/ring.hip);
+//   * entries are 4 B (local row, local column) + either the fp64 Q value (FMT 0) or
+//     its 2-byte score code, looked up in an LDS copy of the score table (FMT 1): the
+//     same fp64 number at half the HBM bytes;
+//   * a sub-block is stored in row order, so the row sums are reduced in registers and
+//     across lanes (fz_row_sums) and only the end of each run of equal rows issues an
+//     LDS atomic: ds_add_f64 costs 3x a gather (profiles/r01_lds_ubench.log).
 // No assumption is made about dispatch order or block->XCD placement: teams,
 // their size and the block round-robin all derive from tickets taken at run
 // time; every wait is bounded and reports through an error word.
@@ -91,7 +97,7 @@ __device__ __forceinline__ uint32_t fz_ld_u32(const uint32_t* p) {
 // hardware returns zeros (loads) or drops the write (stores).  With no branch around a load the
 // compiler can count: a use of block i's registers waits with `s_waitcnt vmcnt(n)`, n = the loads
 // issued since — with exec-masked or skipped loads it has to assume vmcnt(0), which drains the
-// memory pipe every step (measured: 5600 -> see profiles/r01_fused_timeline.txt).
+// memory pipe twice per step (measured: 6.09 -> 5.04 ms per pass).
 typedef unsigned int fz_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int fz_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int FZ_RSRC_FLAGS = 0x00027000;
@@ -102,6 +108,64 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t fz_rsrc(const void* base, uint
 }
 __device__ __forceinline__ double2 fz_as_double2(fz_u32x4 t) {
   return make_double2(__hiloint2double((int)t.y, (int)t.x), __hiloint2double((int)t.w, (int)t.z));
+}
+
+// Cross-lane moves on the VALU (DPP): gfx9 keeps the wavefront shifts and row broadcasts.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int fz_dpp_i(int old, int src) {
+  int r = __builtin_amdgcn_update_dpp(old, src, CTRL, ROWMASK, 0xF, false);   // no source lane -> `old`
+  asm volatile("" : "+v"(r));                                                   // (see fz_shr1_d)
+  return r;
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double fz_dpp_d(double old, double src) {
+  const int lo = fz_dpp_i<CTRL, ROWMASK>(__double2loint(old), __double2loint(src));
+  const int hi = fz_dpp_i<CTRL, ROWMASK>(__double2hiint(old), __double2hiint(src));
+  return __hiloint2double(hi, lo);
+}
+constexpr int FZ_DPP_WAVE_SHL1 = 0x130, FZ_DPP_WAVE_SHR1 = 0x138;
+__device__ __forceinline__ double fz_shr1_d(double v) {     // value of lane l-1 (0 for lane 0)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), FZ_DPP_WAVE_SHR1, 0xF, 0xF, true);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), FZ_DPP_WAVE_SHR1, 0xF, 0xF, true);
+  int lo2 = lo;
+  // pin the moves where they are written: sunk into a divergent branch they would run with a partial
+  // EXEC mask, and a DPP move reads 0 from a lane that is switched off
+  asm volatile("" : "+v"(lo2), "+v"(hi));
+  return __hiloint2double(hi, lo2);
+}
+// Row sums of a wave whose lanes hold four consecutive entries each, stored in row order: add the
+// products m0..m3 (rows r0..r3) into yb[] with ONE LDS atomic per run of equal rows instead of one
+// per entry (ds_add_f64 costs 24 clk per 64 lanes, a gather 8: profiles/r01_lds_ubench.log).  Runs
+// inside a lane are summed in registers; a run that continues into the next lanes is handed on with
+// wavefront shifts on the VALU (as many rounds as the longest chain of lanes lying inside one row:
+// usually 1-3).  Every lane of the wave must call this (idle lanes with idle = true).  The result
+// is right for any entry order; the row order only makes the runs long.
+__device__ __forceinline__ void fz_row_sums(double* yb, bool idle, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3,
+                                            double m0, double m1, double m2, double m3) {
+  const bool e01 = r1 == r0, e12 = r2 == r1, e23 = r3 == r2;
+  const double s1 = e01 ? m0 + m1 : m1;                     // running sums of the runs inside the lane
+  const double s2 = e12 ? s1 + m2 : m2;
+  const double s3 = e23 ? s2 + m3 : m3;
+  const int a = idle ? 0xFFFF : (int)r0, b = idle ? 0xFFFD : (int)r3;
+  const int prev_b = fz_dpp_i<FZ_DPP_WAVE_SHR1, 0xF>(0xFFFE, b);
+  const int next_a = fz_dpp_i<FZ_DPP_WAVE_SHL1, 0xF>(0xFFFC, a);
+  const bool joins = prev_b == a;                            // my first run continues the left neighbour's last one
+  const bool open = e01 & e12 & e23 & joins;                 // the whole lane lies inside that run: pass the sum on
+  double I = idle ? 0.0 : s3;                                // sum of the run that ends with my last entry
+  for (unsigned long long chain = __builtin_amdgcn_ballot_w64(open); chain; chain &= chain << 1) {
+    const double up = fz_shr1_d(I);
+    if (open) I = s3 + up;
+  }
+  const double left = fz_shr1_d(I);                          // (not inside the ?: — every lane must execute the move)
+  const double C = joins ? left : 0.0;                       // what the lanes to the left bring for my first run
+  if (!idle) {
+    // runs that end before my last entry: the first of them takes the carry
+    if (!e01) lds_add(&yb[r0], m0 + C);
+    const double C1 = e01 ? C : 0.0;
+    if (!e12) lds_add(&yb[r1], s1 + C1);
+    if (!e23) lds_add(&yb[r2], s2 + (e12 ? C1 : 0.0));
+    if (next_a != b) lds_add(&yb[r3], I);                    // my last run ends here (else the right neighbour has it)
+  }
 }
 
 struct FzRegs {            // 4 entries per thread: 12 VGPRs (FMT 1: 6 until phase 1 turns the codes into numerators)
@@ -263,6 +327,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
     combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 1);       // issued one step ago, behind burst(i)
     if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
+    if (A.prof && team == 0 && p == 0 && lane == 0 && X.xw == 1 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 9] = clock64();
     __syncthreads();
     ++i;
   };
@@ -402,23 +467,20 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     auto phase1 = [&](FzRegs& rr, int64_t k) {
       const bool idle = FMT == 1 ? (rr.cd.x | rr.cd.y) == 0u
                                  : (rr.v0.x == 0.0) & (rr.v0.y == 0.0) & (rr.v1.x == 0.0) & (rr.v1.y == 0.0);
-      if (idle) { rr.rc.x = 0xFFFFFFFFu; return; }
+      if (__builtin_amdgcn_ballot_w64(!idle) == 0) { rr.rc.x = 0xFFFFFFFFu; return; }   // whole wave idle
       double* yb = y + (k & (FZ_YR - 1)) * R;
-      if (FMT == 1) {                                     // Q from the score table: the same fp64 the fp64 layout stores
-        rr.v0 = make_double2(lutS[rr.cd.x & 0xFFFFu], lutS[rr.cd.x >> 16]);
-        rr.v1 = make_double2(lutS[rr.cd.y & 0xFFFFu], lutS[rr.cd.y >> 16]);
+      double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+      if (!idle) {
+        if (FMT == 1) {                                   // Q from the score table: the same fp64 the fp64 layout stores
+          rr.v0 = make_double2(lutS[rr.cd.x & 0xFFFFu], lutS[rr.cd.x >> 16]);
+          rr.v1 = make_double2(lutS[rr.cd.y & 0xFFFFu], lutS[rr.cd.y >> 16]);
+        }
+        m0 = rr.v0.x * c[rr.rc.x & 0xFFFF]; m1 = rr.v0.y * c[rr.rc.y & 0xFFFF];
+        m2 = rr.v1.x * c[rr.rc.z & 0xFFFF]; m3 = rr.v1.y * c[rr.rc.w & 0xFFFF];
+        if (!lnl) { rr.v0 = make_double2(m0, m1); rr.v1 = make_double2(m2, m3); }   // lnl keeps Q: phase 2 needs it twice
       }
-      if (lnl) {                                          // the registers keep Q: phase 2 needs it twice
-        lds_add(&yb[rr.rc.x >> 16], rr.v0.x * c[rr.rc.x & 0xFFFF]);
-        lds_add(&yb[rr.rc.y >> 16], rr.v0.y * c[rr.rc.y & 0xFFFF]);
-        lds_add(&yb[rr.rc.z >> 16], rr.v1.x * c[rr.rc.z & 0xFFFF]);
-        lds_add(&yb[rr.rc.w >> 16], rr.v1.y * c[rr.rc.w & 0xFFFF]);
-        return;
-      }
-      rr.v0.x *= c[rr.rc.x & 0xFFFF]; lds_add(&yb[rr.rc.x >> 16], rr.v0.x);
-      rr.v0.y *= c[rr.rc.y & 0xFFFF]; lds_add(&yb[rr.rc.y >> 16], rr.v0.y);
-      rr.v1.x *= c[rr.rc.z & 0xFFFF]; lds_add(&yb[rr.rc.z >> 16], rr.v1.x);
-      rr.v1.y *= c[rr.rc.w & 0xFFFF]; lds_add(&yb[rr.rc.w >> 16], rr.v1.y);
+      fz_row_sums(yb, idle, rr.rc.x >> 16, rr.rc.y >> 16, rr.rc.z >> 16, rr.rc.w >> 16, m0, m1, m2, m3);
+      if (idle) rr.rc.x = 0xFFFFFFFFu;
     };
     // phase 2: scatter w * z into the part's column accumulators
     auto phase2 = [&](FzRegs& rr, int64_t k) {
@@ -459,6 +521,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       if (pr) A.prof[i * FZ_PROF_SLOTS + 2] = clock64();
       phase1(rp, i);                                      // waits for burst(i), issued two steps ago
       if (pr) A.prof[i * FZ_PROF_SLOTS + 3] = clock64();
+      if (A.prof && team == 0 && p == 0 && tid == FZ_DT - 64 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 8] = clock64();
       __syncthreads();
       if (pr) A.prof[i * FZ_PROF_SLOTS + 4] = clock64();
       ++i;

@@ -328,6 +328,68 @@ def test_ragged_rows_and_kernel_variants(gpu_device):
     assert b['fused'] == 0 and a['P'] == b['P'] == 2
 
 
+def _random_csr(rng, n, k, max_len, lo, hi, hot_frac=0.0):
+    lens = rng.randint(2, max_len, n)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    rows = []
+    for l in lens:
+        c = rng.choice(k - 1, l, replace=False) + 1
+        if rng.rand() < hot_frac:
+            c[0] = 0                                      # column 0 (`__no_feature`) in most rows
+        rows.append(np.sort(c))
+    indices = np.concatenate(rows).astype(np.int32)
+    data = rng.randint(lo, hi, indptr[-1]).astype(np.uint16)
+    return sp.csr_matrix((data, indices, indptr), shape=(n, k))
+
+
+@pytest.mark.parametrize('fmt,expect_bytes', [(0, 2), (1, 8), (2, 2)])
+def test_entry_formats_agree_with_oracle(gpu_device, fmt, expect_bytes):
+    """uint16 score codes + LDS score table (default) and fp64 entries run the same arithmetic."""
+    raw = _random_csr(np.random.RandomState(11), 40000, 20000, 40, 120, 330)
+    info = _oracle_vs_gpu(raw, options=(('value_format', fmt),))
+    assert info['fused'] == 1 and info['value_bytes'] == expect_bytes
+
+
+def test_large_score_table_falls_back_to_fp64_entries(gpu_device):
+    """Raw scores up to 6000 -> a 6001-entry table does not go to LDS: fp64 entries, same results;
+    asking for codes explicitly is an error, not a silent change of format."""
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+    raw = _random_csr(np.random.RandomState(12), 20000, 9000, 30, 1000, 6000)
+    info = _oracle_vs_gpu(raw)
+    assert info['fused'] == 1 and info['value_bytes'] == 8
+    eng = _lib.Engine(0)
+    eng.set_option('value_format', 2)
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), raw.shape[1], score_lut(int(raw.data.max())))
+    with pytest.raises(_lib.EngineError):
+        TelescopeLikelihood.from_engine(eng, Opts(max_iter=2, em_epsilon=0.0))
+
+
+@pytest.mark.parametrize('hot_split', [1, 0])
+def test_hot_column_gets_several_accumulator_slots(gpu_device, hot_split):
+    """A column present in 80 % of the rows is split over several LDS accumulator slots (or not, with
+    the option off); the column sums are the same either way."""
+    raw = _random_csr(np.random.RandomState(13), 50000, 16000, 24, 139, 300, hot_frac=0.8)
+    info = _oracle_vs_gpu(raw, options=(('hot_split', hot_split),))
+    assert info['fused'] == 1 and info['P'] == 3
+    assert (info['hot_cols'] >= 1) == bool(hot_split)
+
+
+def test_rows_longer_than_a_wave_of_quads(gpu_device):
+    """Rows with hundreds of entries in one column part: the row-sum carry runs across many lanes
+    (and across wave boundaries) of the fused kernel's phase 1."""
+    rng = np.random.RandomState(14)
+    n, k = 6000, 7000                                    # one column part: every row's entries stay together
+    lens = np.where(rng.rand(n) < 0.05, rng.randint(300, 900, n), rng.randint(2, 12, n))
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.randint(139, 300, indptr[-1]).astype(np.uint16)
+    raw = sp.csr_matrix((data, indices, indptr), shape=(n, k))
+    for fmt in (1, 2):
+        info = _oracle_vs_gpu(raw, options=(('value_format', fmt),))
+        assert info['fused'] == 1 and info['P'] == 1
+
+
 def test_fused_and_twopass_agree_at_scale(gpu_device):
     """5M x 30k x 40: the two EM kernels give the same parameters (summation order aside)."""
     res = []

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Turn the CSVs written by tools/profile.sh into the text summaries kept under profiles/.
+
+    python tools/profile_summary.py gpurun_out/prof/<tag> <round-prefix>      e.g. ... r01b r01
+
+Writes profiles/<prefix>_fused_kernel_stats.txt, profiles/<prefix>_pmc_hbm_traffic_fused.txt and
+profiles/pmc_traffic.json (HBM bytes per launch of the EM kernel, per entry format; FETCH_SIZE is
+doubled on gfx950 as /opt/skills/guides/MI355X_MICROARCH.md prescribes for wide streaming reads).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    return name.split('(')[0].replace('void ', '')
+
+
+def kernel_table(path):
+    agg = defaultdict(list)
+    meta = {}
+    for r in csv.DictReader(open(path)):
+        k = short(r['Kernel_Name'])
+        agg[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        meta[k] = (int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), r['Workgroup_Size_X'], r['LDS_Block_Size'],
+                   int(r['VGPR_Count']) + int(r['Accum_VGPR_Count']), r['SGPR_Count'])
+    tot = sum(sum(v) for v in agg.values())
+    lines = ['%-40s %6s %12s %12s %12s %12s %6s  %7s %5s %7s %4s %4s' % (
+        'kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct', 'grid', 'wg', 'lds_B', 'vgpr', 'sgpr')]
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        g, wx, lds, vg, sg = meta[k]
+        lines.append('%-40s %6d %12.1f %12.1f %12.1f %12.1f %6.2f  %7d %5s %7s %4d %4s' % (
+            k[:40], len(v), sum(v) / 1e3, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3, 100.0 * sum(v) / tot,
+            g, wx, lds, vg, sg))
+    return lines, {k: sum(v) / len(v) / 1e3 for k, v in agg.items()}
+
+
+def pmc_table(path, counter):
+    agg = defaultdict(list)
+    dur = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = short(r['Kernel_Name'])
+        agg[k].append(float(r['Counter_Value']))
+        dur[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    lines = ['%-40s %4s %16s %12s' % ('kernel', 'n', 'avg_' + counter + '(KB)', 'avg_dur_us')]
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:8]:
+        lines.append('%-40s %4d %16.5g %12.1f' % (k[:40], len(v), sum(v) / len(v), sum(dur[k]) / len(dur[k]) / 1e3))
+    return lines, {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    src, prefix = sys.argv[1], sys.argv[2]
+    one = lambda pat: sorted(glob.glob(os.path.join(src, pat)))[0]
+    bench = json.load(open(os.path.join(src, 'bench.json')))
+    cmd = 'python bench.py --steps 6 --warmup 2 --no-cpu-baseline'
+    kl, avg = kernel_table(one('trace/*/*_kernel_trace.csv'))
+    with open(os.path.join(ROOT, 'profiles', prefix + '_fused_kernel_stats.txt'), 'w') as f:
+        f.write('# rocprofv3 --kernel-trace --stats -- %s   (default workload; the run times the default code16\n'
+                '# layout k_em_fused<4, 0, 1> and then the fp64 layout k_em_fused<4, 0, 0>)\n' % cmd)
+        f.write('\n'.join(kl) + '\n')
+    fl, fetch = pmc_table(one('fetch/*/*_counter_collection.csv'), 'FETCH_SIZE')
+    wl, write = pmc_table(one('write/*/*_counter_collection.csv'), 'WRITE_SIZE')
+    runs = []
+    notes = []
+    for fmt, vb, key in ((1, 2, 'roofline'), (0, 8, None)):
+        name = 'k_em_fused<4, 0, %d>' % fmt
+        if name not in fetch:
+            continue
+        rd = 2.0 * fetch[name] * 1024.0
+        wr = write.get(name, 0.0) * 1024.0
+        algo = (bench['roofline'] if vb == 2 else bench['f64_layout']['roofline'])['algo_bytes_per_launch']
+        cfg = bench['config']
+        runs.append({'workload': {'rows': cfg['rows'], 'cols': cfg['cols'], 'nnz_row': 40.0, 'dist': cfg['dist'],
+                                  'n_gpus': 1, 'value_bytes': vb, 'kernel': name},
+                     'traffic_bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr,
+                     'algorithmic_bytes': algo})
+        notes.append('# %s: read = 2 * %.5g KB * 1024 = %.4g B ; write = %.4g B ; algorithmic = %d B ; traffic / algorithmic = %.3f'
+                     % (name, fetch[name], rd, wr, algo, (rd + wr) / algo))
+    with open(os.path.join(ROOT, 'profiles', prefix + '_pmc_hbm_traffic_fused.txt'), 'w') as f:
+        f.write('## rocprofv3 --pmc FETCH_SIZE --kernel-trace -- %s\n' % cmd + '\n'.join(fl) + '\n\n')
+        f.write('## rocprofv3 --pmc WRITE_SIZE --kernel-trace -- %s\n' % cmd + '\n'.join(wl) + '\n\n')
+        f.write('# per EM pass; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced streaming read)\n')
+        f.write('\n'.join(notes) + '\n')
+    json.dump({'runs': runs,
+               'source': 'profiles/%s_pmc_hbm_traffic_fused.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; '
+                         'FETCH_SIZE x2 gfx950 correction)' % prefix},
+              open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
+    print('\n'.join(kl[:8]))
+    print('\n'.join(notes))
+
+
+if __name__ == '__main__':
+    main()
