@@ -509,20 +509,35 @@ __global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ a,
   if (threadIdx.x == 0) out[0] = t;
 }
 
-// red[col] = sum_g partial[g][pc]   (fixed order -> deterministic given partials)
-__global__ void k_colreduce(int Kpad, int G, const double* __restrict__ partial, const int32_t* __restrict__ col_of_pc,
-                            const uint32_t* __restrict__ colmap, double* __restrict__ red, int K) {
-  int pc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pc == 0) { red[K] = 0.0; red[K + 1] = 0.0; }
-  if (pc >= Kpad) return;
-  int col = col_of_pc[pc];
-  if (col < 0) return;                                   // padding, or a secondary slot of a split column
-  const int copies = 1 << ((colmap[col] >> 13) & 7u);
+// red[col] = sum_g partial[g][pc]   (fixed order -> deterministic given partials).  A block handles 64
+// slots x 4 interleaved slices of the team axis, so the strided reads of one slot overlap instead of
+// forming a chain of G dependent loads.  `sync` (fused kernel): only the teams that formed wrote
+// their slice — G = sum over XCDs of floor(tickets / P).
+__global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double* __restrict__ partial,
+                            const int32_t* __restrict__ col_of_pc, const uint32_t* __restrict__ colmap,
+                            double* __restrict__ red, int K, const uint32_t* __restrict__ sync, int P) {
+  __shared__ double part[4][64];
+  if (sync) {
+    int t = 0;
+    for (int x = 0; x < 8; ++x) t += (int)(sync[x] / (uint32_t)P);
+    G = min(G, t);
+  }
+  const int pcl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int pc = blockIdx.x * 64 + pcl;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { red[K] = 0.0; red[K + 1] = 0.0; }
+  const int col = pc < Kpad ? col_of_pc[pc] : -1;        // -1: padding, or a secondary slot of a split column
   double s = 0.0;
-  for (int g = 0; g < G; ++g)
-    for (int c = 0; c < copies; ++c) s += partial[(int64_t)g * Kpad + pc + c];
-  red[col] = s;
+  if (col >= 0) {
+    const int copies = 1 << ((colmap[col] >> 13) & 7u);
+    for (int g = slice; g < G; g += 4)
+      for (int c = 0; c < copies; ++c) s += partial[(int64_t)g * Kpad + pc + c];
+  }
+  part[slice][pcl] = s;
+  __syncthreads();
+  if (slice == 0 && col >= 0) red[col] = (part[0][pcl] + part[1][pcl]) + (part[2][pcl] + part[3][pcl]);
 }
+
+__global__ void k_keep_err(const uint32_t* sync, uint32_t* errlog) { errlog[0] |= sync[9]; errlog[1] = sync[10]; }
 
 // M-step closed forms (model.py:733-740) + per-block partials of diff_est (model.py:781)
 __global__ __launch_bounds__(256) void k_update(int K, const double* __restrict__ red,
@@ -530,8 +545,21 @@ __global__ __launch_bounds__(256) void k_update(int K, const double* __restrict_
     double* __restrict__ pi, double* __restrict__ theta, double* __restrict__ pi_prev,
     double* __restrict__ theta_prev, const uint32_t* __restrict__ colmap, int Kp,
     double* __restrict__ ctab, double* __restrict__ ctab_prev, const int32_t* __restrict__ twin_rep,
-    double* __restrict__ diff_out) {
+    double* __restrict__ diff_part, double* __restrict__ diff_out, uint32_t* __restrict__ done,
+    uint32_t* __restrict__ fz_sync, uint32_t* __restrict__ fz_errlog, unsigned long long* __restrict__ fz_xchg, int64_t fz_xchg_n) {
   __shared__ double scratch[16];
+  __shared__ bool last;
+  // the fused kernel's sync words and exchange ring must be zero at its next launch: do it here (this
+  // kernel runs once per EM pass, after the pass) instead of three memsets in front of every launch
+  if (fz_sync) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < fz_xchg_n; i += (int64_t)gridDim.x * blockDim.x)
+      fz_xchg[i] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x < 16) {            // FZ_SYNC_WORDS
+      if (threadIdx.x == 9) atomicOr(&fz_errlog[0], fz_sync[9]);          // keep the error word / miss counter for the host
+      if (threadIdx.x == 10) fz_errlog[1] = fz_sync[10];
+      fz_sync[threadIdx.x] = 0u;
+    }
+  }
   double d = 0.0;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K; j += gridDim.x * blockDim.x) {
     // exact twin columns share one accumulation (see k_colsig) as long as their
@@ -555,7 +583,19 @@ __global__ __launch_bounds__(256) void k_update(int K, const double* __restrict_
     for (int c = 0; c < copies; ++c) { ctab_prev[pc + c] = cold; ctab[pc + c] = cnew; }
   }
   double t = block_sum(d, scratch);
-  if (threadIdx.x == 0) diff_out[blockIdx.x] = t;
+  if (threadIdx.x == 0) {
+    diff_part[blockIdx.x] = t;
+    __threadfence();
+    last = atomicAdd(done, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last) {                                              // fixed order -> deterministic
+    __threadfence();
+    double v = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) v += __hip_atomic_load(&diff_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double tt = block_sum(v, scratch);
+    if (threadIdx.x == 0) { *diff_out = tt; *done = 0u; }
+  }
 }
 
 __global__ void k_make_ctab(int K, const double* __restrict__ pi, const double* __restrict__ theta,
@@ -579,6 +619,7 @@ __global__ void k_fill(double* p, int64_t n, double v) {
 }
 
 #include "tsem_fused.h"
+static_assert(FZ_SYNC_WORDS == 16, "k_update clears 16 sync words");
 
 // ============================================================================
 // CSR row passes: z export, best-hit counts, reassign (model.py:808-865)
@@ -857,7 +898,7 @@ static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
 
 static void free_layout(tsem_ctx* h) {
   dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_pcode); dfree(h->d_prc);
-  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fpartial); dfree(h->d_amb_w); dfree(h->d_sb_q32);
+  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fz_aux); h->fz_clean = false; dfree(h->d_fpartial); dfree(h->d_amb_w); dfree(h->d_sb_q32);
   h->fused_launched = false;
 }
 static void free_matrix(tsem_ctx* h) {
@@ -1524,11 +1565,14 @@ static int begin_timing(tsem_ctx* h, hipEvent_t** pair) {
 // One launch of the persistent fused kernel.  mode 0: EM pass (column sums of w*z into d_fpartial);
 // mode 1: log-likelihood of the ambiguous rows (one partial per workgroup into d_lnl_part).
 static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
-  const size_t sync_bytes = sizeof(uint32_t) * FZ_SYNC_WORDS;
-  TSEM_HIP(hipMemsetAsync(h->d_xflags, 0, sync_bytes, h->stream));
-  if (mode == 0) TSEM_HIP(hipMemsetAsync(h->d_fpartial, 0, sizeof(double) * (size_t)h->fz_teams * h->Kpad, h->stream));
-  else TSEM_HIP(hipMemsetAsync(h->d_lnl_part, 0, sizeof(double) * (size_t)h->fz_grid, h->stream));   // teams that do not form write nothing
-  if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * FZ_XS * h->P * h->R, h->stream));
+  if (!h->fz_clean) {                                      // (k_update leaves them zero after every EM pass)
+    if (h->fused_launched && h->d_fz_aux)                  // keep the error word of a launch nobody cleaned up after
+      k_keep_err<<<1, 1, 0, h->stream>>>(h->d_xflags, h->d_fz_aux + 2);
+    TSEM_HIP(hipMemsetAsync(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS, h->stream));
+    if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * FZ_XS * h->P * h->R, h->stream));
+  }
+  h->fz_clean = false;
+  if (mode == 1) TSEM_HIP(hipMemsetAsync(h->d_lnl_part, 0, sizeof(double) * (size_t)h->fz_grid, h->stream));   // teams that do not form write nothing
   FusedArgs A;
   A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
   A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc;
@@ -1571,9 +1615,11 @@ int tsem_em_pass(tsem_ctx* h) {
   if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
   h->em_launches += 1;
   if (fused_done) {
-    k_colreduce<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K);
+    k_colreduce<<<cdiv64(h->Kpad, 64), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                            h->d_xflags, h->P);
   } else if (h->nb > 0) {
-    k_colreduce<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K);
+    k_colreduce<<<cdiv64(h->Kpad, 64), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                            nullptr, h->P);
   } else {
     TSEM_HIP(hipMemsetAsync(h->d_red, 0, sizeof(double) * (h->K + 2), h->stream));
   }
@@ -1586,21 +1632,30 @@ static int launch_update(tsem_ctx* h, double* d_diff_slot) {
   const double tden = h->W_amb + tpw * h->K, pden = h->W_tot + ppw * h->K;      // model.py:732,738
   const int nblk = std::min(1024, cdiv64(h->K, 256));
   double* part = h->d_lnl_part + 10000;   // scratch for the per-block |pi_hat - pi| partials
+  if (!h->d_fz_aux) {
+    TSEM_ALLOC(h->d_fz_aux, 4);
+    TSEM_HIP(hipMemsetAsync(h->d_fz_aux, 0, sizeof(uint32_t) * 4, h->stream));
+  }
+  const bool clean = h->use_fused && h->d_xflags && h->fused_launched;
   k_update<<<nblk, 256, 0, h->stream>>>(h->K, h->d_red, h->d_pisum0, tpw, tden, ppw, pden, h->d_pi, h->d_theta,
                                         h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab, h->d_ctab_prev,
-                                        h->d_twin_rep, part);
-  k_sum_parts<<<1, 256, 0, h->stream>>>(part, nblk, part, 0, d_diff_slot);   // fixed order -> deterministic
+                                        h->d_twin_rep, part, d_diff_slot, h->d_fz_aux,
+                                        clean ? h->d_xflags : nullptr, h->d_fz_aux + 2,
+                                        reinterpret_cast<unsigned long long*>(h->d_xchg),
+                                        h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
   TSEM_HIP(hipGetLastError());
+  if (clean) h->fz_clean = true;
   return TSEM_OK;
 }
 
 static int check_fused_error(tsem_ctx* h) {
   if (!h->use_fused || !h->d_xflags || !h->fused_launched) return TSEM_OK;
-  uint32_t ee[2] = {0, 0};
+  uint32_t ee[2] = {0, 0}, kept[2] = {0, 0};
   TSEM_HIP(hipMemcpyAsync(ee, h->d_xflags + 9, 8, hipMemcpyDeviceToHost, h->stream));
+  if (h->d_fz_aux) TSEM_HIP(hipMemcpyAsync(kept, h->d_fz_aux + 2, 8, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  const uint32_t e = ee[0];
-  h->last_slow_path = ee[1];
+  const uint32_t e = ee[0] | kept[0];                     // live words, or what k_update saved before zeroing them
+  h->last_slow_path = h->fz_clean ? kept[1] : ee[1];
   if (e) TSEM_FAIL(TSEM_ERR_TIMEOUT, "fused EM kernel: hand-off watchdog fired (code " + std::to_string(e) +
                    "): a team member was not co-resident or a flag never arrived");
   return TSEM_OK;

@@ -128,6 +128,8 @@ struct tsem_ctx {
   // ---- fused-kernel exchange state ----
   double* d_xchg = nullptr;
   uint32_t* d_xflags = nullptr;
+  uint32_t* d_fz_aux = nullptr;     // [0] k_update's block counter, [2..3] error word / miss counter saved by its cleanup
+  bool fz_clean = false;            // sync words and exchange ring are zero (k_update cleaned them after the last pass)
   uint32_t* d_xerr = nullptr;
 
   // ---- instrumentation ----
