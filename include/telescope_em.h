@@ -150,6 +150,11 @@ int  tsem_best_counts(tsem_ctx* h, int which, int32_t* nbest /* n_rows */);
  * NULL to skip).  `picks[i]` (choose only) = ordinal of the chosen best hit. */
 int  tsem_reassign(tsem_ctx* h, int method, double thresh, int which,
                    const int32_t* picks, double* colsums, double* mask);
+/* the same assignment summed per GROUP of rows: scTelescope.output_report's per-barcode count matrix
+ * `_assignments[_rows, :].sum(0)` for every barcode (model.py:611-625).  group_of_row[i] in
+ * [0, n_groups) or -1 (row in no group); out is row-major [n_groups][K], caller-allocated. */
+int  tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks,
+                          const int32_t* group_of_row, int32_t n_groups, double* out);
 
 /* ---- csr_matrix_plus primitives on arbitrary fp64 CSR (sparse_plus.py) ---- */
 int  tsem_csr_norm_rows(int device, int64_t n_rows, const int64_t* indptr,

@@ -107,6 +107,7 @@ def lib():
     L.tsem_calc_lnl.argtypes = [vp, vp, vp, vp, C.POINTER(dbl)]
     L.tsem_best_counts.argtypes = [vp, C.c_int, vp]
     L.tsem_reassign.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, vp]
+    L.tsem_reassign_groups.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, C.c_int32, vp]
     L.tsem_csr_norm_rows.argtypes = [C.c_int, i64, vp, vp, vp]
     L.tsem_csr_binmax_rows.argtypes = [C.c_int, i64, i32, vp, vp, vp]
     L.tsem_csr_scale.argtypes = [C.c_int, C.c_int, i64, i32, vp, vp, vp]
@@ -313,6 +314,18 @@ class Engine(object):
         self._ck(self._L.tsem_reassign(self._h, RA_CODE[method], float(thresh), which, ptr(picks), ptr(cs),
                                        ptr(mask)))
         return cs, mask
+
+    def reassign_groups(self, method, thresh, which, group_of_row, n_groups, picks=None):
+        n, k, _ = self.dims()
+        grp = np.ascontiguousarray(group_of_row, dtype=np.int32)
+        if grp.shape != (n,):
+            raise ValueError('group_of_row must have one entry per row')
+        out = np.zeros((int(n_groups), k))
+        if picks is not None:
+            picks = np.ascontiguousarray(picks, dtype=np.int32)
+        self._ck(self._L.tsem_reassign_groups(self._h, RA_CODE[method], float(thresh), which, ptr(picks), ptr(grp),
+                                              int(n_groups), ptr(out)))
+        return out
 
     # -- instrumentation --
     def kernel_stats(self, reset=False):

@@ -642,6 +642,7 @@ struct RowPassArgs {
   double* zout;          // EXPORT_Z / mask
   int32_t* nbest;
   double* colsums;
+  const int32_t* group;  // REASSIGN: optional row -> group map; colsums is then [n_groups][K]
 };
 
 template <int MODE>
@@ -704,6 +705,7 @@ __global__ __launch_bounds__(256) void k_rowpass(RowPassArgs A) {
       vsum = sg_sum<RP_SUB>(vsum);
     }
     const int pick = (A.method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[row] : 0;
+    const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
     int base = 0;
     for (int64_t k0 = s; k0 < e; k0 += RP_SUB) {
       int64_t k = k0 + lane;
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(256) void k_rowpass(RowPassArgs A) {
       }
       if (valid) {
         if (A.zout) A.zout[k] = val;
-        if (val != 0.0) unsafeAtomicAdd(&A.colsums[A.indices[k]], val);
+        if (val != 0.0 && grp_off >= 0) unsafeAtomicAdd(&A.colsums[grp_off + A.indices[k]], val);
       }
     }
   }
@@ -1761,7 +1763,7 @@ int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likel
 // ---------------------------------------------------------------------------
 static int rowpass_args(tsem_ctx* h, int which, RowPassArgs& A) {
   A.N = h->N; A.K = h->K; A.indptr = h->d_indptr; A.indices = h->d_indices; A.raw = h->d_raw; A.lut = h->d_lut;
-  A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr;
+  A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr; A.group = nullptr;
   if (which == TSEM_Z_INITIAL) { A.pi = nullptr; A.theta = nullptr; }
   else if (which == TSEM_Z_PREV) { A.pi = h->d_pi_prev; A.theta = h->d_theta_prev; }
   else if (which == TSEM_Z_CUR) { A.pi = h->d_pi; A.theta = h->d_theta; }
@@ -1843,6 +1845,37 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
   TSEM_HIP(hipStreamSynchronize(h->stream));
   (void)hipFree(d_cs);
   if (d_mask) (void)hipFree(d_mask);
+  if (d_picks) (void)hipFree(d_picks);
+  return TSEM_OK;
+}
+
+int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks,
+                         const int32_t* group_of_row, int32_t n_groups, double* out) {
+  if (!h || !h->d_indptr || !group_of_row || !out || n_groups < 0) return TSEM_ERR_ARG;
+  if (method < TSEM_RA_EXCLUDE || method > TSEM_RA_ALL) TSEM_FAIL(TSEM_ERR_ARG, "bad reassign method");
+  if (int rc = ensure_device(h)) return rc;
+  for (int64_t i = 0; i < h->N; ++i)
+    if (group_of_row[i] >= n_groups) TSEM_FAIL(TSEM_ERR_ARG, "group_of_row entry out of range");
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  A.method = method; A.thresh = thresh;
+  const int64_t n_out = (int64_t)n_groups * h->K;
+  double* d_out = nullptr;
+  int32_t *d_picks = nullptr, *d_grp = nullptr;
+  TSEM_ALLOC(d_out, n_out);
+  TSEM_ALLOC(d_grp, h->N);
+  TSEM_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * std::max<int64_t>(1, n_out), h->stream));
+  if (h->N) TSEM_HIP(hipMemcpyAsync(d_grp, group_of_row, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+  if (method == TSEM_RA_CHOOSE && picks) {
+    TSEM_ALLOC(d_picks, h->N);
+    if (h->N) TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+  }
+  A.colsums = d_out; A.picks = d_picks; A.group = d_grp;
+  if (h->N && n_out) k_rowpass<RP_REASSIGN><<<rowpass_grid(h), 256, 0, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  if (n_out) TSEM_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_out); (void)hipFree(d_grp);
   if (d_picks) (void)hipFree(d_picks);
   return TSEM_OK;
 }

@@ -306,6 +306,44 @@ class TelescopeLikelihood(object):
             cs = np.rint(cs).astype(np.int64)
         return cs
 
+    def reassign_group_sums(self, method, group_rows, thresh=0.9, initial=False):
+        """Per-group column sums of the assignment matrix: row g of the result is
+        `reassign(method, thresh, initial)[group_rows[g], :].sum(0).A1` — the per-barcode count matrix
+        of `scTelescope.output_report` (model.py:611-625) for `group_rows = barcode_read_indices
+        .values()` — computed in one device pass, without materialising the N x K assignment.
+        A row listed in several groups (or twice in one) counts once per listing, like fancy
+        indexing does.  Row-sharded runs pass the indices local to this rank's rows; the sums are
+        all-reduced."""
+        if method not in REASSIGN_METHODS:
+            raise ValueError('Argument "method" should be one of (exclude, choose, average, conf, unique, all)')
+        which = self._which(initial)
+        picks = self._picks(which) if method == 'choose' else None
+        groups = [np.asarray(list(g), dtype=np.int64) for g in group_rows]
+        out = np.zeros((len(groups), self.K))
+        lo = 0
+        # one pass per "layer": every row belongs to at most one group within a layer
+        pending = [(gi, g - lo) for gi, g in enumerate(groups)]
+        pending = [(gi, g[(g >= 0) & (g < self.N)]) for gi, g in pending]
+        while any(len(g) for _, g in pending):
+            grp = np.full(self.N, -1, np.int32)
+            rest = []
+            for gi, g in pending:
+                if not len(g):
+                    rest.append((gi, g))
+                    continue
+                free = grp[g] < 0
+                first = np.zeros(len(g), bool)
+                first[np.unique(g, return_index=True)[1]] = True   # one listing per row and layer
+                take = free & first
+                grp[g[take]] = gi
+                rest.append((gi, g[~take]))
+            out += self._eng.reassign_groups(method, thresh, which, grp, len(groups), picks)
+            pending = rest
+        out = self.comm.sum_array(out.ravel()).reshape(out.shape)
+        if _MASK_DTYPE[method] != np.float64:
+            out = np.rint(out).astype(np.int64)
+        return out
+
     def reassign(self, method, thresh=0.9, initial=False):
         """model.py:808-865 — returns the assignment matrix as a scipy CSR."""
         if method not in REASSIGN_METHODS:

@@ -328,6 +328,27 @@ def test_ragged_rows_and_kernel_variants(gpu_device):
     assert b['fused'] == 0 and a['P'] == b['P'] == 2
 
 
+@pytest.mark.parametrize('method', ['conf', 'all', 'unique', 'exclude', 'choose', 'average'])
+def test_per_barcode_count_matrix(gpu_device, method):
+    """scTelescope.output_report (model.py:611-625): `_assignments[_rows, :].sum(0).A1` per barcode —
+    the segmented device pass against fancy indexing on the assignment matrix."""
+    c, raw, tl, _ = run_case('bundled')
+    rng = np.random.RandomState(3)
+    bc = rng.randint(0, 9, tl.N)                         # barcode 8 = reads without a barcode
+    groups = [np.flatnonzero(bc == g) for g in range(8)]
+    groups[2] = np.concatenate([groups[2], groups[5][:40], groups[2][:3]])   # shared and repeated rows
+    groups.append(np.zeros(0, np.int64))                 # an empty barcode
+    np.random.seed(int(c['seed']))
+    got = tl.reassign_group_sums(method, groups, 0.9)
+    np.random.seed(int(c['seed']))
+    mat = tl.reassign(method, 0.9)
+    want = np.vstack([np.asarray(mat[g, :].sum(0)).ravel() for g in groups])
+    if method in ('conf', 'average'):
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    else:
+        assert np.array_equal(got, want)
+
+
 def _random_csr(rng, n, k, max_len, lo, hi, hot_frac=0.0):
     lens = rng.randint(2, max_len, n)
     indptr = np.concatenate([[0], np.cumsum(lens)])
