@@ -114,6 +114,7 @@ def lib():
     L.tsem_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
     L.tsem_layout_info.argtypes = [vp, vp]
     L.tsem_debug_fused_prof.argtypes = [vp, vp]
+    L.tsem_debug_log1p.argtypes = [C.c_int, C.c_int32, vp, vp]
     for name in exported_symbols():
         fn = getattr(L, name)
         if name not in ('tsem_destroy', 'tsem_last_error'):
@@ -343,6 +344,15 @@ class Engine(object):
         self._ck(self._L.tsem_layout_info(self._h, ptr(info)))
         return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad', 'twin_cols',
                          'G1', 'G2', 'fused', 'slow_path', 'max_subblock', 'value_bytes', 'hot_cols'), info.tolist()))
+
+
+def debug_log1p(x, device=0):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    rc = lib().tsem_debug_log1p(device, len(x), ptr(x), ptr(y))
+    if rc != OK:
+        raise EngineError('tsem_debug_log1p failed (%d)' % rc)
+    return y
 
 
 def csr_norm_rows(indptr, data, device=0):

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       if (lnl) {                                          // z = (Q c_prev) * recip0(rowsum);  acc[] holds c_cur
         auto term = [&](double q, uint32_t rc) {
           const double z = (q * c[rc & 0xFFFF]) * sb[rc >> 16];
-          if (z != 0.0) lsum += z * log1p(q * acc[rc & 0xFFFF]);
+          if (z != 0.0) lsum += z * ts_log1p_pos(q * acc[rc & 0xFFFF]);
         };
         term(rr.v0.x, rr.rc.x); term(rr.v0.y, rr.rc.y); term(rr.v1.x, rr.rc.z); term(rr.v1.y, rr.rc.w);
         return;

@@ -349,6 +349,19 @@ def test_per_barcode_count_matrix(gpu_device, method):
         assert np.array_equal(got, want)
 
 
+def test_device_log1p_matches_libm(gpu_device):
+    """The lnl passes' log1p (finite x >= 0) against numpy's: <= 2 ulp over 1e-320 .. 1e300."""
+    from telescope_amd import _lib
+    rng = np.random.RandomState(1)
+    x = np.concatenate([10.0 ** rng.uniform(-320, 300, 200000), 10.0 ** rng.uniform(-3, 3, 200000),
+                        rng.uniform(0, 3, 100000), [0.0, 5e-324, 2.0 ** -28, 2.0 ** -28 * (1 - 1e-16), 1.0, 2.0 ** 0.5 - 1,
+                                                    2.0 ** 53, 1e43, 1.7e308]])
+    y = _lib.debug_log1p(x)
+    ref = np.log1p(x)
+    err = np.abs(y - ref) / np.maximum(np.spacing(ref), 5e-324)
+    assert np.all(np.isfinite(y)) and err.max() <= 2.0, (err.max(), x[err.argmax()])
+
+
 def _random_csr(rng, n, k, max_len, lo, hi, hot_frac=0.0):
     lens = rng.randint(2, max_len, n)
     indptr = np.concatenate([[0], np.cumsum(lens)])
