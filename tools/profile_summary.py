@@ -62,8 +62,8 @@ def main():
     cmd = 'python bench.py --steps 6 --warmup 2 --no-cpu-baseline'
     kl, avg = kernel_table(one('trace/*/*_kernel_trace.csv'))
     with open(os.path.join(ROOT, 'profiles', prefix + '_fused_kernel_stats.txt'), 'w') as f:
-        f.write('# rocprofv3 --kernel-trace --stats -- %s   (default workload; the run times the default code16\n'
-                '# layout k_em_fused<4, 0, 1> and then the fp64 layout k_em_fused<4, 0, 0>)\n' % cmd)
+        f.write('# rocprofv3 --kernel-trace --stats -- %s   (default workload; the run times the headline fp64\n'
+                '# layout k_em_fused<4, 0, 0> and then the 2-byte-code layout k_em_fused<4, 0, 1>)\n' % cmd)
         f.write('\n'.join(kl) + '\n')
     fl, fetch = pmc_table(one('fetch/*/*_counter_collection.csv'), 'FETCH_SIZE')
     wl, write = pmc_table(one('write/*/*_counter_collection.csv'), 'WRITE_SIZE')
@@ -75,7 +75,7 @@ def main():
             continue
         rd = 2.0 * fetch[name] * 1024.0
         wr = write.get(name, 0.0) * 1024.0
-        algo = (bench['roofline'] if vb == 2 else bench['f64_layout']['roofline'])['algo_bytes_per_launch']
+        algo = (bench['roofline'] if vb == 8 else bench['code16_layout']['roofline'])['algo_bytes_per_launch']
         cfg = bench['config']
         runs.append({'workload': {'rows': cfg['rows'], 'cols': cfg['cols'], 'nnz_row': 40.0, 'dist': cfg['dist'],
                                   'n_gpus': 1, 'value_bytes': vb, 'kernel': name},
