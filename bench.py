@@ -57,10 +57,7 @@ def parse():
                          '`auto` choice, timed beside the headline as `code16_layout`)')
     ap.add_argument('--block-rows', type=int, default=0)
     ap.add_argument('--chunk-blocks', type=int, default=0)
-    ap.add_argument('--xcd-local', type=int, default=1)
-    ap.add_argument('--poll-delay', type=int, default=-1)
     ap.add_argument('--fused-dbg', type=int, default=0)
-    ap.add_argument('--fill-pct', type=int, default=0)
     ap.add_argument('--hot-split', type=int, default=1, help='0: one accumulator slot per column (experiments)')
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
     ap.add_argument('--cpu-iters', type=int, default=2)
@@ -133,14 +130,9 @@ def main():
         eng.set_option('block_rows', args.block_rows)
     if args.chunk_blocks:
         eng.set_option('chunk_blocks', args.chunk_blocks)
-    eng.set_option('xcd_local', args.xcd_local)
     if args.fused_dbg:
         eng.set_option('fused_dbg', args.fused_dbg)
-    if args.fill_pct:
-        eng.set_option('fill_pct', args.fill_pct)
     eng.set_option('hot_split', args.hot_split)
-    if args.poll_delay >= 0:
-        eng.set_option('poll_delay', args.poll_delay)
     t_setup = time.perf_counter()
     eng.generate(r0, r1, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
     tl = TelescopeLikelihood.from_engine(eng, Opts(args.steps), comm)

@@ -61,6 +61,13 @@ int  tsem_create(tsem_ctx** out, int device);
 void tsem_destroy(tsem_ctx* h);
 const char* tsem_last_error(const tsem_ctx* h);      /* h may be NULL: last create error */
 int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream_t (default: null stream) */
+/* options, set before tsem_rowstats (the layout is built from them):
+ *   "em_kernel"    TSEM_EMK_*                      "block_rows", "parts"  override the layout geometry
+ *   "value_format" 0 auto (2-byte score codes + LDS score table when the fused kernel runs and the table
+ *                  has <= 2048 entries), 1 fp64 Q values, 2 codes (error if not possible)
+ *   "hot_split"    1 (default): very popular columns get several accumulator slots
+ *   "row_offset"   global index of this rank's first row (synthetic generator, column signatures)
+ *   "fused_dbg", "fused_prof", "chunk_blocks"     timing experiments */
 int  tsem_set_option(tsem_ctx* h, const char* key, int64_t value);
 int  tsem_synchronize(tsem_ctx* h);
 

@@ -1004,9 +1004,6 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "parts") h->opt_P = v;
   else if (k == "row_offset") h->row_offset = v;
   else if (k == "chunk_blocks") h->opt_chunk = v;
-  else if (k == "xcd_local") h->opt_xcd_local = v;
-  else if (k == "poll_delay") h->opt_poll_delay = v;
-  else if (k == "fill_pct") h->fill_target = v / 100.0;
   else if (k == "fused_dbg") h->opt_dbg = v;
   else if (k == "value_format") h->opt_format = v;
   else if (k == "hot_split") h->opt_hot_split = v;
@@ -1612,8 +1609,8 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
   A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc;
   A.ctab = mode ? h->d_ctab_prev : h->d_ctab; A.ctab2 = h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = mode;
   A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg;
-  A.sync = h->d_xflags; A.xcd_local = h->opt_xcd_local ? 1 : 0;
-  A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.poll_delay = (int)h->opt_poll_delay; A.dbg = (int)h->opt_dbg;
+  A.sync = h->d_xflags;
+  A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.dbg = (int)h->opt_dbg;
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = h->fmt_code ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
   const size_t ldsf = fz_lds_bytes(h, h->fmt_code);
   if (mode && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");

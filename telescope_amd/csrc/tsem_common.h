@@ -104,11 +104,10 @@ struct tsem_ctx {
   double* d_partial = nullptr;      // [G2][Kpad]
   double* d_lnl_part = nullptr;     // [4096]
   int em_kernel = TSEM_EMK_AUTO;
-  int64_t opt_R = 0, opt_P = 0, opt_chunk = 0, opt_xcd_local = 1, opt_poll_delay = 0, opt_dbg = 0;
+  int64_t opt_R = 0, opt_P = 0, opt_chunk = 0, opt_dbg = 0;
   bool use_fused = false;
   int64_t max_subblock = 0;
   int64_t last_slow_path = 0;       // exchange granules that missed their tag in the last checked pass
-  double fill_target = 0.90;        // mean sub-block size / register tile
   int fz_grid = 0, fz_teams = 0;
   double* d_fpartial = nullptr;     // [fz_teams][Kpad]
   double* d_amb_w = nullptr;        // [N_amb_pad] fragment weights

@@ -81,8 +81,6 @@ struct FusedArgs {
   double* partial;      // [team slots][P*Kp], zero-filled before launch
   double* xchg;         // [team][FZ_XS][P][R] tagged granules, zero-filled before launch
   uint32_t* sync;       // zero-filled before launch
-  int xcd_local;        // 1: plain stores (stay in the XCD's L2); 0: write-through
-  int poll_delay;       // unused (kept for the option plumbing)
   int dbg;              // bit0: skip partner loads (timing experiments only; wrong results)
   unsigned long long* prof;   // optional per-step timestamps of team 0 / member 0
   int prof_blocks;
