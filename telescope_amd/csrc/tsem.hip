@@ -908,9 +908,11 @@ static int ensure_device(tsem_ctx* h) {
 
 typedef void (*fz_fn)(FusedArgs);
 template <int P> static fz_fn fz_pick(int mode, int fmt) {
-  if (fmt) return mode ? k_em_fused<P, 1, 1> : k_em_fused<P, 0, 1>;
+  if (fmt == 1) return mode ? k_em_fused<P, 1, 1> : k_em_fused<P, 0, 1>;
+  if (fmt == 2) return mode ? k_em_fused<P, 1, 2> : k_em_fused<P, 0, 2>;
   return mode ? k_em_fused<P, 1, 0> : k_em_fused<P, 0, 0>;
 }
+static int fz_fmt(const tsem_ctx* h) { return h->fmt_code ? 1 : (h->fmt_wcode ? 2 : 0); }
 static fz_fn fz_kernel(int P, int mode, int fmt) {
   switch (P) {
     case 1: return fz_pick<1>(mode, fmt); case 2: return fz_pick<2>(mode, fmt);
@@ -1410,6 +1412,8 @@ static int build_layout(tsem_ctx* h) {
   }
   if (h->use_fused && (R > fz_rmax(P) || (R & 1) || fz_lds_bytes(h, false) > (size_t)TS_LDS_MAX - 1024)) h->use_fused = false;
   h->fmt_code = h->use_fused && fz_wants_codes(h) && fz_lds_bytes(h, true) <= (size_t)TS_LDS_MAX - 1024;
+  h->fmt_wcode = h->use_fused && !h->fmt_code && h->lut_len > 0 && h->lut_len <= 2048 &&
+                 fz_lds_bytes(h, true) <= (size_t)TS_LDS_MAX - 1024;
   if (h->opt_format == 2 && !h->fmt_code)
     TSEM_FAIL(TSEM_ERR_ARG, "value_format=codes needs the fused kernel and a score table of at most 2048 entries");
   TSEM_ALLOC(h->d_prc, off);
@@ -1447,12 +1451,12 @@ static int build_layout(tsem_ctx* h) {
       TSEM_ALLOC(h->d_xchg, (int64_t)h->fz_teams * FZ_XS * P * R);
       TSEM_ALLOC(h->d_xflags, FZ_SYNC_WORDS);
       TSEM_HIP(hipMemset(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS));
-      if (!h->fmt_code) {                                  // fp64 row weights; the code format reads d_amb_wcode
+      if (!h->fmt_code && !h->fmt_wcode) {                 // fp64 row weights; otherwise the kernel reads d_amb_wcode
         TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
         k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
       }
       for (int mode = 0; mode < 2; ++mode)
-        TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, h->fmt_code ? 1 : 0),
+        TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h)),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
     }
   }
@@ -1611,10 +1615,10 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
   A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg;
   A.sync = h->d_xflags;
   A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.dbg = (int)h->opt_dbg;
-  A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = h->fmt_code ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
-  const size_t ldsf = fz_lds_bytes(h, h->fmt_code);
+  A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
+  const size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
   if (mode && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
-  fz_fn fn = fz_kernel(h->P, mode, h->fmt_code ? 1 : 0);
+  fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h));
   if (!fn) TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
   if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
   fn<<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A);

@@ -67,7 +67,9 @@ struct FusedArgs {
   int64_t nb, N_amb_pad;
   const int64_t* sb_off;
   const uint32_t* sb_q32;   // sb_off / 4 as 32-bit quad indices (fused kernel only)
-  const double* pval;       // FMT 0: Q values (fp64), 8 B per entry
+  // FMT 0: fp64 entries, fp64 row weights (score table too large for LDS)   FMT 1: 2-byte score codes
+  // FMT 2: fp64 entries, row weights as 2-byte codes (6 B less exchange traffic per row and member)
+  const double* pval;       // FMT 0/2: Q values (fp64), 8 B per entry
   const uint16_t* pcode;    // FMT 1: raw score codes, 2 B per entry; Q = lut[code] bit for bit (sparse_plus.py:89-91)
   const double* lut;        // FMT 1: the score table, copied to LDS [lut_len]
   int lut_len;
@@ -99,6 +101,11 @@ __device__ __forceinline__ uint32_t fz_ld_u32(const uint32_t* p) {
 typedef unsigned int fz_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int fz_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int FZ_RSRC_FLAGS = 0x00027000;
+#ifndef FZ_STREAM_POLICY
+#define FZ_STREAM_POLICY 2
+#endif
+constexpr int FZ_STREAM = FZ_STREAM_POLICY;              // cache policy of the entry loads: nt (read once) keeps the
+                                                         // exchange ring and the tables in L2 (fp64 entries: -3.6 %)
 constexpr unsigned FZ_OOB = 0x7FFFFF00u;                 // beyond num_records of every resource used here
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t fz_rsrc(const void* base, uint64_t byte_off, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(base) + byte_off), 0, (int)bytes,
@@ -215,7 +222,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     const bool kv = k >= 0 && k < nblk;
     const uint64_t blk = kv ? (uint64_t)(team + k * T) : 0;
     if (MODE == 0) {                                            // row weights (the lnl pass uses w = 1)
-      if (FMT == 1) {
+      if (FMT != 0) {
         __amdgpu_buffer_rsrc_t wr = fz_rsrc(A.wcode, blk * R * 2, kv ? (unsigned)R * 2 : 0);
 #pragma unroll
         for (int j = 0; j < FZ_RP; ++j)
@@ -282,7 +289,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
           ys1 += __longlong_as_double((long long)v.y);
         }
         double2 w = make_double2(1.0, 1.0);
-        if (MODE == 0) w = FMT == 1 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
+        if (MODE == 0) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
         // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730)
         *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(recip0(ys0) * w.x, recip0(ys1) * w.y);
         *reinterpret_cast<double2*>(&y[(k & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   };
   uint32_t* offs = reinterpret_cast<uint32_t*>(ibox + 16);   // [8][2] sub-block quad ranges (ring), LDS
   double* lutS = reinterpret_cast<double*>(ibox + 32);       // FMT 1: score table [lut_len]
-  if (FMT == 1)
+  if (FMT != 0)
     for (int t = tid; t < A.lut_len; t += FZ_NT) lutS[t] = A.lut[t];
   const int64_t nsteps = nblk + FZ_LAG + 1;               // last scatter is block nblk-1 at step nblk+3
   // prologue: offsets of blocks 0..3 straight into LDS
@@ -446,15 +453,15 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     auto load_blk = [&](FzRegs& rr, uint32_t oq0v, uint32_t oq1v, int64_t k) {
       const uint32_t oq0 = __builtin_amdgcn_readfirstlane(oq0v);
       const uint32_t nq = (k >= 0 && k < nblk) ? __builtin_amdgcn_readfirstlane(oq1v) - oq0 : 0u;
-      fz_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(fz_rsrc(A.prc, (uint64_t)oq0 * 16, nq * 16), (unsigned)tid * 16, 0, 0);
+      fz_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(fz_rsrc(A.prc, (uint64_t)oq0 * 16, nq * 16), (unsigned)tid * 16, 0, FZ_STREAM);
       rr.rc = make_uint4(t.x, t.y, t.z, t.w);
       if (FMT == 1) {
-        fz_u32x2 cd = __builtin_amdgcn_raw_buffer_load_b64(fz_rsrc(A.pcode, (uint64_t)oq0 * 8, nq * 8), (unsigned)tid * 8, 0, 0);
+        fz_u32x2 cd = __builtin_amdgcn_raw_buffer_load_b64(fz_rsrc(A.pcode, (uint64_t)oq0 * 8, nq * 8), (unsigned)tid * 8, 0, FZ_STREAM);
         rr.cd = make_uint2(cd.x, cd.y);
       } else {
         __amdgpu_buffer_rsrc_t vr = fz_rsrc(A.pval, (uint64_t)oq0 * 32, nq * 32);
-        rr.v0 = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(vr, (unsigned)tid * 32, 0, 0));
-        rr.v1 = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(vr, (unsigned)tid * 32 + 16, 0, 0));
+        rr.v0 = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(vr, (unsigned)tid * 32, 0, FZ_STREAM));
+        rr.v1 = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(vr, (unsigned)tid * 32 + 16, 0, FZ_STREAM));
       }
     };
     // phase 1: numerators n = Q * (pi*theta) kept in the registers, partial row sums into y(k).
