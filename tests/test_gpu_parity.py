@@ -311,6 +311,14 @@ def test_column_part_counts(gpu_device, cols, expect_parts):
     assert info['fused'] == 1
 
 
+def test_more_than_eight_column_parts_use_the_two_pass_kernels(gpu_device):
+    """K = 70 000 -> 10 column parts: beyond the fused kernel's team size, the two-pass form runs."""
+    from telescope_amd import synthetic
+    ip, ix, rw = synthetic.generate(30000, 70000, 30, seed=17, dist='zipf', uniq_frac=0.05)
+    info = _oracle_vs_gpu(sp.csr_matrix((rw, ix, ip), shape=(30000, 70000)))
+    assert info['P'] == 10 and info['fused'] == 0 and info['value_bytes'] == 8
+
+
 def test_ragged_rows_and_kernel_variants(gpu_device):
     """Very uneven row lengths (1 .. 3000 entries, a few rows longer than the register tile of a
     fused sub-block) — exercises the block-size retry / two-pass fallback — and both EM kernels on
