@@ -1225,6 +1225,17 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     // column parts (tables of one part must fit LDS) and rows per block
     int P = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP - 1) / TS_MAX_KP;
     if (P < 1) P = 1;
+    if (h->opt_P <= 0 && h->em_kernel != TSEM_EMK_TWOPASS && P < FZ_MAX_P && na > 0) {
+      // Teams never span XCDs, so floor(cpx / P) * P of an XCD's cpx CUs work: 28 of 32 for teams of 7.
+      // One more member per team is worth it when it puts >= 10 % more CUs to work and the rows are
+      // long enough to fill the register tiles of the larger team (measured: K = 50k, 100 nnz/row,
+      // P 7 -> 8: fp64 5.80 -> 5.48 ms, codes 4.82 -> 4.28 ms; K = 38k, 40 nnz/row is better off at P = 5).
+      const int cpx = std::max(1, h->n_cu / 8);
+      auto util = [&](int p) { return (double)(cpx / p * p) / cpx; };
+      const double mean_len = (double)(h->nnz - nu) / (double)na;
+      for (int p2 = P + 1; p2 <= FZ_MAX_P; ++p2)
+        if (util(p2) >= util(P) + 0.10 && mean_len * fz_rmax(p2) >= 1.05 * fz_cap(p2) * p2) { P = p2; break; }
+    }
     if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
     int Kp = (K + P - 1) / P;
     if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
