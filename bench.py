@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
 class Opts(object):
-    def __init__(self, max_iter):
-        self.em_epsilon, self.max_iter = 0.0, max_iter
+    def __init__(self, max_iter, em_epsilon=0.0):
+        self.em_epsilon, self.max_iter = em_epsilon, max_iter
         self.pi_prior, self.theta_prior = 0, 200000
 
 
@@ -96,10 +96,30 @@ def cpu_baseline(args, dist_code, cdf):
     lnl_ref = om.calculate_lnl(om.z, om.pi, om.theta)
     nnz = int(ip[-1])
     rate = nnz * T / dt
+    # per-locus final counts (output_report, model.py:435-457) on the sample: the integer mode must agree
+    # exactly, the confidence-weighted one to rounding
+    np.random.seed(args.seed)
+    g_excl, g_conf = tl.reassign_colsums('exclude', 0.9), tl.reassign_colsums('conf', 0.9)
+    o_excl = np.asarray(om.reassign('exclude', 0.9).sum(0)).ravel()
+    o_conf = np.asarray(om.reassign('conf', 0.9).sum(0)).ravel()
+    # one run to convergence (em_epsilon = 1e-7, the CLI default) on a smaller sample: iterations and lnl
+    nc = min(40_000, n)
+    eng_c = Engine(0)
+    eng_c.generate(0, nc, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
+    ipc, ixc, rwc = eng_c.export_csr()
+    tlc = TelescopeLikelihood.from_engine(eng_c, Opts(100, 1e-7))
+    tlc.em()
+    omc = OracleModel(sp.csr_matrix((rwc, ixc, ipc), shape=(nc, args.cols)), 0, 200000)
+    omc.em(1e-7, 100)
     return dict(nnz_per_sec=rate, sec_per_iter=dt / T, sample_nnz=nnz, sample_rows=n, iters=T,
                 lnl_ref=float(lnl_ref), lnl_gpu=float(tl.lnl),
                 lnl_rel_delta=abs(tl.lnl - lnl_ref) / abs(lnl_ref),
-                pi_max_rel_delta=float(np.max(np.abs(tl.pi - om.pi) / np.maximum(om.pi, 1e-300))))
+                pi_max_rel_delta=float(np.max(np.abs(tl.pi - om.pi) / np.maximum(om.pi, 1e-300))),
+                final_count_mismatches=int(np.count_nonzero(g_excl != o_excl)),
+                final_conf_max_rel_delta=float(np.max(np.abs(g_conf - o_conf) / np.maximum(np.abs(o_conf), 1e-300))),
+                converged_run=dict(rows=nc, em_epsilon=1e-7, iterations_gpu=int(tlc.n_iter), iterations_ref=int(omc.n_iter),
+                                   lnl_gpu=float(tlc.lnl), lnl_ref=float(omc.lnl),
+                                   lnl_rel_delta=abs(tlc.lnl - omc.lnl) / abs(omc.lnl)))
 
 
 def main():
@@ -250,8 +270,9 @@ def main():
             'nnz_per_sec': cb['nnz_per_sec'],
         }
         out['speedup_vs_cpu'] = out['nnz_per_sec'] / cb['nnz_per_sec']
-        out['parity_on_sample'] = {k: cb[k] for k in ('lnl_ref', 'lnl_gpu', 'lnl_rel_delta',
-                                                      'pi_max_rel_delta', 'sample_rows', 'iters')}
+        out['parity_on_sample'] = {k: cb[k] for k in ('lnl_ref', 'lnl_gpu', 'lnl_rel_delta', 'pi_max_rel_delta',
+                                                      'final_count_mismatches', 'final_conf_max_rel_delta',
+                                                      'sample_rows', 'iters', 'converged_run')}
     _shutdown(comm)
     try:   # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line
         import ctypes
