@@ -1445,7 +1445,7 @@ static int build_layout(tsem_ctx* h) {
                                                   h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc);
     TSEM_HIP(hipGetLastError());
   }
-  TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad);
+  if (!h->use_fused) TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad);   // partial row sums of the two-pass kernels
   // launch geometry
   const size_t lds1 = (size_t)(Kp + R) * 8, lds2 = (size_t)(2 * Kp + R) * 8;
   if (lds2 > (size_t)TS_LDS_MAX - 1024) TSEM_FAIL(TSEM_ERR_ARG, "LDS budget exceeded (reduce block_rows)");
@@ -1453,7 +1453,7 @@ static int build_layout(tsem_ctx* h) {
   int w2 = std::max(1, std::min(2, (int)(TS_LDS_MAX / lds2)));   // 1024-thread WGs per CU
   h->G1 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w1 / P));
   h->G2 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w2 / P));
-  TSEM_ALLOC(h->d_partial, (int64_t)h->G2 * h->Kpad);
+  if (!h->use_fused) TSEM_ALLOC(h->d_partial, (int64_t)h->G2 * h->Kpad);
   if (h->use_fused) {
     {
       h->fz_grid = h->n_cu;
