@@ -289,6 +289,70 @@ __global__ __launch_bounds__(256) void k_row_partcounts(int64_t N_amb, const int
   }
 }
 
+// Block boundaries of the fused layout: a block takes consecutive ambiguous rows until one part would
+// exceed `cap` entries (or R rows).  The rule is sequential, so the rows are cut into chunks of L rows
+// (>= 1024 blocks each: the forced break at a chunk end costs < 0.1 % more blocks) and one WAVE walks
+// each chunk 64 rows at a time: lane prefix sums of the per-part counts, then the first lane that does
+// not fit starts the next block.  pass 0 counts the blocks of a chunk, pass 1 (after an exclusive scan
+// of the counts) writes their first rows.  flags[0]: a single row overflows the tile (-> two-pass).
+__global__ __launch_bounds__(64) void k_block_greedy(int64_t na, int P, int R, int cap, int64_t L, int pass,
+    const unsigned long long* __restrict__ pc, int64_t* __restrict__ cnt, const int64_t* __restrict__ off,
+    int64_t* __restrict__ bstart, int* __restrict__ flags) {
+  const int64_t ch = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t a0 = ch * L, a1 = min(na, a0 + L);
+  if (a0 >= a1) return;
+  int c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rows = 0;         // the open block so far (uniform across the wave)
+  int64_t n = 1;
+  const int64_t o = pass ? off[ch] : 0;
+  if (pass && lane == 0) bstart[o] = a0;
+  for (int64_t t0 = a0; t0 < a1; t0 += 64) {
+    const bool v = t0 + lane < a1;
+    const unsigned long long lo = v ? pc[2 * (t0 + lane)] : 0ull, hi = v ? pc[2 * (t0 + lane) + 1] : 0ull;
+    int S[8];
+    bool too_big = false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      S[q] = q < P ? (int)(((q < 4 ? lo : hi) >> (16 * (q & 3))) & 0xFFFF) : 0;
+      too_big |= S[q] > cap;
+    }
+    if (too_big) flags[0] = 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                          // inclusive prefix over the lanes
+      if (q < P) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(S[q], d, 64); if (lane >= d) S[q] += t; }
+      }
+    }
+    int sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // prefix just before the open block's first lane of this tile
+    int s = 0;                                             // that lane (0: the block continues from earlier tiles)
+    for (;;) {
+      bool bad = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bad |= c[q] + S[q] - sub[q] > cap;
+      bad |= rows + lane - s + 1 > R;
+      bad &= v && lane >= s && !(rows == 0 && lane == s);  // the first row of a block always goes in
+      const unsigned long long m = __ballot(bad);
+      if (!m) break;
+      const int b = __ffsll((long long)m) - 1;             // first row that does not fit: it starts the next block
+      if (pass && lane == 0) bstart[o + n] = t0 + b;
+      ++n;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { sub[q] = b > 0 ? __shfl(S[q], b - 1, 64) : 0; c[q] = 0; }
+      rows = 0; s = b;
+    }
+    const int last = (int)min<int64_t>(63, a1 - t0 - 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] += __shfl(S[q], last, 64) - sub[q];
+    rows += last - s + 1;
+  }
+  if (!pass && lane == 0) cnt[ch] = n;
+}
+__global__ void k_fixed_blocks(int64_t nb, int R, int64_t na, int64_t* __restrict__ bstart) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= nb) bstart[b] = min(na, b * R);
+}
+
 // rows of block b are the compact ambiguous rows [bstart[b], bstart[b+1]); the rest of its R slots are holes
 __global__ __launch_bounds__(256) void k_make_slots(int64_t nb, int R, const int64_t* __restrict__ bstart,
     const int32_t* __restrict__ amb_row, const uint16_t* __restrict__ wcode_c, int32_t* __restrict__ slot_row,
@@ -1157,6 +1221,7 @@ int tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* ra
 // ---------------------------------------------------------------------------
 int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_count, uint64_t* col_hash) {
   if (!h || !h->d_indptr) return TSEM_ERR_ARG;
+  if (!h->d_lut || h->lut_len <= 0) TSEM_FAIL(TSEM_ERR_ARG, "no score table: call tsem_set_lut after tsem_generate");
   if (int rc = ensure_device(h)) return rc;
   const int64_t N = h->N;
   const int K = h->K;
@@ -1334,49 +1399,55 @@ static int build_layout(tsem_ctx* h) {
   //    register tile takes (no part may exceed FZ_CAP entries, at most R rows) — rows per block vary,
   //    every block still owns R row SLOTS (holes at the end), so all kernels keep b*R+lr indexing.
   const int R = h->R;
-  std::vector<int64_t> bstart;
+  int64_t nb = 0;
+  int64_t* d_bs = nullptr;                                 // first compact row of every block, [nb + 1]
   if (h->use_fused && na > 0 && P <= FZ_MAX_P) {
     unsigned long long* d_pc = nullptr;
     TSEM_ALLOC(d_pc, 2 * na);
     k_row_partcounts<<<(unsigned)std::min<int64_t>(65535, (na + 15) / 16), 256, 0, h->stream>>>(
         na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc);
     TSEM_HIP(hipGetLastError());
-    std::vector<unsigned long long> pc(2 * na);
-    TSEM_HIP(hipMemcpyAsync(pc.data(), d_pc, sizeof(unsigned long long) * 2 * na, hipMemcpyDeviceToHost, h->stream));
-    TSEM_HIP(hipStreamSynchronize(h->stream));
-    (void)hipFree(d_pc);
     const int cap = fz_cap(P) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
-    int c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rows = 0;
-    bstart.push_back(0);
-    for (int64_t a = 0; a < na; ++a) {
-      int r[8];
-      for (int q = 0; q < 8; ++q) r[q] = (int)((pc[2 * a + (q >> 2)] >> (16 * (q & 3))) & 0xFFFF);
-      bool too_big = false, full = rows == R;
-      for (int q = 0; q < P; ++q) { too_big |= r[q] > cap; full |= c[q] + r[q] > cap; }
-      if (too_big) { h->use_fused = false; break; }       // one row overflows the register tile
-      if (full) {
-        bstart.push_back(a);
-        for (int q = 0; q < 8; ++q) c[q] = 0;
-        rows = 0;
-      }
-      for (int q = 0; q < P; ++q) c[q] += r[q];
-      ++rows;
+    const int64_t L = std::max<int64_t>((int64_t)R * 1024, (na + 4095) / 4096);
+    const int64_t nch = (na + L - 1) / L;
+    int64_t *d_cnt = nullptr, *d_off = nullptr;
+    int* d_flag = nullptr;
+    TSEM_ALLOC(d_cnt, nch + 1); TSEM_ALLOC(d_off, nch + 1); TSEM_ALLOC(d_flag, 1);
+    TSEM_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), h->stream));
+    TSEM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int64_t) * (nch + 1), h->stream));
+    k_block_greedy<<<(unsigned)nch, 64, 0, h->stream>>>(na, P, R, cap, L, 0, d_pc, d_cnt, nullptr, nullptr, d_flag);
+    TSEM_HIP(hipGetLastError());
+    {
+      size_t tb = 0;
+      (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_cnt, d_off, nch + 1, h->stream);
+      void* tmp = nullptr;
+      TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+      (void)hipcub::DeviceScan::ExclusiveSum(tmp, tb, d_cnt, d_off, nch + 1, h->stream);
+      int flag = 0;
+      TSEM_HIP(hipMemcpyAsync(&nb, d_off + nch, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      (void)hipFree(tmp);
+      if (flag) { h->use_fused = false; nb = 0; }          // one row overflows the register tile
     }
-    bstart.push_back(na);
+    if (h->use_fused) {
+      TSEM_ALLOC(d_bs, nb + 1);
+      k_block_greedy<<<(unsigned)nch, 64, 0, h->stream>>>(na, P, R, cap, L, 1, d_pc, d_cnt, d_off, d_bs, d_flag);
+      TSEM_HIP(hipGetLastError());
+      TSEM_HIP(hipMemcpyAsync(d_bs + nb, &na, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+    }
+    (void)hipFree(d_pc); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_flag);
   }
-  if (!h->use_fused || bstart.empty()) {
-    bstart.clear();
-    for (int64_t a = 0; a < na; a += R) bstart.push_back(a);
-    bstart.push_back(na);
-    if (na == 0) bstart.assign(1, 0);
+  if (!d_bs) {                                             // two-pass layout: R rows per block
+    nb = (na + R - 1) / R;
+    TSEM_ALLOC(d_bs, nb + 1);
+    k_fixed_blocks<<<cdiv64(nb + 1, 256), 256, 0, h->stream>>>(nb, R, na, d_bs);
+    TSEM_HIP(hipGetLastError());
   }
-  const int64_t nb = (int64_t)bstart.size() - 1;
   h->nb = nb;
   h->N_amb_pad = std::max<int64_t>(1, nb) * R;
   {
-    int64_t* d_bs = nullptr;
-    TSEM_ALLOC(d_bs, nb + 1);
-    TSEM_HIP(hipMemcpy(d_bs, bstart.data(), sizeof(int64_t) * (nb + 1), hipMemcpyHostToDevice));
     TSEM_ALLOC(h->d_slot_row, h->N_amb_pad);
     TSEM_ALLOC(h->d_amb_wcode, h->N_amb_pad);
     if (nb) k_make_slots<<<(unsigned)nb, 256, 0, h->stream>>>(nb, R, d_bs, h->d_amb_row, h->d_amb_wcode_c,

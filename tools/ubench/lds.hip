@@ -25,6 +25,12 @@ __global__ __launch_bounds__(1024) void k(int H, int iters, int act, double* out
     uint32_t key = (MODE == 3) ? (uint32_t)((tid / act) * 4 + j) : (uint32_t)(tid * 4 + j);
     idx[j] = mix(key * 2654435761u + 12345u) % (uint32_t)(MODE == 4 ? 300 : H);
   }
+  if (MODE == 8 || MODE == 9) {                      // conflict-free: the lanes of one instruction touch consecutive doubles
+    for (int j = 0; j < 4; ++j) idx[j] = (uint32_t)(((tid >> 6) * 256 + j * 64 + (tid & 63)) % H);
+  }
+  if (MODE == 10) {                                  // random rows of 64 consecutive doubles per instruction, lanes shuffled inside
+    for (int j = 0; j < 4; ++j) idx[j] = (uint32_t)((mix((tid >> 6) * 4 + j) % (H / 64)) * 64 + (mix(tid * 7 + j) & 63));
+  }
   const bool on = (MODE == 2 || MODE == 6) ? ((mix(lane * 77u + 5u) & 63u) < (unsigned)act) : true;
   double a = 0.0;
   __syncthreads();
@@ -34,7 +40,9 @@ __global__ __launch_bounds__(1024) void k(int H, int iters, int act, double* out
       a += tab[idx[0]] + tab[idx[1]] + tab[idx[2]] + tab[idx[3]];
     } else if (MODE == 6) {
       if (on) a += tab[idx[0]] + tab[idx[1]] + tab[idx[2]] + tab[idx[3]];
-    } else if (MODE == 1 || MODE == 3) {
+    } else if (MODE == 9) {
+      a += tab[idx[0]] + tab[idx[1]] + tab[idx[2]] + tab[idx[3]];
+    } else if (MODE == 1 || MODE == 3 || MODE == 8 || MODE == 10) {
       lds_add(&tab[idx[0]], 1.0); lds_add(&tab[idx[1]], 1.0); lds_add(&tab[idx[2]], 1.0); lds_add(&tab[idx[3]], 1.0);
     } else if (MODE == 2) {
       if (on) { lds_add(&tab[idx[0]], 1.0); lds_add(&tab[idx[1]], 1.0); lds_add(&tab[idx[2]], 1.0); lds_add(&tab[idx[3]], 1.0); }
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(1024) void k(int H, int iters, int act, double* out
       a += r0.x + r0.y + r1.x + r1.y;
     }
     // rotate the indices a little so the compiler cannot hoist anything
-    idx[0] = (idx[0] + 1 == (uint32_t)(MODE == 4 ? 300 : H)) ? 0 : idx[0] + 1;
+    if (MODE < 8) idx[0] = (idx[0] + 1 == (uint32_t)(MODE == 4 ? 300 : H)) ? 0 : idx[0] + 1;
     asm volatile("" : "+v"(idx[0]), "+v"(idx[1]), "+v"(idx[2]), "+v"(idx[3]));
   }
   __syncthreads();
@@ -87,5 +95,8 @@ int main() {
   for (int a : {32, 16, 8}) run<6>("gather b64 random, lanes active", 7500, a);
   for (int a : {2, 3, 4, 8}) run<3>("ds_add_f64, runs of adjacent lanes same addr", 384, a);
   run<7>("gather b128 (2 x per thread) random", 7500, 64);
+  run<8>("ds_add_f64 conflict-free (consecutive)", 7424, 64);
+  run<9>("gather b64 conflict-free (consecutive)", 7424, 64);
+  run<10>("ds_add_f64 64 random lanes within 64 doubles", 7424, 64);
   return 0;
 }
