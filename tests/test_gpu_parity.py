@@ -432,6 +432,50 @@ def test_rows_longer_than_a_wave_of_quads(gpu_device):
         assert info['fused'] == 1 and info['P'] == 1
 
 
+@pytest.mark.parametrize('seed', range(24))
+def test_random_shapes_against_oracle(gpu_device, seed):
+    """Small random matrices of every shape the layout code branches on: 1..5 column parts, few or
+    many blocks (fewer blocks than teams, a single block, blocks of very different fill), rows with
+    1..120 entries, 0..60 % unique rows, narrow and wide score ranges, forced block sizes, both
+    entry formats, priors on and off."""
+    rng = np.random.RandomState(1000 + seed)
+    k = int(rng.choice([3, 17, 200, 5000, 9000, 16000, 24000, 33000]))
+    n = int(rng.choice([1, 7, 300, 2500, 12000, 40000]))
+    max_len = int(min(k, rng.choice([2, 5, 30, 120])))
+    uniq = float(rng.choice([0.0, 0.1, 0.6]))
+    lens = np.where(rng.rand(n) < uniq, 1, rng.randint(1, max_len + 1, n))
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    lo, hi = [(139, 212), (1, 5), (100, 1500), (60000, 65535)][int(rng.randint(4))]
+    data = rng.randint(lo, hi + 1, indptr[-1]).astype(np.uint16)
+    raw = sp.csr_matrix((data, indices, indptr), shape=(n, k))
+    options = [('value_format', int(rng.randint(0, 2)))]
+    if rng.rand() < 0.3:
+        options.append(('block_rows', int(rng.choice([64, 128, 256]))))
+    if rng.rand() < 0.2:
+        options.append(('em_kernel', 1))
+    from oracle.telescope_oracle import OracleModel
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+    o = Opts(max_iter=int(rng.randint(1, 6)), em_epsilon=0.0)
+    o.pi_prior, o.theta_prior = [(0, 200000), (0, 0), (5, 1000)][int(rng.randint(3))]
+    eng = _lib.Engine(0)
+    for key, v in options:
+        eng.set_option(key, v)
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), k, score_lut(int(raw.data.max())))
+    tl = TelescopeLikelihood.from_engine(eng, o)
+    tl._raw = raw
+    tl.em()
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    om.em(0.0, o.max_iter)
+    ctx = (seed, n, k, max_len, uniq, (lo, hi), options, eng.layout_info())
+    assert abs(tl.lnl - om.lnl) <= RTOL * max(abs(om.lnl), 1e-300), ctx
+    assert np.allclose(tl.pi, om.pi, rtol=RTOL, atol=1e-300), ctx
+    assert np.allclose(tl.theta, om.theta, rtol=RTOL, atol=1e-300), ctx
+    for method in ('exclude', 'all', 'unique'):
+        assert np.array_equal(tl.reassign_colsums(method), np.asarray(om.reassign(method).sum(0)).ravel()), (method, ctx)
+
+
 def test_fused_and_twopass_agree_at_scale(gpu_device):
     """5M x 30k x 40: the two EM kernels give the same parameters (summation order aside)."""
     res = []
