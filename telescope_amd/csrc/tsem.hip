@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_row_partcounts(int64_t N_amb, const int
 
 // Block boundaries of the fused layout: a block takes consecutive ambiguous rows until one part would
 // exceed `cap` entries (or R rows).  The rule is sequential, so the rows are cut into chunks of L rows
-// (>= 1024 blocks each: the forced break at a chunk end costs < 0.1 % more blocks) and one WAVE walks
+// (>= 256 blocks each: the forced break at a chunk end costs ~0.2 % more blocks) and one WAVE walks
 // each chunk 64 rows at a time: lane prefix sums of the per-part counts, then the first lane that does
 // not fit starts the next block.  pass 0 counts the blocks of a chunk, pass 1 (after an exclusive scan
 // of the counts) writes their first rows.  flags[0]: a single row overflows the tile (-> two-pass).
@@ -1408,7 +1408,7 @@ static int build_layout(tsem_ctx* h) {
         na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc);
     TSEM_HIP(hipGetLastError());
     const int cap = fz_cap(P) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
-    const int64_t L = std::max<int64_t>((int64_t)R * 1024, (na + 4095) / 4096);
+    const int64_t L = std::max<int64_t>((int64_t)R * 256, (na + 4095) / 4096);
     const int64_t nch = (na + L - 1) / L;
     int64_t *d_cnt = nullptr, *d_off = nullptr;
     int* d_flag = nullptr;
