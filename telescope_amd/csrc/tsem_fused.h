@@ -499,10 +499,13 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
         term(rr.v0.x, rr.rc.x); term(rr.v0.y, rr.rc.y); term(rr.v1.x, rr.rc.z); term(rr.v1.y, rr.rc.w);
         return;
       }
-      lds_add(&acc[rr.rc.x & 0xFFFF], rr.v0.x * sb[rr.rc.x >> 16]);
-      lds_add(&acc[rr.rc.y & 0xFFFF], rr.v0.y * sb[rr.rc.y >> 16]);
-      lds_add(&acc[rr.rc.z & 0xFFFF], rr.v1.x * sb[rr.rc.z >> 16]);
-      lds_add(&acc[rr.rc.w & 0xFFFF], rr.v1.y * sb[rr.rc.w >> 16]);
+      // all four gathers first: an LDS atomic may alias a later LDS read as far as the compiler knows,
+      // so `add(acc, v * s[..])` four times in a row serialises gather -> wait -> atomic -> gather ...
+      const double s0 = sb[rr.rc.x >> 16], s1 = sb[rr.rc.y >> 16], s2 = sb[rr.rc.z >> 16], s3 = sb[rr.rc.w >> 16];
+      lds_add(&acc[rr.rc.x & 0xFFFF], rr.v0.x * s0);
+      lds_add(&acc[rr.rc.y & 0xFFFF], rr.v0.y * s1);
+      lds_add(&acc[rr.rc.z & 0xFFFF], rr.v1.x * s2);
+      lds_add(&acc[rr.rc.w & 0xFFFF], rr.v1.y * s3);
     };
     FzRegs r0, r1, r2, r3, r4, r5;
     {

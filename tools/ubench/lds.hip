@@ -31,6 +31,13 @@ __global__ __launch_bounds__(1024) void k(int H, int iters, int act, double* out
   if (MODE == 10) {                                  // random rows of 64 consecutive doubles per instruction, lanes shuffled inside
     for (int j = 0; j < 4; ++j) idx[j] = (uint32_t)((mix((tid >> 6) * 4 + j) % (H / 64)) * 64 + (mix(tid * 7 + j) & 63));
   }
+  if (MODE == 11 || MODE == 12) {                    // bank class = lane % 16 (MODE 11) or lane % 32 (MODE 12); the row of the table is random
+    const int md = MODE == 11 ? 16 : 32;
+    for (int j = 0; j < 4; ++j) idx[j] = (uint32_t)(((mix(tid * 4 + j) % (H / 32)) * 32 + (lane % md)) % H);
+  }
+  if (MODE == 13) {                                  // 2 lanes of every 16 share a class, otherwise distinct
+    for (int j = 0; j < 4; ++j) idx[j] = (uint32_t)(((mix(tid * 4 + j) % (H / 32)) * 32 + ((lane % 16) / 2) * 2 + 16 * ((lane / 16) & 1)) % H);
+  }
   const bool on = (MODE == 2 || MODE == 6) ? ((mix(lane * 77u + 5u) & 63u) < (unsigned)act) : true;
   double a = 0.0;
   __syncthreads();
@@ -42,7 +49,7 @@ __global__ __launch_bounds__(1024) void k(int H, int iters, int act, double* out
       if (on) a += tab[idx[0]] + tab[idx[1]] + tab[idx[2]] + tab[idx[3]];
     } else if (MODE == 9) {
       a += tab[idx[0]] + tab[idx[1]] + tab[idx[2]] + tab[idx[3]];
-    } else if (MODE == 1 || MODE == 3 || MODE == 8 || MODE == 10) {
+    } else if (MODE == 1 || MODE == 3 || MODE == 8 || MODE == 10 || MODE == 11 || MODE == 12 || MODE == 13) {
       lds_add(&tab[idx[0]], 1.0); lds_add(&tab[idx[1]], 1.0); lds_add(&tab[idx[2]], 1.0); lds_add(&tab[idx[3]], 1.0);
     } else if (MODE == 2) {
       if (on) { lds_add(&tab[idx[0]], 1.0); lds_add(&tab[idx[1]], 1.0); lds_add(&tab[idx[2]], 1.0); lds_add(&tab[idx[3]], 1.0); }
@@ -98,5 +105,8 @@ int main() {
   run<8>("ds_add_f64 conflict-free (consecutive)", 7424, 64);
   run<9>("gather b64 conflict-free (consecutive)", 7424, 64);
   run<10>("ds_add_f64 64 random lanes within 64 doubles", 7424, 64);
+  run<11>("ds_add_f64 class = lane % 16, random row", 7424, 64);
+  run<12>("ds_add_f64 class = lane % 32, random row", 7424, 64);
+  run<13>("ds_add_f64 pairs share a class in each 16 lanes", 7424, 64);
   return 0;
 }
