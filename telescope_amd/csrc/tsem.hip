@@ -764,6 +764,77 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       double c = amb ? A.pi[col] * A.theta[col] : A.pi[col];
       return q * c;
     };
+    if (e - s <= 4 * RP_SUB) {
+      // Rows of up to 64 entries (all of them, for alignment data): the numerators are computed once
+      // and stay in registers for the row sum, the row maximum, the tie count and the output value.
+      double n[4]; bool vld[4], inp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t k = s + lane + i * RP_SUB;
+        vld[i] = k < e;
+        n[i] = vld[i] ? numer(k) : 0.0;
+        inp[i] = vld[i] && (initial || n[i] != 0.0);
+      }
+      // same summation order as the long-row path below: lane-strided partial sums, then across lanes
+      const double r = recip0(sg_sum<RP_SUB>(((n[0] + n[1]) + n[2]) + n[3]));
+      double zmax = -1.0; int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (inp[i]) { zmax = fmax(zmax, n[i] * r); ++cnt; }
+      zmax = sg_max<RP_SUB>(zmax);
+      cnt = sg_sum_i<RP_SUB>(cnt);
+      if (MODE == RP_EXPORT_Z) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (vld[i]) A.zout[s + lane + i * RP_SUB] = inp[i] ? n[i] * r : -1.0;
+        continue;
+      }
+      int nb = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nb += (inp[i] && (n[i] * r) == zmax) ? 1 : 0;
+      nb = sg_sum_i<RP_SUB>(nb);
+      if (MODE == RP_BEST) {
+        if (lane == 0) A.nbest[row] = cnt ? nb : 0;
+        continue;
+      }
+      double vsum = 0.0;
+      if (A.method == TSEM_RA_CONF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (inp[i] && n[i] * r >= A.thresh) vsum += n[i] * r;
+        vsum = sg_sum<RP_SUB>(vsum);
+      }
+      const int pick = (A.method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[row] : 0;
+      const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
+      int base = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t k = s + lane + i * RP_SUB;
+        const double z = n[i] * r;
+        const bool best = inp[i] && (z == zmax);
+        const unsigned long long bal = __ballot(best);
+        const unsigned grp = (unsigned)((bal >> ((threadIdx.x & 63) / RP_SUB * RP_SUB)) & 0xFFFFull);
+        const int ord = base + __popc(grp & ((1u << lane) - 1u));
+        base += __popc(grp);
+        double val = 0.0;
+        switch (A.method) {
+          case TSEM_RA_EXCLUDE: val = (best && nb == 1) ? 1.0 : 0.0; break;
+          case TSEM_RA_CHOOSE:  val = (best && ord == pick) ? 1.0 : 0.0; break;
+          case TSEM_RA_AVERAGE: val = best ? 1.0 * recip0((double)nb) : 0.0; break;
+          case TSEM_RA_CONF:    val = (inp[i] && z >= A.thresh) ? z * recip0(vsum) : 0.0; break;
+          case TSEM_RA_UNIQUE:  val = (inp[i] && !amb) ? ceil(z) : 0.0; break;
+          case TSEM_RA_ALL:     val = (inp[i] && z > 0.0) ? 1.0 : 0.0; break;
+        }
+        if (vld[i]) {
+          if (A.zout) A.zout[k] = val;
+          if (val != 0.0 && grp_off >= 0) {
+            const int col = A.indices[k];
+            uint32_t cm = 0xFFFFFFFFu;
+            if (nhot) cm = A.colmap[col];
+            if (nhot && (int)(cm & 0x1FFFu) < A.Hs) lds_add(&hot[(cm >> 16) * A.Hs + (cm & 0x1FFFu)], val);
+            else unsafeAtomicAdd(&A.colsums[grp_off + col], val);
+          }
+        }
+      }
+      continue;
+    }
     // sweep 1: row sum
     double y = 0.0;
     for (int64_t k = s + lane; k < e; k += RP_SUB) y += numer(k);
