@@ -67,6 +67,44 @@ class _NullComm(object):
         return parts[0]
 
 
+class Assignment(object):
+    """What `TelescopeLikelihood.reassign` returns: a stand-in for the reference's N x K
+    `csr_matrix_plus` that answers `.sum(0)` from the device and turns into the real scipy matrix
+    (rows of this rank) when anything else is asked of it."""
+
+    def __init__(self, tl, method, thresh, which, picks):
+        self._tl, self._args, self._mat, self._colsum = tl, (method, thresh, which, picks), None, None
+        self.shape = (tl.N, tl.K)
+
+    def tocsr(self):
+        if self._mat is None:
+            self._mat = self._tl._assignment_matrix(*self._args)
+        return self._mat
+
+    def sum(self, axis=None, **kw):
+        if axis in (0, -2) and not kw and self._mat is None:
+            if self._colsum is None:
+                method, thresh, which, picks = self._args
+                cs, _ = self._tl._eng.reassign(method, thresh, which, picks)
+                cs = self._tl.comm.sum_array(cs)
+                if _MASK_DTYPE[method] != np.float64:
+                    cs = np.rint(cs).astype(np.int64)
+                self._colsum = cs
+            return np.asarray(self._colsum).reshape(1, -1).view(np.matrix)   # scipy returns a 1 x K np.matrix: `.A1` works
+        return self.tocsr().sum(axis, **kw)
+
+    def __getitem__(self, key):
+        return self.tocsr()[key]
+
+    def __getattr__(self, name):                         # data, indices, indptr, multiply, nnz, toarray, ...
+        if name.startswith('__') and name.endswith('__'):
+            raise AttributeError(name)
+        return getattr(self.tocsr(), name)
+
+    def __array__(self, *a, **kw):
+        return self.tocsr().toarray()
+
+
 class TelescopeLikelihood(object):
     """EM model over a fragments x loci score matrix (model.py:631-865)."""
 
@@ -345,11 +383,18 @@ class TelescopeLikelihood(object):
         return out
 
     def reassign(self, method, thresh=0.9, initial=False):
-        """model.py:808-865 — returns the assignment matrix as a scipy CSR."""
+        """model.py:808-865 — the assignment matrix.  Returned as an `Assignment`: `.sum(0)` (all the
+        reference's `output_report` asks of it, model.py:435-457) is answered by one device pass over
+        the rows; anything else (`[i, j]`, `.data`, `scipy.sparse.csr_matrix(a)`, ...) builds the
+        scipy CSR on first use.  `choose` draws its random picks NOW, so the caller's numpy RNG
+        stream is consumed exactly where the reference consumes it."""
         if method not in REASSIGN_METHODS:
             raise ValueError('Argument "method" should be one of (exclude, choose, average, conf, unique, all)')
         which = self._which(initial)
         picks = self._picks(which) if method == 'choose' else None
+        return Assignment(self, method, thresh, which, picks)
+
+    def _assignment_matrix(self, method, thresh, which, picks):
         _, mask = self._eng.reassign(method, thresh, which, picks, want_mask=True)
         r = self._need_raw()
         keep = mask != 0

@@ -123,7 +123,15 @@ def test_z_and_masks_match_reference(gpu_device, name):
     for initial in (False, True):
         for meth in ALL_METHODS:
             np.random.seed(int(c['seed']))
-            m = sp.csr_matrix(tl.reassign(meth, 0.9, initial))
+            a = tl.reassign(meth, 0.9, initial)
+            after = np.random.get_state()[2]                 # `choose` has drawn by now, not later
+            colsum = a.sum(0).A1                             # what output_report asks for (model.py:435-457)
+            m = a.tocsr()
+            assert np.random.get_state()[2] == after
+            assert a.shape == raw.shape and sp.issparse(m)
+            assert np.allclose(colsum, np.asarray(m.sum(0)).ravel(), rtol=1e-12, atol=1e-12)
+            assert colsum.dtype == (np.int64 if meth in INT_METHODS else np.float64)
+            assert a[0, int(raw.indices[0])] == m[0, int(raw.indices[0])] and a.nnz == m.nnz
             tag = 'ra_%s_%d_' % (meth, int(initial))
             ref = sp.csr_matrix((c[tag + 'data'], c[tag + 'indices'], c[tag + 'indptr']), shape=raw.shape)
             assert str(m.dtype) == str(c[tag + 'dtype'])
