@@ -484,6 +484,23 @@ def test_random_shapes_against_oracle(gpu_device, seed):
         assert np.array_equal(tl.reassign_colsums(method), np.asarray(om.reassign(method).sum(0)).ravel()), (method, ctx)
 
 
+def test_config3_entry_formats_agree(gpu_device):
+    """BASELINE config 3 (10M x 30k x ~40) asks for a precision sweep of the stored values.  No reduced
+    precision is offered: 2-byte score codes + the fp64 score table are SMALLER than fp32 values and give
+    the same fp64 numbers — the two layouts must agree to summation-order noise at full size."""
+    res = []
+    for fmt in (1, 2):
+        tl = _synthetic_tl(10_000_000, 30000, 40, 'zipf', options=(('value_format', fmt),),
+                           opts=Opts(max_iter=8, em_epsilon=0.0))
+        tl.em()
+        res.append((tl.pi.copy(), tl.theta.copy(), tl.lnl, tl._eng.layout_info()['value_bytes'],
+                    tl.reassign_colsums('exclude')))
+    assert (res[0][3], res[1][3]) == (8, 2)
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-11, atol=0) and np.allclose(res[0][1], res[1][1], rtol=1e-11, atol=0)
+    assert abs(res[0][2] - res[1][2]) <= 1e-12 * abs(res[0][2])
+    assert np.array_equal(res[0][4], res[1][4])
+
+
 def test_fused_and_twopass_agree_at_scale(gpu_device):
     """5M x 30k x 40: the two EM kernels give the same parameters (summation order aside)."""
     res = []
