@@ -1064,18 +1064,22 @@ static int ensure_device(tsem_ctx* h) {
 }
 
 typedef void (*fz_fn)(FusedArgs);
-template <int P> static fz_fn fz_pick(int mode, int fmt) {
-  if (fmt == 1) return mode ? k_em_fused<P, 1, 1> : k_em_fused<P, 0, 1>;
-  if (fmt == 2) return mode ? k_em_fused<P, 1, 2> : k_em_fused<P, 0, 2>;
-  return mode ? k_em_fused<P, 1, 0> : k_em_fused<P, 0, 0>;
+template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
+  if (fmt == 1) return mode ? k_em_fused<P, 1, 1, GEO> : k_em_fused<P, 0, 1, GEO>;
+  if (fmt == 2) return mode ? k_em_fused<P, 1, 2, GEO> : k_em_fused<P, 0, 2, GEO>;
+  return mode ? k_em_fused<P, 1, 0, GEO> : k_em_fused<P, 0, 0, GEO>;
+}
+template <int P> static fz_fn fz_pick(int mode, int fmt, int geo) {
+  if constexpr (P > 4) return fz_pick2<P, 1>(mode, fmt);   // teams of 5-8: one geometry
+  else return geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 0>(mode, fmt);
 }
 static int fz_fmt(const tsem_ctx* h) { return h->fmt_code ? 1 : (h->fmt_wcode ? 2 : 0); }
-static fz_fn fz_kernel(int P, int mode, int fmt) {
+static fz_fn fz_kernel(int P, int mode, int fmt, int geo) {
   switch (P) {
-    case 1: return fz_pick<1>(mode, fmt); case 2: return fz_pick<2>(mode, fmt);
-    case 3: return fz_pick<3>(mode, fmt); case 4: return fz_pick<4>(mode, fmt);
-    case 5: return fz_pick<5>(mode, fmt); case 6: return fz_pick<6>(mode, fmt);
-    case 7: return fz_pick<7>(mode, fmt); case 8: return fz_pick<8>(mode, fmt);
+    case 1: return fz_pick<1>(mode, fmt, geo); case 2: return fz_pick<2>(mode, fmt, geo);
+    case 3: return fz_pick<3>(mode, fmt, geo); case 4: return fz_pick<4>(mode, fmt, geo);
+    case 5: return fz_pick<5>(mode, fmt, geo); case 6: return fz_pick<6>(mode, fmt, geo);
+    case 7: return fz_pick<7>(mode, fmt, geo); case 8: return fz_pick<8>(mode, fmt, geo);
     default: return nullptr;
   }
 }
@@ -1166,6 +1170,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "fused_dbg") h->opt_dbg = v;
   else if (k == "value_format") h->opt_format = v;
   else if (k == "hot_split") h->opt_hot_split = v;
+  else if (k == "geometry") h->opt_geo = v;
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
     if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
@@ -1392,7 +1397,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
       auto util = [&](int p) { return (double)(cpx / p * p) / cpx; };
       const double mean_len = (double)(h->nnz - nu) / (double)na;
       for (int p2 = P + 1; p2 <= FZ_MAX_P; ++p2)
-        if (util(p2) >= util(P) + 0.10 && mean_len * fz_rmax(p2) >= 1.05 * fz_cap(p2) * p2) { P = p2; break; }
+        if (util(p2) >= util(P) + 0.10 && mean_len * fz_rmax(1) >= 1.05 * fz_cap(1) * p2) { P = p2; break; }
     }
     if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
     int Kp = (K + P - 1) / P;
@@ -1403,14 +1408,19 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
     h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
     int R = 2048;
+    h->geo = P > 4 ? 1 : 0;
     if (h->use_fused && na > 0) {
       // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
       double mean_len = (double)(h->nnz - nu) / (double)na;
       // row SLOTS per block: ~7 % above the average a register tile takes, so blocks end on the
       // tile's capacity, not on R (the exchange cost depends on R, hence not more than needed)
-      double r = 1.07 * fz_cap(P) * P / std::max(2.0, mean_len);
-      const int lut_bytes = fz_wants_codes(h) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
-      int rmax = std::min(fz_rmax(P), (TS_LDS_MAX - 2048 - 2 * Kp * 8 - lut_bytes) / ((FZ_YR + 2) * 8));
+      // geometry: teams of 5-8 have one; smaller teams switch to three exchange waves when the rows
+      // are so short that 512 row slots cannot fill the register tile
+      h->geo = P > 4 ? 1 : (1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > fz_rmax(0) ? 2 : 0);
+      if (h->opt_geo >= 0 && P <= 4) h->geo = h->opt_geo == 2 ? 2 : 0;
+      double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
+      const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2048 - 2 * Kp * 8 - lut_bytes) / ((FZ_YR + 2) * 8));
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
       R = std::min(R, rmax / 8 * 8);
@@ -1500,7 +1510,7 @@ static int build_layout(tsem_ctx* h) {
     k_row_partcounts<<<(unsigned)std::min<int64_t>(65535, (na + 15) / 16), 256, 0, h->stream>>>(
         na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc);
     TSEM_HIP(hipGetLastError());
-    const int cap = fz_cap(P) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
+    const int cap = fz_cap(h->geo) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
     const int64_t L = std::max<int64_t>((int64_t)R * 256, (na + 4095) / 4096);
     const int64_t nch = (na + L - 1) / L;
     int64_t *d_cnt = nullptr, *d_off = nullptr;
@@ -1565,7 +1575,7 @@ static int build_layout(tsem_ctx* h) {
     int64_t mx = 0;
     for (int64_t i = 0; i < nb * P; ++i) mx = std::max(mx, sb[i]);
     h->max_subblock = mx;
-    if (mx > fz_cap(P)) h->use_fused = false;
+    if (mx > fz_cap(h->geo)) h->use_fused = false;
   }
   int64_t off = 0;
   for (int64_t i = 0; i < nb * P; ++i) {   // sub-blocks padded to TS_STRANDS*4 entries (strand-transposed order)
@@ -1585,7 +1595,7 @@ static int build_layout(tsem_ctx* h) {
   } else if (h->use_fused) {
     h->use_fused = false;
   }
-  if (h->use_fused && (R > fz_rmax(P) || (R & 1) || fz_lds_bytes(h, false) > (size_t)TS_LDS_MAX - 1024)) h->use_fused = false;
+  if (h->use_fused && (R > fz_rmax(h->geo) || (R & 1) || fz_lds_bytes(h, false) > (size_t)TS_LDS_MAX - 1024)) h->use_fused = false;
   h->fmt_code = h->use_fused && fz_wants_codes(h) && fz_lds_bytes(h, true) <= (size_t)TS_LDS_MAX - 1024;
   h->fmt_wcode = h->use_fused && !h->fmt_code && h->lut_len > 0 && h->lut_len <= 2048 &&
                  fz_lds_bytes(h, true) <= (size_t)TS_LDS_MAX - 1024;
@@ -1631,7 +1641,7 @@ static int build_layout(tsem_ctx* h) {
         k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
       }
       for (int mode = 0; mode < 2; ++mode)
-        TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h)),
+        TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h), h->geo),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
     }
   }
@@ -1793,7 +1803,7 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
   const size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
   if (mode && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
-  fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h));
+  fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h), h->geo);
   if (!fn) TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
   if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
   fn<<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A);

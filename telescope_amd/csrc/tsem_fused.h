@@ -37,15 +37,17 @@
 #pragma once
 
 constexpr int FZ_NT = 1024;            // threads per workgroup
-// Geometry by team size: the exchange waves keep two generations of (P-1) partner values per
-// row pair in registers, so larger teams use more exchange waves with fewer row pairs per lane.
-//   P <= 4 : 2 exchange waves x 2 row pairs per lane (R <= 512), 14 data waves
-//   P <= 8 : 3 exchange waves x 1 row pair  per lane (R <= 384), 13 data waves
-__host__ __device__ constexpr int fz_nxw(int P) { return P <= 4 ? 2 : 3; }          // exchange waves
-__host__ __device__ constexpr int fz_rp(int P) { return P <= 4 ? 2 : 1; }           // row pairs per lane
-__host__ __device__ constexpr int fz_dt(int P) { return FZ_NT - 64 * fz_nxw(P); }   // data threads
-__host__ __device__ constexpr int fz_cap(int P) { return fz_dt(P) * 4; }            // entries per register tile
-__host__ __device__ constexpr int fz_rmax(int P) { return 2 * 64 * fz_rp(P) * fz_nxw(P); }
+// Geometry (GEO): the exchange waves keep two generations of (P-1) partner values per row pair in
+// registers, so larger teams use more exchange waves with fewer row pairs per lane; short rows need
+// more row slots per block to fill the register tile.
+//   0 : 2 exchange waves x 2 row pairs per lane (R <= 512), 14 data waves   teams of 1-4
+//   1 : 3 exchange waves x 1 row pair  per lane (R <= 384), 13 data waves   teams of 5-8
+//   2 : 3 exchange waves x 2 row pairs per lane (R <= 768), 13 data waves   teams of 1-4, short rows
+__host__ __device__ constexpr int fz_nxw(int g) { return g == 0 ? 2 : 3; }          // exchange waves
+__host__ __device__ constexpr int fz_rp(int g) { return g == 1 ? 1 : 2; }           // row pairs per lane
+__host__ __device__ constexpr int fz_dt(int g) { return FZ_NT - 64 * fz_nxw(g); }   // data threads
+__host__ __device__ constexpr int fz_cap(int g) { return fz_dt(g) * 4; }            // entries per register tile
+__host__ __device__ constexpr int fz_rmax(int g) { return 2 * 64 * fz_rp(g) * fz_nxw(g); }
 constexpr int FZ_MAX_P = 8;
 #ifndef FZ_GAP_STEPS
 #define FZ_GAP_STEPS 1
@@ -54,7 +56,7 @@ constexpr int FZ_GAP = FZ_GAP_STEPS;   // steps between a block's publish and th
 constexpr int FZ_NS = 5 + FZ_GAP;      // register sets: block k lives in set k % FZ_NS
 constexpr int FZ_DL = 2;               // prefetch distance (steps)
 constexpr int FZ_LAG = 3 + FZ_GAP;     // scatter lag (steps) = FZ_NS - FZ_DL
-constexpr int FZ_YR = 8;               // y ring (row sums live from step k to k+2+GAP)
+constexpr int FZ_YR = 4;               // y ring: row sums of block k live from step k to k+3 (combine), GAP = 1
 constexpr int FZ_XS = 8;               // exchange slots per team (ring)
 constexpr unsigned FZ_SPIN_LIMIT = 2000000u;
 constexpr int FZ_PROF_SLOTS = 16;
@@ -187,11 +189,11 @@ struct FzX {                 // context handed to the exchange wave
 };
 
 // Exchange wave of member PP of a P-member team (see k_em_fused for the schedule).
-template <int P, int PP, int MODE, int FMT>
+template <int P, int PP, int MODE, int FMT, int GEO>
 __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   constexpr int p = PP;
-  constexpr int FZ_RP = fz_rp(P);
+  constexpr int FZ_RP = fz_rp(GEO);
   constexpr int NPART = P > 1 ? P - 1 : 1;
   double* const y = X.y; double* const s = X.s; uint32_t* const offs = X.offs; uint32_t* const err = X.err;
   unsigned long long* const xbase = X.xbase;
@@ -342,11 +344,11 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   }
 }
 
-template <int PT, int MODE, int FMT>
+template <int PT, int MODE, int FMT, int GEO>
 __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int P = PT;
-  constexpr int FZ_DT = fz_dt(P);
+  constexpr int FZ_DT = fz_dt(GEO);
   const int Kp = A.Kp, R = A.R;
   double* c = reinterpret_cast<double*>(smem);
   double* acc = c + Kp;
@@ -436,14 +438,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     X.lut = lutS; X.y = y; X.s = s; X.offs = offs; X.xbase = xbase; X.err = err; X.R = R; X.team = team; X.T = T;
     X.nblk = nblk; X.nsteps = nsteps; X.lane = (tid - FZ_DT) & 63; X.xw = (tid - FZ_DT) >> 6;
     switch (p) {
-      case 0: fz_xchg<P, 0, MODE, FMT>(A, X); break;
-      case 1: if (P > 1) fz_xchg<P, (P > 1 ? 1 : 0), MODE, FMT>(A, X); break;
-      case 2: if (P > 2) fz_xchg<P, (P > 2 ? 2 : 0), MODE, FMT>(A, X); break;
-      case 3: if (P > 3) fz_xchg<P, (P > 3 ? 3 : 0), MODE, FMT>(A, X); break;
-      case 4: if (P > 4) fz_xchg<P, (P > 4 ? 4 : 0), MODE, FMT>(A, X); break;
-      case 5: if (P > 5) fz_xchg<P, (P > 5 ? 5 : 0), MODE, FMT>(A, X); break;
-      case 6: if (P > 6) fz_xchg<P, (P > 6 ? 6 : 0), MODE, FMT>(A, X); break;
-      case 7: if (P > 7) fz_xchg<P, (P > 7 ? 7 : 0), MODE, FMT>(A, X); break;
+      case 0: fz_xchg<P, 0, MODE, FMT, GEO>(A, X); break;
+      case 1: if (P > 1) fz_xchg<P, (P > 1 ? 1 : 0), MODE, FMT, GEO>(A, X); break;
+      case 2: if (P > 2) fz_xchg<P, (P > 2 ? 2 : 0), MODE, FMT, GEO>(A, X); break;
+      case 3: if (P > 3) fz_xchg<P, (P > 3 ? 3 : 0), MODE, FMT, GEO>(A, X); break;
+      case 4: if (P > 4) fz_xchg<P, (P > 4 ? 4 : 0), MODE, FMT, GEO>(A, X); break;
+      case 5: if (P > 5) fz_xchg<P, (P > 5 ? 5 : 0), MODE, FMT, GEO>(A, X); break;
+      case 6: if (P > 6) fz_xchg<P, (P > 6 ? 6 : 0), MODE, FMT, GEO>(A, X); break;
+      case 7: if (P > 7) fz_xchg<P, (P > 7 ? 7 : 0), MODE, FMT, GEO>(A, X); break;
       default: break;
     }
   } else {
