@@ -399,18 +399,17 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   // Block k of this team is row block team + k*T.  Schedule of one block:
   //   step k-2 : prefetch burst          load(k)            -> register set k % 6
   //   step k   : row sums                P1(k)              -> y[k & 3]
-  //   step k+1 : publish                 granules of y(k)   (threads t < R)
-  //   step k+2 : partner loads issued    (before that step's burst; threads t < R)
+  //   step k+1 : publish                 granules of y(k)   (exchange waves)
+  //   step k+2 : partner loads issued    (exchange waves, before that step's burst)
   //   step k+3 : combine                 s[k & 1] = w / sum_q y_q ; y[k & 3] = 0
   //   step k+4 : scatter                 P2(k), set k % 6 is then refilled with block k+6
   // one barrier per step.
   const int64_t nblk = (A.nb > team) ? (A.nb - team + T - 1) / T : 0;
-  // Role split: wave 15 is the exchange wave (it holds no matrix entries, so it can afford the
-  // registers for two generations of partner values); waves 0-14 are data waves.  The vector-
-  // memory pipe of a CU is limited by the NUMBER of instructions in flight and returns in
-  // order, so every exchange access is 16 bytes wide, issued right after the barrier (ahead of
-  // the data waves' burst) and only waited for one step later, when the burst issued before it
-  // has landed anyway.
+  // Role split: the last 2-3 waves are exchange waves (they hold no matrix entries, so they can afford
+  // the registers for two generations of partner values); the others are data waves.  A CU's vector-
+  // memory pipe returns in order, so every exchange access is issued right after the barrier (ahead of
+  // the data waves' burst) and only waited for one step later, when the burst issued before it has
+  // landed anyway.
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   auto slot_of = [&](int64_t k, int q) -> unsigned long long* {
     return xbase + ((int64_t)(k & (FZ_XS - 1)) * P + q) * R;
