@@ -63,14 +63,14 @@ def main():
     kl, avg = kernel_table(one('trace/*/*_kernel_trace.csv'))
     with open(os.path.join(ROOT, 'profiles', prefix + '_fused_kernel_stats.txt'), 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats -- %s   (default workload; the run times the headline fp64\n'
-                '# layout k_em_fused<4, 0, 2> and then the 2-byte-code layout k_em_fused<4, 0, 1>)\n' % cmd)
+                '# layout k_em_fused<4, 0, 2, 0> and then the 2-byte-code layout k_em_fused<4, 0, 1, 0>;\n# template arguments: team size, mode (0 EM / 1 lnl), entry format, geometry)\n' % cmd)
         f.write('\n'.join(kl) + '\n')
     fl, fetch = pmc_table(one('fetch/*/*_counter_collection.csv'), 'FETCH_SIZE')
     wl, write = pmc_table(one('write/*/*_counter_collection.csv'), 'WRITE_SIZE')
     runs = []
     notes = []
     for fmts, vb in (((2, 0), 8), ((1,), 2)):                # kernel FMT 2 / 0: fp64 entries, FMT 1: 2-byte codes
-        name = next((n for n in ('k_em_fused<4, 0, %d>' % f for f in fmts) if n in fetch), None)
+        name = next((n for f in fmts for n in fetch if n.startswith('k_em_fused<4, 0, %d' % f)), None)
         if name is None:
             continue
         rd = 2.0 * fetch[name] * 1024.0
