@@ -237,7 +237,7 @@ __global__ void k_compact_rows(int64_t N, const uint8_t* __restrict__ cls, const
 // Counts order columns by popularity; (count, hash) identifies exact twin
 // columns (same rows, same scores) whose parameters the reference keeps
 // bit-identical (it accumulates every column in row order).
-constexpr int SIG_WIN = 8192;
+constexpr int SIG_WIN = 12288;      // 12 B of LDS per column: 147 KB
 __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, const int64_t* __restrict__ indptr,
     const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw, int col_base, int K,
     unsigned long long* __restrict__ counts, unsigned long long* __restrict__ hashes) {
