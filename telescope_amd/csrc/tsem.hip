@@ -348,6 +348,22 @@ __global__ __launch_bounds__(64) void k_block_greedy(int64_t na, int P, int R, i
   }
   if (!pass && lane == 0) cnt[ch] = n;
 }
+// sub-block sizes from the per-row part counts the block boundaries were computed from (one wave per block)
+__global__ __launch_bounds__(64) void k_sb_count_pc(int64_t nb, int P, const int64_t* __restrict__ bstart,
+    const unsigned long long* __restrict__ pc, int64_t* __restrict__ sb_cnt) {
+  const int64_t b = blockIdx.x;
+  int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t a = bstart[b] + threadIdx.x; a < bstart[b + 1]; a += 64) {
+    const unsigned long long lo = pc[2 * a], hi = pc[2 * a + 1];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] += (int)(((q < 4 ? lo : hi) >> (16 * (q & 3))) & 0xFFFF);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int t = sg_sum_i<64>(c[q]);
+    if (threadIdx.x == 0 && q < P) sb_cnt[b * P + q] = t;
+  }
+}
 __global__ void k_fixed_blocks(int64_t nb, int R, int64_t na, int64_t* __restrict__ bstart) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b <= nb) bstart[b] = min(na, b * R);
@@ -1504,8 +1520,8 @@ static int build_layout(tsem_ctx* h) {
   const int R = h->R;
   int64_t nb = 0;
   int64_t* d_bs = nullptr;                                 // first compact row of every block, [nb + 1]
+  unsigned long long* d_pc = nullptr;                      // per-row part counts (fused layout only)
   if (h->use_fused && na > 0 && P <= FZ_MAX_P) {
-    unsigned long long* d_pc = nullptr;
     TSEM_ALLOC(d_pc, 2 * na);
     k_row_partcounts<<<(unsigned)std::min<int64_t>(65535, (na + 15) / 16), 256, 0, h->stream>>>(
         na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc);
@@ -1540,7 +1556,8 @@ static int build_layout(tsem_ctx* h) {
       TSEM_HIP(hipMemcpyAsync(d_bs + nb, &na, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
       TSEM_HIP(hipStreamSynchronize(h->stream));
     }
-    (void)hipFree(d_pc); (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_flag);
+    (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_flag);
+    if (!h->use_fused) { (void)hipFree(d_pc); d_pc = nullptr; }
   }
   if (!d_bs) {                                             // two-pass layout: R rows per block
     nb = (na + R - 1) / R;
@@ -1557,20 +1574,22 @@ static int build_layout(tsem_ctx* h) {
                                                              h->d_slot_row, h->d_amb_wcode);
     else TSEM_HIP(hipMemsetAsync(h->d_amb_wcode, 0, sizeof(uint16_t) * h->N_amb_pad, h->stream));
     TSEM_HIP(hipGetLastError());
-    TSEM_HIP(hipStreamSynchronize(h->stream));
-    (void)hipFree(d_bs);
   }
   // 4. sub-block sizes -> offsets
   std::vector<int64_t> sb(nb * P + 1, 0);
   if (nb) {
     int64_t* d_cnt = nullptr;
     TSEM_ALLOC(d_cnt, nb * P);
-    k_sb_count<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_colmap, d_cnt);
+    if (d_pc) k_sb_count_pc<<<(unsigned)nb, 64, 0, h->stream>>>(nb, P, d_bs, d_pc, d_cnt);
+    else k_sb_count<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_colmap, d_cnt);
     TSEM_HIP(hipGetLastError());
     TSEM_HIP(hipMemcpyAsync(sb.data(), d_cnt, sizeof(int64_t) * nb * P, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
     (void)hipFree(d_cnt);
   }
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_bs);
+  if (d_pc) (void)hipFree(d_pc);
   if (h->use_fused) {
     int64_t mx = 0;
     for (int64_t i = 0; i < nb * P; ++i) mx = std::max(mx, sb[i]);
