@@ -439,17 +439,26 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
 __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
     const double* __restrict__ lut, const uint32_t* __restrict__ colmap, const int64_t* __restrict__ sb_off,
-    double* __restrict__ pval, uint16_t* __restrict__ pcode, uint32_t* __restrict__ prc) {
+    double* __restrict__ pval, uint16_t* __restrict__ pcode, uint32_t* __restrict__ prc,
+    const int64_t* __restrict__ bstart, const unsigned long long* __restrict__ pc) {
   __shared__ uint32_t cnt[512 * 8];                        // [row slot][part]: counts, then write cursors
   __shared__ uint32_t total[8], lastrow[8];
   const int64_t b = blockIdx.x;
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
   for (int t = threadIdx.x; t < R * P; t += blockDim.x) cnt[t] = 0;
   __syncthreads();
-  for (int lr = sub; lr < R; lr += subs) {
-    const int64_t i = amb_row[b * R + lr];
-    if (i < 0) continue;
-    for (int64_t k = indptr[i] + lane; k < indptr[i + 1]; k += RS_SUB) atomicAdd(&cnt[lr * P + (colmap[indices[k]] >> 16)], 1u);
+  if (pc) {                                                // the per-row part counts are already known
+    const int64_t a0 = bstart[b], n = bstart[b + 1] - a0;
+    for (int lr = threadIdx.x; lr < n; lr += blockDim.x) {
+      const unsigned long long lo = pc[2 * (a0 + lr)], hi = pc[2 * (a0 + lr) + 1];
+      for (int q = 0; q < P; ++q) cnt[lr * P + q] = (uint32_t)(((q < 4 ? lo : hi) >> (16 * (q & 3))) & 0xFFFF);
+    }
+  } else {
+    for (int lr = sub; lr < R; lr += subs) {
+      const int64_t i = amb_row[b * R + lr];
+      if (i < 0) continue;
+      for (int64_t k = indptr[i] + lane; k < indptr[i + 1]; k += RS_SUB) atomicAdd(&cnt[lr * P + (colmap[indices[k]] >> 16)], 1u);
+    }
   }
   __syncthreads();
   if (threadIdx.x < P) {                                   // exclusive scan down the rows, one thread per part
@@ -1587,9 +1596,6 @@ static int build_layout(tsem_ctx* h) {
     TSEM_HIP(hipStreamSynchronize(h->stream));
     (void)hipFree(d_cnt);
   }
-  TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_bs);
-  if (d_pc) (void)hipFree(d_pc);
   if (h->use_fused) {
     int64_t mx = 0;
     for (int64_t i = 0; i < nb * P; ++i) mx = std::max(mx, sb[i]);
@@ -1631,13 +1637,17 @@ static int build_layout(tsem_ctx* h) {
   }
   if (nb && h->use_fused && R <= 512 && P <= 8) {
     k_sb_fill_sorted<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
-                                                         h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc);
+                                                         h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
+                                                         d_pc ? d_bs : nullptr, d_pc);
     TSEM_HIP(hipGetLastError());
   } else if (nb) {
     k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                   h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc);
     TSEM_HIP(hipGetLastError());
   }
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_bs);
+  if (d_pc) (void)hipFree(d_pc);
   if (!h->use_fused) TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad);   // partial row sums of the two-pass kernels
   // launch geometry
   const size_t lds1 = (size_t)(Kp + R) * 8, lds2 = (size_t)(2 * Kp + R) * 8;
