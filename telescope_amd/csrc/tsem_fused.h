@@ -477,13 +477,17 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       double* yb = y + (k & (FZ_YR - 1)) * R;
       double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
       if (!idle) {
+        double2 q0 = rr.v0, q1 = rr.v1;
         if (FMT == 1) {                                   // Q from the score table: the same fp64 the fp64 layout stores
-          rr.v0 = make_double2(lutS[rr.cd.x & 0xFFFFu], lutS[rr.cd.x >> 16]);
-          rr.v1 = make_double2(lutS[rr.cd.y & 0xFFFFu], lutS[rr.cd.y >> 16]);
+          q0 = make_double2(lutS[rr.cd.x & 0xFFFFu], lutS[rr.cd.x >> 16]);
+          q1 = make_double2(lutS[rr.cd.y & 0xFFFFu], lutS[rr.cd.y >> 16]);
         }
-        m0 = rr.v0.x * c[rr.rc.x & 0xFFFF]; m1 = rr.v0.y * c[rr.rc.y & 0xFFFF];
-        m2 = rr.v1.x * c[rr.rc.z & 0xFFFF]; m3 = rr.v1.y * c[rr.rc.w & 0xFFFF];
-        if (!lnl) { rr.v0 = make_double2(m0, m1); rr.v1 = make_double2(m2, m3); }   // lnl keeps Q: phase 2 needs it twice
+        m0 = q0.x * c[rr.rc.x & 0xFFFF]; m1 = q0.y * c[rr.rc.y & 0xFFFF];
+        m2 = q1.x * c[rr.rc.z & 0xFFFF]; m3 = q1.y * c[rr.rc.w & 0xFFFF];
+        // EM: the set keeps the numerators for phase 2.  lnl: phase 2 needs Q itself (twice) — the fp64
+        // layout has it in the set already, the code layout looks it up again (2 registers per set
+        // instead of 8: with four log1p expansions in flight the lnl kernel would spill otherwise)
+        if (!lnl) { rr.v0 = make_double2(m0, m1); rr.v1 = make_double2(m2, m3); }
       }
       fz_row_sums(yb, idle, rr.rc.x >> 16, rr.rc.y >> 16, rr.rc.z >> 16, rr.rc.w >> 16, m0, m1, m2, m3);
       if (idle) rr.rc.x = 0xFFFFFFFFu;
@@ -497,7 +501,12 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
           const double z = (q * c[rc & 0xFFFF]) * sb[rc >> 16];
           if (z != 0.0) lsum += z * ts_log1p_pos(q * acc[rc & 0xFFFF]);
         };
-        term(rr.v0.x, rr.rc.x); term(rr.v0.y, rr.rc.y); term(rr.v1.x, rr.rc.z); term(rr.v1.y, rr.rc.w);
+        if (FMT == 1) {
+          term(lutS[rr.cd.x & 0xFFFFu], rr.rc.x); term(lutS[rr.cd.x >> 16], rr.rc.y);
+          term(lutS[rr.cd.y & 0xFFFFu], rr.rc.z); term(lutS[rr.cd.y >> 16], rr.rc.w);
+        } else {
+          term(rr.v0.x, rr.rc.x); term(rr.v0.y, rr.rc.y); term(rr.v1.x, rr.rc.z); term(rr.v1.y, rr.rc.w);
+        }
         return;
       }
       // all four gathers first: an LDS atomic may alias a later LDS read as far as the compiler knows,
