@@ -58,6 +58,7 @@ def parse():
     ap.add_argument('--block-rows', type=int, default=0)
     ap.add_argument('--chunk-blocks', type=int, default=0)
     ap.add_argument('--fused-dbg', type=int, default=0)
+    ap.add_argument('--sorted-fill', type=int, default=-1, help='sub-block order: 1 row order, 0 strand-transposed (-1 auto)')
     ap.add_argument('--geometry', type=int, default=-1, help='fused kernel geometry of teams of 1-4: 0 or 2 (-1 auto)')
     ap.add_argument('--parts', type=int, default=0, help='column parts per team (0 = fewest that fit LDS)')
     ap.add_argument('--hot-split', type=int, default=1, help='0: one accumulator slot per column (experiments)')
@@ -154,6 +155,8 @@ def main():
         eng.set_option('parts', args.parts)
     if args.geometry >= 0:
         eng.set_option('geometry', args.geometry)
+    if args.sorted_fill >= 0:
+        eng.set_option('sorted_fill', args.sorted_fill)
     if args.chunk_blocks:
         eng.set_option('chunk_blocks', args.chunk_blocks)
     if args.fused_dbg:

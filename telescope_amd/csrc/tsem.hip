@@ -1196,6 +1196,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "value_format") h->opt_format = v;
   else if (k == "hot_split") h->opt_hot_split = v;
   else if (k == "geometry") h->opt_geo = v;
+  else if (k == "sorted_fill") h->opt_sorted = v;
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
     if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
@@ -1440,8 +1441,9 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
       // row SLOTS per block: ~7 % above the average a register tile takes, so blocks end on the
       // tile's capacity, not on R (the exchange cost depends on R, hence not more than needed)
       // geometry: teams of 5-8 have one; smaller teams switch to three exchange waves when the rows
-      // are so short that 512 row slots cannot fill the register tile
-      h->geo = P > 4 ? 1 : (1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > fz_rmax(0) ? 2 : 0);
+      // are so short that 512 row slots cannot fill the register tile and the pass is bound by the
+      // exchange (fp64 entries; with score codes the 14th data wave is worth more)
+      h->geo = P > 4 ? 1 : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > fz_rmax(0) && !fz_wants_codes(h)) ? 2 : 0);
       if (h->opt_geo >= 0 && P <= 4) h->geo = h->opt_geo == 2 ? 2 : 0;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
@@ -1635,7 +1637,13 @@ static int build_layout(tsem_ctx* h) {
     TSEM_ALLOC(h->d_pval, off);
     TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
   }
-  if (nb && h->use_fused && R <= 512 && P <= 8) {
+  // Row order pays when the runs are long and the LDS is the limit (score codes): 40 nnz/row at P = 4
+  // 4.70 -> 4.06 ms; with runs of ~5 entries or with fp64 entries (HBM-bound) the plain order is as
+  // fast or faster (fewer VALU instructions): measured matrix in DESIGN.md 9.
+  const double run_len = na > 0 ? (double)(h->nnz - h->N_uni) / (double)na / P : 0.0;
+  h->sorted_layout = h->use_fused && R * P <= 512 * 8 &&   // (the fill kernel keeps R x P counters in LDS)
+                     (h->opt_sorted >= 0 ? h->opt_sorted != 0 : (h->fmt_code && run_len >= 8.0));
+  if (nb && h->sorted_layout) {
     k_sb_fill_sorted<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
                                                          d_pc ? d_bs : nullptr, d_pc);
@@ -1826,7 +1834,7 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
   A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
   A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc;
   A.ctab = mode ? h->d_ctab_prev : h->d_ctab; A.ctab2 = h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = mode;
-  A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg;
+  A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg; A.sorted = h->sorted_layout ? 1 : 0;
   A.sync = h->d_xflags;
   A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.dbg = (int)h->opt_dbg;
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;

@@ -93,7 +93,9 @@ struct tsem_ctx {
   int64_t* d_sb_off = nullptr;      // [nb*P+1] entry offsets (multiples of 4)
   double* d_pval = nullptr;         // [nnz_pad]  Q values (fp64 entry format)
   uint16_t* d_pcode = nullptr;      // [nnz_pad]  raw score codes (code16 entry format: Q = lut[code])
+  int64_t opt_sorted = -1;          // -1 auto, 0: strand-transposed sub-blocks, 1: row-ordered sub-blocks (fused layout)
   int64_t opt_geo = -1;             // -1 auto; 0 / 2 force the geometry of teams of 1-4 (experiments)
+  bool sorted_layout = false;       // sub-blocks stored in row order (k_sb_fill_sorted)
   int geo = 0;                      // fused kernel geometry (tsem_fused.h): exchange waves x row pairs per lane
   bool fmt_wcode = false;           // fp64 entries, but the score table sits in LDS for the row weights (kernel FMT 2)
   bool fmt_code = false;            // entry format of the blocked layout: false = fp64 values, true = 2-byte codes

@@ -80,6 +80,7 @@ struct FusedArgs {
   const double* ctab;
   const double* ctab2;  // lnl mode: pi*theta of the CURRENT params (ctab then holds the previous ones)
   double* lnl_out;      // lnl mode: one partial sum per workgroup [grid]
+  int sorted;           // 1: sub-blocks in row order (row sums reduced in registers), 0: strand-transposed (one atomic per entry)
   int lnl_mode;         // 0: EM pass (scatter w*z); 1: sum z(prev) * log1p(Q * c_cur)  (model.py:744-760)
   const double* wrow;   // [N_amb_pad] fragment weight w_i = max_j Q_ij (0 in the padding)
   double* partial;      // [team slots][P*Kp], zero-filled before launch
@@ -489,7 +490,12 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
         // instead of 8: with four log1p expansions in flight the lnl kernel would spill otherwise)
         if (!lnl) { rr.v0 = make_double2(m0, m1); rr.v1 = make_double2(m2, m3); }
       }
-      fz_row_sums(yb, idle, rr.rc.x >> 16, rr.rc.y >> 16, rr.rc.z >> 16, rr.rc.w >> 16, m0, m1, m2, m3);
+      if (A.sorted) {
+        fz_row_sums(yb, idle, rr.rc.x >> 16, rr.rc.y >> 16, rr.rc.z >> 16, rr.rc.w >> 16, m0, m1, m2, m3);
+      } else if (!idle) {                                  // strand-transposed order: neighbouring entries never share a row
+        lds_add(&yb[rr.rc.x >> 16], m0); lds_add(&yb[rr.rc.y >> 16], m1);
+        lds_add(&yb[rr.rc.z >> 16], m2); lds_add(&yb[rr.rc.w >> 16], m3);
+      }
       if (idle) rr.rc.x = 0xFFFFFFFFu;
     };
     // phase 2: scatter w * z into the part's column accumulators
