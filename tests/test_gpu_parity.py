@@ -484,6 +484,22 @@ def test_random_shapes_against_oracle(gpu_device, seed):
         assert np.array_equal(tl.reassign_colsums(method), np.asarray(om.reassign(method).sum(0)).ravel()), (method, ctx)
 
 
+def test_more_than_2_31_entries_on_one_gpu(gpu_device):
+    """60M x 30k x ~40 = 2.4e9 stored entries (> 2^31): 64-bit offsets everywhere; the fused kernel with
+    both entry formats and the two-pass kernels agree to summation-order noise."""
+    res = []
+    for options in ((('value_format', 1),), (('value_format', 2),), (('em_kernel', 1),)):
+        tl = _synthetic_tl(60_000_000, 30000, 40, 'zipf', options=options, opts=Opts(max_iter=3, em_epsilon=0.0))
+        tl.em()
+        assert tl._eng.dims()[2] > 2 ** 31
+        res.append((tl.lnl, tl.pi.copy(), tl.reassign_colsums('exclude'), tl._eng.layout_info()['fused']))
+        del tl
+    assert [r[3] for r in res] == [1, 1, 0]
+    for r in res[1:]:
+        assert abs(r[0] - res[0][0]) <= 1e-12 * abs(res[0][0])
+        assert np.allclose(r[1], res[0][1], rtol=1e-11, atol=0) and np.array_equal(r[2], res[0][2])
+
+
 def test_config3_entry_formats_agree(gpu_device):
     """BASELINE config 3 (10M x 30k x ~40) asks for a precision sweep of the stored values.  No reduced
     precision is offered: 2-byte score codes + the fp64 score table are SMALLER than fp32 values and give
