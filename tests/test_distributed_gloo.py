@@ -43,6 +43,10 @@ def _worker(rank, world, port, name, q):
             out['ra_' + meth] = tl.reassign_colsums(meth, 0.9, False)
         np.random.seed(int(c['seed']))
         out['ra_choose_init'] = tl.reassign_colsums('choose', 0.9, True)
+        np.random.seed(int(c['seed']))
+        a = tl.reassign('choose', 0.9)                     # the reference's call pattern: reassign(...).sum(0).A1
+        out['ra_assignment_choose'] = a.sum(0).A1
+        out['ra_assignment_shape'] = a.shape
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -76,4 +80,6 @@ def test_two_rank_gloo_matches_reference(name):
         for meth in ('average', 'conf'):
             assert np.allclose(r['ra_' + meth], c['ra_%s_0_colsum' % meth], rtol=1e-9, atol=1e-12)
         assert np.array_equal(r['ra_choose_init'], c['ra_choose_1_colsum'])
+        assert np.array_equal(r['ra_assignment_choose'], c['ra_choose_0_colsum'])
+        assert r['ra_assignment_shape'] == (r['rows'][1] - r['rows'][0], len(c['pi']))
     assert np.array_equal(a['pi'], b['pi'])
