@@ -108,7 +108,10 @@ class Assignment(object):
 class TelescopeLikelihood(object):
     """EM model over a fragments x loci score matrix (model.py:631-865)."""
 
-    def __init__(self, score_matrix, opts, device=None, comm=None, engine=None):
+    def __init__(self, score_matrix, opts, device=None, comm=None, engine=None, engine_options=None):
+        """`score_matrix`, `opts` as in the reference (model.py:635-662).  Extra keywords: `device`
+        (GPU index), `comm` (row-sharded runs, telescope_amd.distributed), `engine_options` — a dict for
+        `tsem_set_option`, e.g. {'value_format': 1} for fp64 entries (include/telescope_em.h)."""
         self.comm = comm if comm is not None else _NullComm()
         raw = sp.csr_matrix(score_matrix)
         if not raw.has_canonical_format:
@@ -134,6 +137,8 @@ class TelescopeLikelihood(object):
         if device is None:
             device = getattr(self.comm, 'device', 0)
         self._eng = engine if engine is not None else Engine(device)
+        for key, value in (engine_options or {}).items():
+            self._eng.set_option(key, int(value))
         if engine is None:
             self._eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16),
                                   self.K, self._lut)

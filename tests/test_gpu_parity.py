@@ -158,6 +158,16 @@ def test_public_estep_mstep_lnl(gpu_device, name):
     assert abs(l2 - float(c['x_lnl2'])) <= RTOL * abs(float(c['x_lnl2']))
 
 
+def test_engine_options_keyword(gpu_device):
+    c = load_case('bundled')
+    from telescope_amd.likelihood import TelescopeLikelihood
+    for fmt, nbytes in ((1, 8), (2, 2)):
+        tl = TelescopeLikelihood(case_matrix(c), Opts(c), engine_options={'value_format': fmt})
+        tl.em()
+        assert tl._eng.layout_info()['value_bytes'] == nbytes
+        assert abs(tl.lnl - float(c['lnl'])) <= RTOL * abs(float(c['lnl']))
+
+
 def test_error_behaviour(gpu_device):
     c = load_case('tiny_ties')
     tl = make_tl(case_matrix(c), Opts(c))
