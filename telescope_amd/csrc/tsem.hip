@@ -1111,8 +1111,11 @@ static fz_fn fz_kernel(int P, int mode, int fmt, int geo) {
 
 // code16 entry format: only with the fused kernel, and only while the score table is small enough to
 // sit in LDS beside the column tables (uint16 scores allow 65536 entries; alignments give a few hundred)
+// `auto` keeps fp64 entries for very short rows (< 4 entries per row and part): the pass is then bound by
+// the per-row exchange, and the fp64 layout's third exchange wave beats the smaller entries
+// (10 nnz/row at P = 4: 1.82 ms against 2.30 ms; 20 nnz/row: 2.59 against 2.68, where codes win on memory).
 static bool fz_wants_codes(const tsem_ctx* h) {
-  return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048;
+  return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048 && (h->opt_format == 2 || h->run_len_est >= 4.0);
 }
 static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
   return (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192 + (codes ? (size_t)h->lut_len * 8 : 0);
@@ -1435,6 +1438,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
     int R = 2048;
     h->geo = P > 4 ? 1 : 0;
+    h->run_len_est = na > 0 ? (double)(h->nnz - nu) / (double)na / P : 0.0;   // entries per ambiguous row and part
     if (h->use_fused && na > 0) {
       // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
       double mean_len = (double)(h->nnz - nu) / (double)na;

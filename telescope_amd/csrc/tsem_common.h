@@ -95,6 +95,7 @@ struct tsem_ctx {
   uint16_t* d_pcode = nullptr;      // [nnz_pad]  raw score codes (code16 entry format: Q = lut[code])
   int64_t opt_sorted = -1;          // -1 auto, 0: strand-transposed sub-blocks, 1: row-ordered sub-blocks (fused layout)
   int64_t opt_geo = -1;             // -1 auto; 0 / 2 force the geometry of teams of 1-4 (experiments)
+  double run_len_est = 0.0;         // mean entries per ambiguous row and column part (set by tsem_rowstats)
   bool sorted_layout = false;       // sub-blocks stored in row order (k_sb_fill_sorted)
   int geo = 0;                      // fused kernel geometry (tsem_fused.h): exchange waves x row pairs per lane
   bool fmt_wcode = false;           // fp64 entries, but the score table sits in LDS for the row weights (kernel FMT 2)
