@@ -64,6 +64,8 @@ def parse():
     ap.add_argument('--hot-split', type=int, default=1, help='0: one accumulator slot per column (experiments)')
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
     ap.add_argument('--cpu-iters', type=int, default=2)
+    ap.add_argument('--cpu-fused-rows', type=int, default=4_000_000,
+                    help='sample rows for the all-cores C baseline (oracle/em_fused.c); 0 skips it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-layout', action='store_true',
                     help='skip the second measurement with 2-byte score codes (N=1, default --value-format only)')
@@ -113,7 +115,25 @@ def cpu_baseline(args, dist_code, cdf):
     tlc.em()
     omc = OracleModel(sp.csr_matrix((rwc, ixc, ipc), shape=(nc, args.cols)), 0, 200000)
     omc.em(1e-7, 100)
-    return dict(nnz_per_sec=rate, sec_per_iter=dt / T, sample_nnz=nnz, sample_rows=n, iters=T,
+    fused_c = None
+    if args.cpu_fused_rows > 0:
+        try:   # a strong CPU baseline: the same EM as one fused OpenMP pass per iteration, all host cores
+            from oracle.em_fused import em_fused
+            nf = min(args.cpu_fused_rows, args.rows)
+            eng_f = Engine(0)
+            eng_f.generate(0, nf, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
+            ipf, ixf, rwf = eng_f.export_csr()
+            eng_f.close()
+            rawf = sp.csr_matrix((rwf, ixf, ipf), shape=(nf, args.cols))
+            em_fused(rawf, 0, 200000, 0.0, 1)                                  # warm the threads / page cache
+            t1 = time.perf_counter(); em_fused(rawf, 0, 200000, 0.0, 1); t1 = time.perf_counter() - t1
+            t5 = time.perf_counter(); r5 = em_fused(rawf, 0, 200000, 0.0, 5); t5 = time.perf_counter() - t5
+            per_iter = max(1e-9, (t5 - t1) / 4.0)                               # setup and the final lnl pass cancel out
+            fused_c = dict(nnz_per_sec=int(ipf[-1]) / per_iter, sec_per_iter=per_iter, sample_rows=nf,
+                           sample_nnz=int(ipf[-1]), cores=os.cpu_count(), lnl=float(r5['lnl']))
+        except Exception as e:   # noqa: BLE001 — the extra baseline must never break the bench line
+            fused_c = dict(error=repr(e))
+    return dict(nnz_per_sec=rate, sec_per_iter=dt / T, sample_nnz=nnz, sample_rows=n, iters=T, fused_c=fused_c,
                 lnl_ref=float(lnl_ref), lnl_gpu=float(tl.lnl),
                 lnl_rel_delta=abs(tl.lnl - lnl_ref) / abs(lnl_ref),
                 pi_max_rel_delta=float(np.max(np.abs(tl.pi - om.pi) / np.maximum(om.pi, 1e-300))),
@@ -276,6 +296,19 @@ def main():
             'nnz_per_sec': cb['nnz_per_sec'],
         }
         out['speedup_vs_cpu'] = out['nnz_per_sec'] / cb['nnz_per_sec']
+        fc = cb.get('fused_c')
+        if fc and 'nnz_per_sec' in fc:
+            out['cpu_baseline_fused_c'] = {
+                'value': fc['nnz_per_sec'] / nnz_total, 'unit': 'iter/s', 'cores': fc['cores'], 'kind': 'port',
+                'sample': 'oracle/em_fused.c (plain C restatement: one fused OpenMP pass over the CSR rows per iteration, '
+                          'thread-private column accumulators) on the first %d rows (%d nnz), all host cores: %.4f s/iter = '
+                          '%.3g nnz/s; value = that rate / workload nnz' % (fc['sample_rows'], fc['sample_nnz'],
+                                                                             fc['sec_per_iter'], fc['nnz_per_sec']),
+                'nnz_per_sec': fc['nnz_per_sec'],
+            }
+            out['speedup_vs_cpu_fused_c'] = out['nnz_per_sec'] / fc['nnz_per_sec']
+        elif fc:
+            out['cpu_baseline_fused_c'] = fc
         out['parity_on_sample'] = {k: cb[k] for k in ('lnl_ref', 'lnl_gpu', 'lnl_rel_delta', 'pi_max_rel_delta',
                                                       'final_count_mismatches', 'final_conf_max_rel_delta',
                                                       'sample_rows', 'iters', 'converged_run')}

@@ -1,0 +1,51 @@
+"""TEST INFRASTRUCTURE — ctypes loader of oracle/em_fused.c (the plain-C, OpenMP restatement of the EM
+loop).  Used by tests/ (a second oracle beside telescope_oracle.py) and by bench.py's cpu_baseline leg
+(a strong all-cores CPU number beside the reference-equivalent scipy one).  Never imported by telescope_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, '_build', 'libem_fused.so')
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            subprocess.run(['make', '-s', '-C', HERE], check=True)
+        L = C.CDLL(LIB)
+        vp, dbl = C.c_void_p, C.c_double
+        L.oracle_em_fused.restype = C.c_int
+        L.oracle_em_fused.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, dbl, dbl, dbl, C.c_int32, C.c_int32,
+                                      vp, vp, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def score_lut(max_score, scale=100.):
+    """Q for every raw score 0..max, with the reference's numpy expression (model.py:653, sparse_plus.py:89-91)."""
+    return np.expm1((np.arange(max_score + 1, dtype=np.uint16) * (1. / max_score)) * scale)
+
+
+def em_fused(raw, pi_prior=0, theta_prior=200000, epsilon=1e-7, max_iter=100, nthreads=0):
+    """EM on a scipy CSR of integer raw scores; returns dict(pi, theta, pi_init, lnl, n_iter, converged, diffs)."""
+    raw = raw.tocsr()
+    n, k = raw.shape
+    indptr = np.ascontiguousarray(raw.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(raw.indices, dtype=np.int32)
+    data = np.ascontiguousarray(raw.data, dtype=np.uint16)
+    lut = np.ascontiguousarray(score_lut(int(data.max())) if data.size else np.zeros(1))
+    pi, theta, pi_init = np.zeros(k), np.zeros(k), np.zeros(k)
+    lnl, conv = C.c_double(), C.c_int32()
+    diffs = np.zeros(max(1, max_iter))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    it = lib().oracle_em_fused(n, k, p(indptr), p(indices), p(data), p(lut), float(pi_prior), float(theta_prior),
+                               float(epsilon), int(max_iter), int(nthreads), p(pi), p(theta), p(pi_init),
+                               C.addressof(lnl), C.addressof(conv), p(diffs))
+    if it < 0:
+        raise MemoryError('oracle_em_fused')
+    return dict(pi=pi, theta=theta, pi_init=pi_init, lnl=lnl.value, n_iter=it, converged=bool(conv.value), diffs=diffs[:it])
