@@ -492,6 +492,9 @@ def test_random_shapes_against_oracle(gpu_device, seed):
     assert np.allclose(tl.theta, om.theta, rtol=RTOL, atol=1e-300), ctx
     for method in ('exclude', 'all', 'unique'):
         assert np.array_equal(tl.reassign_colsums(method), np.asarray(om.reassign(method).sum(0)).ravel()), (method, ctx)
+    from oracle.em_fused import em_fused                  # the independently written C restatement agrees too
+    rc = em_fused(raw, o.pi_prior, o.theta_prior, 0.0, o.max_iter)
+    assert np.allclose(tl.pi, rc['pi'], rtol=RTOL, atol=1e-300) and abs(tl.lnl - rc['lnl']) <= RTOL * max(abs(rc['lnl']), 1e-300), ctx
 
 
 def test_more_than_2_31_entries_on_one_gpu(gpu_device):
