@@ -513,6 +513,143 @@ def test_more_than_2_31_entries_on_one_gpu(gpu_device):
         assert np.allclose(r[1], res[0][1], rtol=1e-11, atol=0) and np.array_equal(r[2], res[0][2])
 
 
+class _ThreadComm(object):
+    """Two 'ranks' as two threads of this process, each with its own engine on the SAME GPU (null stream,
+    so their kernels serialise): the collectives of telescope_amd.distributed.Comm on shared memory.
+    Exercises the whole row-sharded protocol — global score table, setup sums, column signatures, the
+    per-iteration all-reduce of the device reduce buffers, lnl, reassign sums, choose picks — on real
+    engines, which the 2-rank gloo test can only do with the oracle standing in for the device."""
+    import threading
+    _lock = threading.Lock()
+
+    def __init__(self, rank, world, shared):
+        import threading
+        self.rank, self.world, self.sh = rank, world, shared
+        self.device = 0
+
+    def _exchange(self, key, value, combine):
+        sh = self.sh
+        sh['slots'][self.rank] = value
+        sh['barrier'].wait()
+        if self.rank == 0:
+            sh[key] = combine(sh['slots'])
+        sh['barrier'].wait()
+        out = sh[key]
+        sh['barrier'].wait()
+        return out
+
+    def max_scalar(self, v):
+        return int(self._exchange('r', int(v), lambda xs: max(xs)))
+
+    def sum_array(self, a):
+        return self._exchange('r', np.asarray(a, np.float64), lambda xs: np.sum(xs, axis=0)).copy()
+
+    def max_array(self, a):
+        return self._exchange('r', np.asarray(a, np.float64), lambda xs: np.max(xs, axis=0)).copy()
+
+    def sum_array_u64(self, a):
+        return self._exchange('r', np.asarray(a, np.uint64), lambda xs: np.sum(np.array(xs, dtype=np.uint64), axis=0,
+                                                                               dtype=np.uint64)).copy()
+
+    def gather_rows(self, a):
+        return self._exchange('r', np.asarray(a), lambda xs: list(xs))
+
+    def scatter_rows(self, parts):
+        return self._exchange('r', parts if self.rank == 0 else None, lambda xs: xs[0])[self.rank]
+
+    def barrier(self):
+        self.sh['barrier'].wait()
+
+    def attach(self, engine, n_cols):
+        import torch
+        self._red = torch.zeros(n_cols + 2, dtype=torch.float64, device='cuda:0')
+        self.sh['red'][self.rank] = self._red
+        engine.bind_reduce_buffer(self._red.data_ptr(), n_cols + 2)
+
+    def allreduce_device(self, engine, offset=0, count=None):
+        import torch
+        sh = self.sh
+        sh['barrier'].wait()
+        if self.rank == 0:
+            torch.cuda.synchronize()
+            tot = sh['red'][0] + sh['red'][1]
+            for r in sh['red']:
+                r.copy_(tot)
+            torch.cuda.synchronize()
+        sh['barrier'].wait()
+
+
+@pytest.mark.parametrize('fmt', [1, 2])
+def test_two_row_shards_on_one_gpu(gpu_device, fmt):
+    """Row-sharded EM with two real engines (rows split 45 / 55 %) against one engine on all rows."""
+    import threading
+    from telescope_amd import _lib, synthetic
+    from telescope_amd.likelihood import TelescopeLikelihood
+    N, K = 300000, 30000
+    cdf = synthetic.poisson_cdf_u32(24)
+    o = Opts(max_iter=6, em_epsilon=0.0)
+
+    def make(r0, r1, comm):
+        eng = _lib.Engine(0)
+        eng.set_option('value_format', fmt)
+        eng.set_option('row_offset', r0)
+        eng.generate(r0, r1, K, cdf, 9, synthetic.DIST_CODE['zipf'], 0.08)
+        return TelescopeLikelihood.from_engine(eng, o, comm)
+
+    ref = make(0, N, None)
+    ref.em()
+    np.random.seed(4); ref_choose = ref.reassign_colsums('choose')
+    ref_excl, ref_conf = ref.reassign_colsums('exclude'), ref.reassign_colsums('conf')
+    shared = dict(slots=[None, None], barrier=threading.Barrier(2), red=[None, None])
+    cut = int(N * 0.45)
+    out, errs = [None, None], []
+
+    def worker(rank):
+        try:
+            comm = _ThreadComm(rank, 2, shared)
+            tl = make(0 if rank == 0 else cut, cut if rank == 0 else N, comm)
+            tl.em()
+            if rank == 0:
+                np.random.seed(4)                          # only rank 0 draws (it holds the RNG stream)
+            out[rank] = dict(pi=tl.pi.copy(), theta=tl.theta.copy(), lnl=tl.lnl, n=tl.N,
+                             choose=tl.reassign_colsums('choose'), excl=tl.reassign_colsums('exclude'),
+                             conf=tl.reassign_colsums('conf'))
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+            shared['barrier'].abort()
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errs, errs
+    assert out[0]['n'] + out[1]['n'] == N
+    for r in out:                                          # every rank holds the global result
+        assert abs(r['lnl'] - ref.lnl) <= 1e-12 * abs(ref.lnl)
+        assert np.allclose(r['pi'], ref.pi, rtol=1e-11, atol=0) and np.allclose(r['theta'], ref.theta, rtol=1e-11, atol=0)
+        assert np.array_equal(r['excl'], ref_excl) and np.array_equal(r['choose'], ref_choose)
+        assert np.allclose(r['conf'], ref_conf, rtol=1e-10, atol=1e-12)
+    assert np.array_equal(out[0]['pi'], out[1]['pi'])
+
+
+def test_full_size_properties(gpu_device):
+    """BASELINE config 4 (50M x 30k x ~40, 5 % unique rows) through size-independent properties:
+    pi and theta are distributions; `all` counts every stored entry, `unique` every unique row, `choose`
+    and `average` one per fragment; `exclude` never exceeds `choose` on any locus."""
+    tl = _synthetic_tl(50_000_000, 30000, 40, 'zipf', uniq=0.05, opts=Opts(max_iter=3, em_epsilon=0.0))
+    tl.em()
+    n, k, nnz = tl._eng.dims()
+    info = tl._eng.layout_info()
+    assert abs(tl.pi.sum() - 1.0) <= 1e-12 and abs(tl.theta.sum() - 1.0) <= 1e-12
+    assert np.all(tl.pi > 0) and np.isfinite(tl.lnl)
+    assert int(tl.reassign_colsums('all').sum()) == nnz
+    assert int(tl.reassign_colsums('unique').sum()) == info['N_uni'] == n - info['N_amb']
+    np.random.seed(2)
+    choose, excl = tl.reassign_colsums('choose'), tl.reassign_colsums('exclude')
+    assert int(choose.sum()) == n and np.all(excl <= choose) and int(excl.sum()) <= n
+    assert abs(tl.reassign_colsums('average').sum() - n) <= 1e-9 * n
+    conf = tl.reassign_colsums('conf', 0.9)
+    assert 0 < conf.sum() <= n * (1 + 1e-12)
+
+
 def test_config3_entry_formats_agree(gpu_device):
     """BASELINE config 3 (10M x 30k x ~40) asks for a precision sweep of the stored values.  No reduced
     precision is offered: 2-byte score codes + the fp64 score table are SMALLER than fp32 values and give
