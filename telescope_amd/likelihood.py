@@ -328,13 +328,15 @@ class TelescopeLikelihood(object):
         nbest = self._eng.best_counts(which)
         parts = self.comm.gather_rows(nbest)
         if self.comm.rank == 0:
-            allnb = np.concatenate(parts)
-            picks = np.zeros(len(allnb), dtype=np.int32)
-            multi = np.nonzero(allnb > 1)[0]
-            if multi.size:
+            allnb = parts[0] if len(parts) == 1 else np.concatenate(parts)
+            multi = np.flatnonzero(allnb > 1)
+            if multi.size == 0:                               # no row has a tie: nothing to draw, nothing to ship
+                parts = [None] * len(parts)
+            else:
+                picks = np.zeros(len(allnb), dtype=np.int32)
                 picks[multi] = np.random.randint(0, allnb[multi])
-            cuts = np.cumsum([len(p) for p in parts])[:-1]
-            parts = np.split(picks, cuts)
+                cuts = np.cumsum([len(p) for p in parts])[:-1]
+                parts = np.split(picks, cuts)
         return self.comm.scatter_rows(parts)
 
     def reassign_colsums(self, method, thresh=0.9, initial=False):
