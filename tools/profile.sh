@@ -14,6 +14,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $
 python tools/fused_prof.py 20000000 value_format=2 > $OUT/timeline_code16.txt 2>&1
 python tools/fused_prof.py 20000000 value_format=1 > $OUT/timeline_f64.txt 2>&1
 tools/ubench/lds > $OUT/lds_ubench.log 2>&1
+tools/ubench/stream > $OUT/stream_ubench.log 2>&1
 python bench.py --steps 20 --warmup 3 > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log > $OUT/bench.json
 find $OUT -name "*.csv" | head -40
