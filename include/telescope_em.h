@@ -180,6 +180,8 @@ int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launch
 int  tsem_layout_info(tsem_ctx* h, int64_t* info16);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
+/* the packed local row / local column words of one sub-block of the blocked layout (layout studies) */
+int64_t tsem_debug_subblock(tsem_ctx* h, int64_t block, int32_t part, uint32_t* out, int64_t cap);
 /* y[i] = the device log1p the lnl passes use (finite x >= 0), for accuracy tests against libm */
 int  tsem_debug_log1p(int device, int32_t n, const double* x, double* y);
 

@@ -115,6 +115,8 @@ def lib():
     L.tsem_layout_info.argtypes = [vp, vp]
     L.tsem_debug_fused_prof.argtypes = [vp, vp]
     L.tsem_debug_log1p.argtypes = [C.c_int, C.c_int32, vp, vp]
+    L.tsem_debug_subblock.argtypes = [vp, C.c_int64, C.c_int32, vp, C.c_int64]
+    L.tsem_debug_subblock.restype = C.c_int64
     for name in exported_symbols():
         fn = getattr(L, name)
         if name not in ('tsem_destroy', 'tsem_last_error'):
@@ -338,6 +340,13 @@ class Engine(object):
         out = np.zeros((64, 16), np.uint64)
         self._ck(self._L.tsem_debug_fused_prof(self._h, ptr(out)))
         return out
+
+    def debug_subblock(self, block, part, cap=8192):
+        out = np.zeros(cap, np.uint32)
+        n = self._L.tsem_debug_subblock(self._h, int(block), int(part), ptr(out), cap)
+        if n < 0:
+            raise EngineError('tsem_debug_subblock failed (%d)' % n)
+        return out[:n]
 
     def layout_info(self):
         info = np.zeros(16, np.int64)

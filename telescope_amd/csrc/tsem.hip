@@ -2325,6 +2325,16 @@ int tsem_debug_log1p(int device, int32_t n, const double* x, double* y) {
   return e == hipSuccess ? TSEM_OK : TSEM_ERR_HIP;
 }
 
+/* debug: the packed (local row << 16 | local column) words of sub-block (block, part); returns their number */
+int64_t tsem_debug_subblock(tsem_ctx* h, int64_t block, int32_t part, uint32_t* out, int64_t cap) {
+  if (!h || !h->d_prc || !h->d_sb_off || block < 0 || block >= h->nb || part < 0 || part >= h->P) return TSEM_ERR_ARG;
+  int64_t o[2];
+  if (hipMemcpy(o, h->d_sb_off + block * h->P + part, 16, hipMemcpyDeviceToHost) != hipSuccess) return TSEM_ERR_HIP;
+  const int64_t n = std::min(cap, o[1] - o[0]);
+  if (n > 0 && hipMemcpy(out, h->d_prc + o[0], sizeof(uint32_t) * n, hipMemcpyDeviceToHost) != hipSuccess) return TSEM_ERR_HIP;
+  return n;
+}
+
 int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   if (!h || !info) return TSEM_ERR_ARG;
   info[0] = h->P; info[1] = h->Kp; info[2] = h->R; info[3] = h->nb;
