@@ -234,7 +234,7 @@ def test_against_oracle_midsize_seeded(gpu_device):
 
 
 @pytest.mark.parametrize('dist', ['zipf', 'uniform'])
-def test_full_size_properties(gpu_device, dist):
+def test_config3_properties_and_shard_linearity(gpu_device, dist):
     """BASELINE config 3 shape (10M x 30k, ~40 nnz/row): size-independent checks.
        * sum(pi) = sum(theta) = 1: every ambiguous fragment's posteriors sum to 1, so the
          column sums add up to the total weight (a checksum of checksums);
@@ -630,7 +630,7 @@ def test_two_row_shards_on_one_gpu(gpu_device, fmt):
     assert np.array_equal(out[0]['pi'], out[1]['pi'])
 
 
-def test_full_size_properties(gpu_device):
+def test_config4_full_size_properties(gpu_device):
     """BASELINE config 4 (50M x 30k x ~40, 5 % unique rows) through size-independent properties:
     pi and theta are distributions; `all` counts every stored entry, `unique` every unique row, `choose`
     and `average` one per fragment; `exclude` never exceeds `choose` on any locus."""
