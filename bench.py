@@ -190,13 +190,10 @@ def main():
     _, _, nnz_local = eng.dims()
 
     def run(n):
-        if comm is None:
-            eng.em_steps(n, want_diffs=False)
-        else:
-            for _ in range(n):
-                eng.em_pass()
-                comm.allreduce_device(eng, 0, args.cols)
-                eng.em_update(want_diff=False)
+        # exactly what TelescopeLikelihood.em() runs per chunk of iterations (likelihood.py): pass, in-library
+        # RCCL all-reduce (N > 1 / --force-comm), update and the device-side convergence test (never true at
+        # em_epsilon = 0), one host synchronisation per call
+        eng.em_chunk(n, 0.0, False)
 
     def fence():
         eng.synchronize()
@@ -206,7 +203,8 @@ def main():
             comm.barrier()
             torch.cuda.synchronize()
 
-    run(args.warmup)
+    if args.warmup:
+        run(args.warmup)
     eng.kernel_stats(reset=True)
     fence()
     t0 = time.perf_counter()
@@ -238,7 +236,7 @@ def main():
                         'pi_prior=0 theta_prior=200000, em_epsilon=0 (fixed iterations)'
                         % (total_rows // 1_000_000, args.cols // 1000, args.nnz_row, args.dist),
             'rows': total_rows, 'cols': args.cols, 'nnz': nnz_total, 'dist': args.dist, 'seed': args.seed,
-            'parallelism': 'row-sharded x%d, 1 all-reduce(K f64)/iter' % world if world > 1 else 'single GPU',
+            'parallelism': ('row-sharded x%d, 1 in-library RCCL all-reduce(K+2 f64)/iter' % world) if comm is not None else 'single GPU',
             'em_kernel': args.em_kernel, 'layout': info,
             'value_format': 'code16+lut (6 B/nnz stored)' if info.get('value_bytes') == 2 else 'f64 (12 B/nnz stored)', 'setup_s': round(t_setup, 3),
         },
@@ -262,11 +260,11 @@ def main():
         tl2 = TelescopeLikelihood.from_engine(eng2, Opts(args.steps), None)
         info2 = eng2.layout_info()
         if info2.get('value_bytes') == 2:
-            eng2.em_steps(args.warmup, want_diffs=False)
+            eng2.em_chunk(max(1, args.warmup), 0.0, False)
             eng2.kernel_stats(reset=True)
             eng2.synchronize()
             t0 = time.perf_counter()
-            eng2.em_steps(args.steps, want_diffs=False)
+            eng2.em_chunk(args.steps, 0.0, False)
             eng2.synchronize()
             el2 = time.perf_counter() - t0
             ks2 = eng2.kernel_stats()
@@ -337,6 +335,10 @@ def _pmc_traffic(total_rows, args, world, value_bytes):
 def _shutdown(comm):
     if comm is not None:
         import torch.distributed as dist
+        try:
+            comm.close()                    # the library's RCCL communicator
+        except Exception:   # noqa: BLE001
+            pass
         try:
             dist.destroy_process_group()
         except Exception:   # noqa: BLE001 — never let teardown hide the result line

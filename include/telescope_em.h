@@ -14,8 +14,11 @@
  *     tsem_last_error).  No exceptions or abort() cross the boundary.
  *   - one handle == one GPU == one host thread (not thread-safe).  Multi-GPU is
  *     one process per GPU; the only per-iteration exchange is a sum all-reduce
- *     of the reduce buffer (K+2 doubles), done by the host over RCCL between
- *     tsem_em_pass() and tsem_em_update().
+ *     of the reduce buffer (K+2 doubles: the per-locus column sums and an error
+ *     flag).  With a communicator attached (tsem_comm_*) the library issues it
+ *     itself — ncclAllReduce (RCCL over xGMI) on the engine's stream between the
+ *     EM pass and the parameter update, no host round trip (tsem_em_chunk).  A
+ *     host may instead do it between tsem_em_pass() and tsem_em_update().
  *   - host pointers are borrowed for the duration of the call; the library owns
  *     all device memory except a reduce buffer bound with
  *     tsem_bind_reduce_buffer().
@@ -48,6 +51,9 @@ extern "C" {
 #define TSEM_Z_PREV     0   /* params before the last M-step == reference self.z (model.py:795) */
 #define TSEM_Z_CUR      1   /* current params */
 #define TSEM_Z_INITIAL  2   /* Q.norm(1), model.py:837 (initial=True)      */
+#define TSEM_Z_USER     4   /* the z installed with tsem_set_user_z, used as is (a caller assigned tl.z, model.py:837) */
+#define TSEM_Z_FIRST    3   /* tsem_get_params only: params after the FIRST iteration of the last run
+                               == pi_init / theta_init (model.py:776-778) */
 
 /* EM kernel selection (tsem_set_option "em_kernel") */
 #define TSEM_EMK_AUTO     0
@@ -113,7 +119,7 @@ int  tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0,
 
 /* ---- parameters ---------------------------------------------------------- */
 int  tsem_set_params(tsem_ctx* h, const double* pi, const double* theta);
-int  tsem_get_params(tsem_ctx* h, int which /*TSEM_Z_PREV|TSEM_Z_CUR*/, double* pi, double* theta);
+int  tsem_get_params(tsem_ctx* h, int which /*TSEM_Z_PREV|TSEM_Z_CUR|TSEM_Z_FIRST*/, double* pi, double* theta);
 
 /* ---- EM iteration (estep model.py:702-722 + mstep 724-742, fused) ---------
  * tsem_em_pass: local fused E+M over this rank's rows with the current
@@ -130,24 +136,73 @@ int  tsem_em_pass(tsem_ctx* h);
 int  tsem_em_update(tsem_ctx* h, double* diff_est);
 int  tsem_lnl_pass(tsem_ctx* h);
 int  tsem_read_reduce(tsem_ctx* h, double* out, int64_t offset, int64_t count);
-/* n fixed iterations (pass+update) with no host round trip; the per-iteration
- * diff_est values are left in a device ring and copied out at the end.
- * Single-rank only (no exchange step).  == em() with em_epsilon=0, max_iter=n. */
+/* n fixed iterations (pass [+ all-reduce] + update) with no host round trip; the
+ * per-iteration diff_est values are left in a device ring and copied out at the
+ * end.  == em() with em_epsilon=0, max_iter=n. */
 int  tsem_em_steps(tsem_ctx* h, int32_t n, double* diffs_out /* n or NULL */);
-/* Full single-rank EM loop (model.py:762-806). */
+/* The loop body of em() (model.py:771-797) for up to n_max iterations, enqueued
+ * back to back: fused E+M pass, column reduce, all-reduce (communicator
+ * attached), parameter update; with use_likelihood also the lnl pass, its
+ * all-reduce and the |lnl - lnl_prev| test.  Convergence (diff_est < epsilon,
+ * or the lnl test) is decided ON THE DEVICE: the update kernel raises a stop
+ * flag and every kernel enqueued behind it returns at once, so the host
+ * synchronises once per chunk, not once per iteration, and the state after the
+ * call is exactly the reference's after its last iteration.  first != 0 starts
+ * a run (lnl_prev = inf, the next update saves pi_init / theta_init).
+ * *n_done = iterations committed, *stopped = 1 when the convergence test fired.
+ * A hand-off time-out of the fused kernel on ANY rank (the flag travels in the
+ * all-reduce) leaves the parameters untouched on every rank; the failing rank
+ * rebuilds its layout for the two-pass kernels and the iteration is redone. */
+int  tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likelihood, int32_t first,
+                   int32_t* n_done, int32_t* stopped, double* diffs_out /* n_max or NULL */,
+                   double* lnls_out /* n_max or NULL */);
+/* Switch this handle to the two-pass kernels (rebuilds the blocked layout, keeps the parameters): what
+ * tsem_em_chunk does after a time-out; public for hosts that drive pass / update themselves. */
+int  tsem_fallback_twopass(tsem_ctx* h);
+/* After tsem_em_update returned TSEM_ERR_TIMEOUT (every rank does, the flag is all-reduced): the rank whose
+ * own fused pass raised the error word switches to the two-pass kernels (*switched = 1), the others do
+ * nothing; then every rank redoes the pass. */
+int  tsem_recover_timeout(tsem_ctx* h, int32_t* switched);
+/* calculate_lnl(z(prev params), current params) (model.py:800-801), summed over the ranks of an attached
+ * communicator; synchronous.  Redone on the two-pass kernels after a time-out of the fused pass. */
+int  tsem_final_lnl(tsem_ctx* h, double* lnl);
+/* Full EM loop (model.py:762-806) on top of tsem_em_chunk. */
 int  tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likelihood,
                  int32_t* n_iter, int32_t* converged, double* lnl,
                  double* diffs /* max_iter */, double* lnls /* max_iter or NULL */,
                  double* pi_init, double* theta_init /* K each or NULL */);
 
+/* ---- communicator (row-sharded runs) ---------------------------
+ * One RCCL communicator per process / GPU, created from an id that rank 0
+ * generates and the host ships to the other ranks by any means (the Python
+ * host uses its torch.distributed group).  Attached to a handle, it makes
+ * tsem_em_chunk / tsem_em_steps / tsem_em_run all-reduce the reduce buffer
+ * (sum, fp64, K+2) and the log-likelihood scalar on the handle's stream.
+ * tsem_comm_allreduce_host: in-place sum of a host fp64 / uint64 vector over the
+ * communicator (setup sums, reassign column sums).  */
+#define TSEM_COMM_ID_BYTES 128
+typedef struct tsem_comm tsem_comm;
+int  tsem_comm_unique_id(void* id128);
+int  tsem_comm_create(tsem_comm** out, int device, const void* id128, int rank, int world);
+void tsem_comm_destroy(tsem_comm* c);
+const char* tsem_comm_last_error(void);
+int  tsem_comm_attach(tsem_ctx* h, tsem_comm* c);             /* c == NULL detaches */
+int  tsem_comm_allreduce(tsem_ctx* h, int64_t offset, int64_t count);   /* reduce buffer [offset, offset+count), async */
+int  tsem_comm_allreduce_host(tsem_comm* c, void* data, int64_t count, int dtype /*0 f64 sum, 1 u64 sum, 2 f64 max, 3 i64 max*/);
+
 /* ---- results -------------------------------------------------------------- */
 /* z aligned to the CSR pattern of the loaded scores (-1 where the reference
  * drops the entry from z's pattern, i.e. where Q_ij * pi_j[*theta_j] == 0).  model.py:795 / 837.  */
 int  tsem_export_z(tsem_ctx* h, int which, double* z /* nnz */);
+/* install (z != NULL) or drop (NULL) a caller-supplied z aligned to the CSR pattern, NaN where z has no
+ * entry: `which` = TSEM_Z_USER then makes reassign / best_counts / reassign_groups read it as is, without
+ * renormalising — what the reference does with whatever `self.z` holds (model.py:837) */
+int  tsem_set_user_z(tsem_ctx* h, const double* z /* nnz or NULL */);
 /* estep on explicit params (public estep(pi,theta), model.py:702-722) */
 int  tsem_estep(tsem_ctx* h, const double* pi, const double* theta, double* z /* nnz */);
 /* public mstep(z) (model.py:724-742) and calculate_lnl(z,pi,theta) (744-760) on a
- * caller-supplied z aligned to the CSR pattern (0 where z has no entry) */
+ * caller-supplied z aligned to the CSR pattern (0 where z has no entry); with a communicator
+ * attached both sum over the ranks' row shards before the closed forms / the return */
 int  tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat);
 int  tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* theta, double* lnl);
 /* rows' best-hit counts for `choose` (sparse_plus.py:117-129): nbest[i] */

@@ -49,12 +49,17 @@ int oracle_em_fused(int64_t N, int32_t K, const int64_t* indptr, const int32_t* 
   double* w = (double*)malloc(sizeof(double) * (N > 0 ? N : 1));
   if (!acc || !pisum0 || !c || !pin || !thn || !w) return -1;
   double W_tot = 0.0, W_amb = 0.0, w_max = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : W_tot, W_amb) reduction(max : w_max)
   for (int64_t i = 0; i < N; ++i) {                                   /* model.py:679-699 */
     double m = 0.0;
     for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) { double q = lut[raw[k]]; if (q > m) m = q; }
     w[i] = m; W_tot += m; if (m > w_max) w_max = m;
     if (indptr[i + 1] - indptr[i] > 1) W_amb += m;
-    else for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) pisum0[indices[k]] += lut[raw[k]];
+    else for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+      const double q = lut[raw[k]];
+#pragma omp atomic
+      pisum0[indices[k]] += q;
+    }
   }
   const double tp = theta_prior * w_max, pp = pi_prior * w_max;
   for (int j = 0; j < K; ++j) pi[j] = theta[j] = 1.0 / K;             /* model.py:667,673 */
@@ -118,4 +123,33 @@ int oracle_em_fused(int64_t N, int32_t K, const int64_t* indptr, const int32_t* 
   if (converged) *converged = conv;
   free(acc); free(pisum0); free(c); free(pin); free(thn); free(w);
   return it;
+}
+
+/* reassign('exclude').sum(0) (model.py:837-842, sparse_plus.py:99-129) with z = estep(pi, theta) computed row by
+ * row: counts[j] = number of rows whose UNIQUE largest posterior sits in column j (rows whose maximum is shared
+ * by several entries are dropped).  Entries whose numerator is exactly 0 are not in z's pattern (model.py:720).
+ * Returns 0. */
+int oracle_exclude_counts(int64_t N, int32_t K, const int64_t* indptr, const int32_t* indices, const uint16_t* raw,
+                          const double* lut, const double* pi, const double* theta, int64_t* counts) {
+  (void)K;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t s = indptr[i], e = indptr[i + 1];
+    const int amb = (e - s) > 1;
+    double sum = 0.0;
+    for (int64_t k = s; k < e; ++k) sum += lut[raw[k]] * (amb ? pi[indices[k]] * theta[indices[k]] : pi[indices[k]]);
+    const double r = recip0(sum);
+    double zmax = -1.0; int nbest = 0; int64_t kbest = -1;
+    for (int64_t k = s; k < e; ++k) {
+      const double n = lut[raw[k]] * (amb ? pi[indices[k]] * theta[indices[k]] : pi[indices[k]]);
+      if (n == 0.0) continue;
+      const double z = n * r;
+      if (z > zmax) { zmax = z; nbest = 1; kbest = k; } else if (z == zmax) ++nbest;
+    }
+    if (nbest == 1) {
+#pragma omp atomic
+      counts[indices[kbest]] += 1;
+    }
+  }
+  return 0;
 }

@@ -22,6 +22,8 @@ def lib():
         L.oracle_em_fused.restype = C.c_int
         L.oracle_em_fused.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, dbl, dbl, dbl, C.c_int32, C.c_int32,
                                       vp, vp, vp, vp, vp, vp]
+        L.oracle_exclude_counts.restype = C.c_int
+        L.oracle_exclude_counts.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -34,10 +36,29 @@ def score_lut(max_score, scale=100.):
 def em_fused(raw, pi_prior=0, theta_prior=200000, epsilon=1e-7, max_iter=100, nthreads=0):
     """EM on a scipy CSR of integer raw scores; returns dict(pi, theta, pi_init, lnl, n_iter, converged, diffs)."""
     raw = raw.tocsr()
-    n, k = raw.shape
-    indptr = np.ascontiguousarray(raw.indptr, dtype=np.int64)
-    indices = np.ascontiguousarray(raw.indices, dtype=np.int32)
-    data = np.ascontiguousarray(raw.data, dtype=np.uint16)
+    return em_fused_arrays(raw.indptr, raw.indices, raw.data, raw.shape[1], pi_prior, theta_prior, epsilon, max_iter, nthreads)
+
+
+def exclude_counts(indptr, indices, data, k, pi, theta, max_score=None):
+    """reassign('exclude').sum(0) for z = estep(pi, theta) (oracle_exclude_counts in em_fused.c)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    data = np.ascontiguousarray(data, dtype=np.uint16)
+    lut = np.ascontiguousarray(score_lut(int(max_score if max_score is not None else data.max())))
+    pi = np.ascontiguousarray(pi, dtype=np.float64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    counts = np.zeros(k, np.int64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib().oracle_exclude_counts(len(indptr) - 1, int(k), p(indptr), p(indices), p(data), p(lut), p(pi), p(theta), p(counts))
+    return counts
+
+
+def em_fused_arrays(indptr, indices, data, k, pi_prior=0, theta_prior=200000, epsilon=1e-7, max_iter=100, nthreads=0):
+    """The same on raw CSR arrays (no scipy object, no copies when the dtypes already match)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    data = np.ascontiguousarray(data, dtype=np.uint16)
+    n = len(indptr) - 1
     lut = np.ascontiguousarray(score_lut(int(data.max())) if data.size else np.zeros(1))
     pi, theta, pi_init = np.zeros(k), np.zeros(k), np.zeros(k)
     lnl, conv = C.c_double(), C.c_int32()

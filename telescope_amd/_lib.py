@@ -18,12 +18,12 @@ SRC = os.path.join(HERE, 'csrc', 'tsem.hip')
 
 OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_TIMEOUT = 0, -1, -2, -3, -4
 RA_CODE = {'exclude': 0, 'choose': 1, 'average': 2, 'conf': 3, 'unique': 4, 'all': 5}
-Z_PREV, Z_CUR, Z_INITIAL = 0, 1, 2
+Z_PREV, Z_CUR, Z_INITIAL, Z_FIRST, Z_USER = 0, 1, 2, 3, 4
 EMK_AUTO, EMK_TWOPASS, EMK_FUSED = 0, 1, 2
 
 
 class EngineError(RuntimeError):
-    pass
+    code = 0
 
 
 def build_library(force=False, verbose=False):
@@ -37,7 +37,7 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
            '-munsafe-fp-atomics', '-I' + os.path.join(ROOT, 'include'),
-           '-I' + os.path.join(HERE, 'csrc'), '-o', LIB_PATH, SRC]
+           '-I' + os.path.join(HERE, 'csrc'), '-o', LIB_PATH, SRC, '-lrccl']
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
@@ -99,10 +99,24 @@ def lib():
     L.tsem_lnl_pass.argtypes = [vp]
     L.tsem_read_reduce.argtypes = [vp, vp, i64, i64]
     L.tsem_em_steps.argtypes = [vp, i32, vp]
+    L.tsem_em_chunk.argtypes = [vp, i32, dbl, i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
+    L.tsem_fallback_twopass.argtypes = [vp]
+    L.tsem_recover_timeout.argtypes = [vp, C.POINTER(i32)]
+    L.tsem_final_lnl.argtypes = [vp, C.POINTER(dbl)]
+    L.tsem_comm_unique_id.argtypes = [vp]
+    L.tsem_comm_create.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, C.c_int]
+    L.tsem_comm_destroy.argtypes = [vp]
+    L.tsem_comm_destroy.restype = None
+    L.tsem_comm_last_error.argtypes = []
+    L.tsem_comm_last_error.restype = C.c_char_p
+    L.tsem_comm_attach.argtypes = [vp, vp]
+    L.tsem_comm_allreduce.argtypes = [vp, i64, i64]
+    L.tsem_comm_allreduce_host.argtypes = [vp, vp, i64, C.c_int]
     L.tsem_em_run.argtypes = [vp, dbl, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(dbl),
                               vp, vp, vp, vp]
     L.tsem_export_z.argtypes = [vp, C.c_int, vp]
     L.tsem_estep.argtypes = [vp, vp, vp, vp]
+    L.tsem_set_user_z.argtypes = [vp, vp]
     L.tsem_mstep.argtypes = [vp, vp, vp, vp]
     L.tsem_calc_lnl.argtypes = [vp, vp, vp, vp, C.POINTER(dbl)]
     L.tsem_best_counts.argtypes = [vp, C.c_int, vp]
@@ -116,11 +130,12 @@ def lib():
     L.tsem_debug_fused_prof.argtypes = [vp, vp]
     L.tsem_debug_log1p.argtypes = [C.c_int, C.c_int32, vp, vp]
     L.tsem_debug_subblock.argtypes = [vp, C.c_int64, C.c_int32, vp, C.c_int64]
-    L.tsem_debug_subblock.restype = C.c_int64
     for name in exported_symbols():
         fn = getattr(L, name)
-        if name not in ('tsem_destroy', 'tsem_last_error'):
+        if name not in ('tsem_destroy', 'tsem_last_error', 'tsem_comm_destroy', 'tsem_comm_last_error',
+                        'tsem_debug_subblock'):
             fn.restype = C.c_int
+    L.tsem_debug_subblock.restype = C.c_int64
     _lib = L
     return L
 
@@ -155,7 +170,9 @@ class Engine(object):
 
     def _ck(self, rc):
         if rc != OK:
-            raise EngineError('libtelescope_em error %d: %s' % (rc, self._L.tsem_last_error(self._h).decode()))
+            e = EngineError('libtelescope_em error %d: %s' % (rc, self._L.tsem_last_error(self._h).decode()))
+            e.code = rc
+            raise e
 
     # -- plumbing --
     def set_stream(self, stream_handle):
@@ -260,6 +277,36 @@ class Engine(object):
         self._ck(self._L.tsem_em_steps(self._h, int(n), ptr(out)))
         return out
 
+    def em_chunk(self, n_max, epsilon=0.0, use_likelihood=False, first=False):
+        """Up to `n_max` iterations of the em() loop body enqueued back to back; convergence is decided on
+        the device (include/telescope_em.h).  Returns (diffs, lnls, stopped) of the committed iterations."""
+        n_max = int(n_max)
+        diffs, lnls = np.empty(max(1, n_max)), np.empty(max(1, n_max))
+        done, stopped = C.c_int32(), C.c_int32()
+        self._ck(self._L.tsem_em_chunk(self._h, n_max, float(epsilon), int(bool(use_likelihood)), int(bool(first)),
+                                       C.byref(done), C.byref(stopped), ptr(diffs), ptr(lnls)))
+        n = done.value
+        return diffs[:n], (lnls[:n] if use_likelihood else None), bool(stopped.value)
+
+    def final_lnl(self):
+        out = C.c_double()
+        self._ck(self._L.tsem_final_lnl(self._h, C.byref(out)))
+        return out.value
+
+    def fallback_twopass(self):
+        self._ck(self._L.tsem_fallback_twopass(self._h))
+
+    def recover_timeout(self):
+        sw = C.c_int32()
+        self._ck(self._L.tsem_recover_timeout(self._h, C.byref(sw)))
+        return bool(sw.value)
+
+    def comm_attach(self, comm_handle):
+        self._ck(self._L.tsem_comm_attach(self._h, comm_handle))
+
+    def comm_allreduce(self, offset, count):
+        self._ck(self._L.tsem_comm_allreduce(self._h, int(offset), int(count)))
+
     def em_run(self, epsilon, max_iter, use_likelihood):
         _, k, _ = self.dims()
         n_iter, conv, lnl = C.c_int32(), C.c_int32(), C.c_double()
@@ -278,6 +325,11 @@ class Engine(object):
         z = np.empty(nnz)
         self._ck(self._L.tsem_export_z(self._h, which, ptr(z)))
         return z
+
+    def set_user_z(self, z_aligned):
+        if z_aligned is not None:
+            z_aligned = np.ascontiguousarray(z_aligned, dtype=np.float64)
+        self._ck(self._L.tsem_set_user_z(self._h, ptr(z_aligned)))
 
     def estep(self, pi, theta):
         _, _, nnz = self.dims()
@@ -353,6 +405,45 @@ class Engine(object):
         self._ck(self._L.tsem_layout_info(self._h, ptr(info)))
         return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad', 'twin_cols',
                          'G1', 'G2', 'fused', 'slow_path', 'max_subblock', 'value_bytes', 'hot_cols'), info.tolist()))
+
+
+class LibComm(object):
+    """The library's own RCCL communicator (one per process / GPU): `unique_id()` on rank 0, ship the 128
+    bytes to the other ranks, then `LibComm(device, id, rank, world)` everywhere (collective)."""
+    ID_BYTES = 128
+    _DT = {('f64', 'sum'): 0, ('u64', 'sum'): 1, ('f64', 'max'): 2, ('i64', 'max'): 3}
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(LibComm.ID_BYTES, np.uint8)
+        rc = lib().tsem_comm_unique_id(ptr(buf))
+        if rc != OK:
+            raise EngineError('tsem_comm_unique_id failed (%d): %s' % (rc, lib().tsem_comm_last_error().decode()))
+        return buf.tobytes()
+
+    def __init__(self, device, unique_id, rank, world):
+        L = lib()
+        h = C.c_void_p()
+        idb = np.frombuffer(unique_id, np.uint8).copy()
+        rc = L.tsem_comm_create(C.byref(h), int(device), ptr(idb), int(rank), int(world))
+        if rc != OK:
+            raise EngineError('tsem_comm_create failed (%d): %s' % (rc, L.tsem_comm_last_error().decode()))
+        self._L, self.handle, self.rank, self.world, self.device = L, h, rank, world, device
+
+    def allreduce(self, a, kind='f64', op='sum'):
+        dt = {'f64': np.float64, 'u64': np.uint64, 'i64': np.int64}[kind]
+        a = np.array(a, dtype=dt, copy=True).ravel()
+        rc = self._L.tsem_comm_allreduce_host(self.handle, ptr(a), a.size, self._DT[(kind, op)])
+        if rc != OK:
+            raise EngineError('tsem_comm_allreduce_host failed (%d): %s' % (rc, self._L.tsem_comm_last_error().decode()))
+        return a
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._L.tsem_comm_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
 
 
 def debug_log1p(x, device=0):

@@ -15,7 +15,7 @@
 //   (profiles/r01_primitives_ubench.log), hence every per-entry gather and
 //   scatter of the hot loop goes through LDS.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -498,8 +498,9 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
 template <int NT>
 __global__ __launch_bounds__(NT) void k_phase1(int P, int Kp, int R, int64_t b0, int64_t nb, int G, int64_t N_amb_pad,
     const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
-    const double* __restrict__ ctab, double* __restrict__ ypart) {
+    const double* __restrict__ ctab, double* __restrict__ ypart, const uint32_t* __restrict__ ctl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the run has stopped (tsem_em_chunk)
   double* c = reinterpret_cast<double*>(smem);
   double* y = c + Kp;
   const int p = blockIdx.x % P, g = blockIdx.x / P;
@@ -529,8 +530,9 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_phase2_em(int P, int Kp, int R, int64_t b0, int64_t nb, int G, int accumulate, int64_t N_amb_pad,
     const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
     const double* __restrict__ ctab, const double* __restrict__ ypart, const uint16_t* __restrict__ wcode,
-    const double* __restrict__ lut, double* __restrict__ partial) {
+    const double* __restrict__ lut, double* __restrict__ partial, const uint32_t* __restrict__ ctl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
   double* c = reinterpret_cast<double*>(smem);
   double* acc = c + Kp;
   double* s = acc + Kp;
@@ -634,10 +636,14 @@ __global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ a,
 // slots x 4 interleaved slices of the team axis, so the strided reads of one slot overlap instead of
 // forming a chain of G dependent loads.  `sync` (fused kernel): only the teams that formed wrote
 // their slice — G = sum over XCDs of floor(tickets / P).
+// red[K] = 1 when this rank's fused pass raised its watchdog error word (the flag is summed with the column
+// sums by the all-reduce, so every rank's update kernel sees that SOME rank failed), red[K+1] = 0.
 __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double* __restrict__ partial,
                             const int32_t* __restrict__ col_of_pc, const uint32_t* __restrict__ colmap,
-                            double* __restrict__ red, int K, const uint32_t* __restrict__ sync, int P) {
+                            double* __restrict__ red, int K, const uint32_t* __restrict__ sync, int P,
+                            const uint32_t* __restrict__ ctl) {
   __shared__ double part[4][64];
+  if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the run has stopped
   if (sync) {
     int t = 0;
     for (int x = 0; x < 8; ++x) t += (int)(sync[x] / (uint32_t)P);
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double
   }
   const int pcl = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int pc = blockIdx.x * 64 + pcl;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { red[K] = 0.0; red[K + 1] = 0.0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { red[K] = (sync && sync[9]) ? 1.0 : 0.0; red[K + 1] = 0.0; }
   const int col = pc < Kpad ? col_of_pc[pc] : -1;        // -1: padding, or a secondary slot of a split column
   double s = 0.0;
   if (col >= 0) {
@@ -660,8 +666,19 @@ __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double
 
 __global__ void k_keep_err(const uint32_t* sync, uint32_t* errlog) { errlog[0] |= sync[9]; errlog[1] = sync[10]; }
 
+// Loop control of tsem_em_chunk, evaluated on the device so that the host need not synchronise every
+// iteration: ctl[0] = stop flag (0 run, 1 converged, 2 a rank's EM pass timed out), ctl[1] = iterations
+// committed since the host last cleared it.
+struct UpdCtl {
+  uint32_t* ctl;          // null: legacy stepwise use (always commit unless the error flag is up)
+  double eps;             // converged = diff_est < eps (model.py:792) unless use_lnl
+  int use_lnl;            // convergence is decided by k_lnl_check instead (model.py:785-789)
+  double* pi_first;       // non-null: also store the new parameters here (pi_init / theta_init, model.py:776-778)
+  double* theta_first;
+};
+
 // M-step closed forms (model.py:733-740) + per-block partials of diff_est (model.py:781)
-__global__ __launch_bounds__(256) void k_update(int K, const double* __restrict__ red,
+__global__ __launch_bounds__(256) void k_update(UpdCtl C, int K, const double* __restrict__ red,
     const double* __restrict__ pisum0, double theta_pw, double theta_den, double pi_pw, double pi_den,
     double* __restrict__ pi, double* __restrict__ theta, double* __restrict__ pi_prev,
     double* __restrict__ theta_prev, const uint32_t* __restrict__ colmap, int Kp,
@@ -681,8 +698,12 @@ __global__ __launch_bounds__(256) void k_update(int K, const double* __restrict_
       fz_sync[threadIdx.x] = 0u;
     }
   }
+  if (C.ctl && __hip_atomic_load(C.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the run has stopped: nothing to commit
+  // some rank's fused pass timed out (flag summed by the all-reduce): the column sums are incomplete, so NO
+  // rank commits; the last block raises stop = 2 and the host redoes the iteration (tsem_em_chunk)
+  const bool failed = red[K] > 0.0;
   double d = 0.0;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K; j += gridDim.x * blockDim.x) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K && !failed; j += gridDim.x * blockDim.x) {
     // exact twin columns share one accumulation (see k_colsig) as long as their
     // sums agree to rounding, i.e. their parameters are still symmetric
     const int jr = twin_rep[j];
@@ -698,6 +719,7 @@ __global__ __launch_bounds__(256) void k_update(int K, const double* __restrict_
     d += fabs(ph - po);
     pi_prev[j] = po; theta_prev[j] = to;
     pi[j] = ph; theta[j] = th;
+    if (C.pi_first) { C.pi_first[j] = ph; C.theta_first[j] = th; }
     const uint32_t cm = colmap[j];
     const int pc = (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu), copies = 1 << ((cm >> 13) & 7u);
     const double cold = ctab[pc], cnew = ph * th;
@@ -715,8 +737,37 @@ __global__ __launch_bounds__(256) void k_update(int K, const double* __restrict_
     double v = 0.0;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) v += __hip_atomic_load(&diff_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double tt = block_sum(v, scratch);
-    if (threadIdx.x == 0) { *diff_out = tt; *done = 0u; }
+    if (threadIdx.x == 0) {
+      *done = 0u;
+      if (failed) {
+        if (C.ctl) C.ctl[0] = 2u;
+        *diff_out = -1.0;                                  // (legacy stepwise hosts: negative = not committed)
+      } else {
+        *diff_out = tt;
+        if (C.ctl) {
+          C.ctl[1] += 1u;
+          if (!C.use_lnl && tt < C.eps) C.ctl[0] = 1u;     // model.py:792
+        }
+      }
+    }
   }
+}
+
+// use_likelihood convergence test (model.py:785-789): lred[0] = all-reduced log-likelihood of the iteration just
+// committed, lred[1] > 0 when some rank's lnl pass timed out.
+__global__ void k_lnl_check(uint32_t* ctl, double* ctld, const double* __restrict__ lred, double eps,
+                            double* __restrict__ lnl_out) {
+  if (ctl[0]) return;
+  if (lred[1] > 0.0) { ctl[0] = 3u; return; }
+  const double l = lred[0];
+  *lnl_out = l;
+  if (fabs(l - ctld[0]) < eps) ctl[0] = 1u;
+  ctld[0] = l;
+}
+// lnl partial + error flag of this rank into the two lnl reduce slots
+__global__ void k_lnl_slots(const double* __restrict__ red_lnl, const uint32_t* __restrict__ sync, double* __restrict__ lred) {
+  lred[0] = *red_lnl;
+  lred[1] = (sync && sync[9]) ? 1.0 : 0.0;
 }
 
 __global__ void k_make_ctab(int K, const double* __restrict__ pi, const double* __restrict__ theta,
@@ -757,6 +808,7 @@ struct RowPassArgs {
   const double* lut;
   const double* pi;      // null => initial (c == 1)
   const double* theta;
+  const double* zin;     // non-null: the caller's z (TSEM_Z_USER), aligned to the CSR pattern, NaN = no entry; used as is
   int method;
   double thresh;
   const int32_t* picks;
@@ -783,6 +835,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
     const int64_t s = A.indptr[row], e = A.indptr[row + 1];
     const bool amb = (e - s) > 1;
     auto numer = [&](int64_t k) -> double {
+      if (A.zin) return A.zin[k];
       double q = A.lut[A.raw[k]];
       if (initial) return q;
       int col = A.indices[k];
@@ -798,10 +851,12 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
         const int64_t k = s + lane + i * RP_SUB;
         vld[i] = k < e;
         n[i] = vld[i] ? numer(k) : 0.0;
-        inp[i] = vld[i] && (initial || n[i] != 0.0);
+        inp[i] = vld[i] && (A.zin ? !isnan(n[i]) : (initial || n[i] != 0.0));
+        if (A.zin && !inp[i]) n[i] = 0.0;
       }
       // same summation order as the long-row path below: lane-strided partial sums, then across lanes
-      const double r = recip0(sg_sum<RP_SUB>(((n[0] + n[1]) + n[2]) + n[3]));
+      const double rs = recip0(sg_sum<RP_SUB>(((n[0] + n[1]) + n[2]) + n[3]));
+      const double r = A.zin ? 1.0 : rs;                    // the caller's z is used as is (model.py:837)
       double zmax = -1.0; int cnt = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) if (inp[i]) { zmax = fmax(zmax, n[i] * r); ++cnt; }
@@ -862,15 +917,15 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
     }
     // sweep 1: row sum
     double y = 0.0;
-    for (int64_t k = s + lane; k < e; k += RP_SUB) y += numer(k);
+    for (int64_t k = s + lane; k < e; k += RP_SUB) { const double v = numer(k); y += (A.zin && isnan(v)) ? 0.0 : v; }
     y = sg_sum<RP_SUB>(y);
-    const double r = recip0(y);
+    const double r = A.zin ? 1.0 : recip0(y);
     // sweep 2: row max over z's pattern
     double zmax = -1.0;
     int cnt = 0;
     for (int64_t k = s + lane; k < e; k += RP_SUB) {
       double n = numer(k);
-      bool inpat = initial || (n != 0.0);
+      bool inpat = A.zin ? !isnan(n) : (initial || (n != 0.0));
       if (inpat) { zmax = fmax(zmax, n * r); ++cnt; }
     }
     zmax = sg_max<RP_SUB>(zmax);
@@ -878,7 +933,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
     if (MODE == RP_EXPORT_Z) {
       for (int64_t k = s + lane; k < e; k += RP_SUB) {
         double n = numer(k);
-        bool inpat = initial || (n != 0.0);
+        bool inpat = A.zin ? !isnan(n) : (initial || (n != 0.0));
         A.zout[k] = inpat ? n * r : -1.0;   // -1 marks an entry the reference drops from z's pattern
       }
       continue;
@@ -887,7 +942,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
     int nb = 0;
     for (int64_t k = s + lane; k < e; k += RP_SUB) {
       double n = numer(k);
-      bool inpat = initial || (n != 0.0);
+      bool inpat = A.zin ? !isnan(n) : (initial || (n != 0.0));
       if (inpat && (n * r) == zmax) ++nb;
     }
     nb = sg_sum_i<RP_SUB>(nb);
@@ -901,7 +956,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       for (int64_t k = s + lane; k < e; k += RP_SUB) {
         double n = numer(k);
         double z = n * r;
-        if ((initial || n != 0.0) && z >= A.thresh) vsum += z;
+        if ((A.zin ? !isnan(n) : (initial || n != 0.0)) && z >= A.thresh) vsum += z;
       }
       vsum = sg_sum<RP_SUB>(vsum);
     }
@@ -912,7 +967,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       int64_t k = k0 + lane;
       bool valid = k < e;
       double n = valid ? numer(k) : 0.0;
-      bool inpat = valid && (initial || n != 0.0);
+      bool inpat = valid && (A.zin ? !isnan(n) : (initial || n != 0.0));
       double z = n * r;
       bool best = inpat && (z == zmax);
       unsigned long long bal = __ballot(best);
@@ -1133,6 +1188,8 @@ static void free_matrix(tsem_ctx* h) {
   free_layout(h);
   dfree(h->d_pi); dfree(h->d_theta); dfree(h->d_pi_prev); dfree(h->d_theta_prev);
   dfree(h->d_ctab); dfree(h->d_ctab_prev); dfree(h->d_red_own); dfree(h->d_tmp_pi); dfree(h->d_tmp_theta);
+  dfree(h->d_ctl); dfree(h->d_ctld); dfree(h->d_lnls); dfree(h->d_pi_first); dfree(h->d_theta_first); dfree(h->d_user_z);
+  h->first_pending = false;
   h->d_red = nullptr;
   h->have_rowstats = h->have_model = false;
   h->N = h->nnz = 0; h->K = 0;
@@ -1274,10 +1331,10 @@ int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_col
   if (n) {
     k_gen_len<<<cdiv64(n, 256), 256, 0, h->stream>>>(row_begin, n, n_cols, d_cdf, cdf_len, seed, uth, h->d_indptr + 1);
     size_t tb = 0;
-    hipcub::DeviceScan::InclusiveSum(nullptr, tb, h->d_indptr + 1, h->d_indptr + 1, n, h->stream);
+    TSEM_HIP(rocprim::inclusive_scan(nullptr, tb, h->d_indptr + 1, h->d_indptr + 1, (size_t)n, rocprim::plus<int64_t>(), h->stream));
     void* tmp = nullptr;
     TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
-    hipcub::DeviceScan::InclusiveSum(tmp, tb, h->d_indptr + 1, h->d_indptr + 1, n, h->stream);
+    TSEM_HIP(rocprim::inclusive_scan(tmp, tb, h->d_indptr + 1, h->d_indptr + 1, (size_t)n, rocprim::plus<int64_t>(), h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
     (void)hipFree(tmp);
   }
@@ -1343,6 +1400,63 @@ int tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* ra
   return TSEM_OK;
 }
 
+// Column parts (the tables of one part must fit LDS), rows per block and the fused kernel's geometry, from
+// the row statistics and the options; called again when a handle falls back to the two-pass kernels.
+static int choose_geometry(tsem_ctx* h) {
+  const int K = h->K;
+  const int64_t na = h->N_amb, nu = h->N_uni;
+  {
+    // column parts (tables of one part must fit LDS) and rows per block
+    int P = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP - 1) / TS_MAX_KP;
+    if (P < 1) P = 1;
+    if (h->opt_P <= 0 && h->em_kernel != TSEM_EMK_TWOPASS && P < FZ_MAX_P && na > 0) {
+      // Teams never span XCDs, so floor(cpx / P) * P of an XCD's cpx CUs work: 28 of 32 for teams of 7.
+      // One more member per team is worth it when it puts >= 10 % more CUs to work and the rows are
+      // long enough to fill the register tiles of the larger team (measured: K = 50k, 100 nnz/row,
+      // P 7 -> 8: fp64 5.80 -> 5.48 ms, codes 4.82 -> 4.28 ms; K = 38k, 40 nnz/row is better off at P = 5).
+      const int cpx = std::max(1, h->n_cu / 8);
+      auto util = [&](int p) { return (double)(cpx / p * p) / cpx; };
+      const double mean_len = (double)(h->nnz - nu) / (double)na;
+      for (int p2 = P + 1; p2 <= FZ_MAX_P; ++p2)
+        if (util(p2) >= util(P) + 0.10 && mean_len * fz_rmax(1) >= 1.05 * fz_cap(1) * p2) { P = p2; break; }
+    }
+    if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
+    int Kp = (K + P - 1) / P;
+    if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
+    // spare accumulator slots per part for very popular columns (build_layout splits them)
+    h->hot_extra = h->opt_hot_split ? std::min(64, TS_MAX_KP - Kp) : 0;
+    Kp += h->hot_extra;
+    h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
+    h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
+    int R = 2048;
+    h->geo = P > 4 ? 1 : 0;
+    h->run_len_est = na > 0 ? (double)(h->nnz - nu) / (double)na / P : 0.0;   // entries per ambiguous row and part
+    if (h->use_fused && na > 0) {
+      // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
+      double mean_len = (double)(h->nnz - nu) / (double)na;
+      // row SLOTS per block: ~7 % above the average a register tile takes, so blocks end on the
+      // tile's capacity, not on R (the exchange cost depends on R, hence not more than needed)
+      // geometry: teams of 5-8 have one; smaller teams switch to three exchange waves when the rows
+      // are so short that 512 row slots cannot fill the register tile and the pass is bound by the
+      // exchange (fp64 entries; with score codes the 14th data wave is worth more)
+      h->geo = P > 4 ? 1 : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > fz_rmax(0) && !fz_wants_codes(h)) ? 2 : 0);
+      if (h->opt_geo >= 0 && P <= 4) h->geo = h->opt_geo == 2 ? 2 : 0;
+      double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
+      const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2048 - 2 * Kp * 8 - lut_bytes) / ((FZ_YR + 2) * 8));
+      R = (int)std::min<double>(r, rmax);
+      R = std::max(64, (R + 63) / 64 * 64);
+      R = std::min(R, rmax / 8 * 8);
+    }
+    if (h->opt_R > 0) R = (int)h->opt_R;
+    h->R = R;
+  }
+  if (h->R > 65536 || h->R < 64) TSEM_FAIL(TSEM_ERR_ARG, "block_rows must be in [64, 65536]");
+  h->nb = (na + h->R - 1) / h->R;
+  h->N_amb_pad = std::max<int64_t>(1, h->nb) * h->R;
+  return TSEM_OK;
+}
+
 // ---------------------------------------------------------------------------
 // rowstats: classes, weights, local sums; compacts ambiguous / unique rows
 // ---------------------------------------------------------------------------
@@ -1402,66 +1516,18 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   if (N) {
     k_class_flags<<<cdiv64(N, 256), 256, 0, h->stream>>>(N, d_cls, d_fa, d_fu);
     size_t tb = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_fa, d_fa, N + 1, h->stream);
+    TSEM_HIP(rocprim::exclusive_scan(nullptr, tb, d_fa, d_fa, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(), h->stream));
     void* tmp = nullptr;
     TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
-    hipcub::DeviceScan::ExclusiveSum(tmp, tb, d_fa, d_fa, N + 1, h->stream);
-    hipcub::DeviceScan::ExclusiveSum(tmp, tb, d_fu, d_fu, N + 1, h->stream);
+    TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_fa, d_fa, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(), h->stream));
+    TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_fu, d_fu, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(), h->stream));
     TSEM_HIP(hipMemcpyAsync(&na, d_fa + N, 4, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipMemcpyAsync(&nu, d_fu + N, 4, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
     (void)hipFree(tmp);
   }
   h->N_amb = na; h->N_uni = nu;
-  {
-    // column parts (tables of one part must fit LDS) and rows per block
-    int P = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP - 1) / TS_MAX_KP;
-    if (P < 1) P = 1;
-    if (h->opt_P <= 0 && h->em_kernel != TSEM_EMK_TWOPASS && P < FZ_MAX_P && na > 0) {
-      // Teams never span XCDs, so floor(cpx / P) * P of an XCD's cpx CUs work: 28 of 32 for teams of 7.
-      // One more member per team is worth it when it puts >= 10 % more CUs to work and the rows are
-      // long enough to fill the register tiles of the larger team (measured: K = 50k, 100 nnz/row,
-      // P 7 -> 8: fp64 5.80 -> 5.48 ms, codes 4.82 -> 4.28 ms; K = 38k, 40 nnz/row is better off at P = 5).
-      const int cpx = std::max(1, h->n_cu / 8);
-      auto util = [&](int p) { return (double)(cpx / p * p) / cpx; };
-      const double mean_len = (double)(h->nnz - nu) / (double)na;
-      for (int p2 = P + 1; p2 <= FZ_MAX_P; ++p2)
-        if (util(p2) >= util(P) + 0.10 && mean_len * fz_rmax(1) >= 1.05 * fz_cap(1) * p2) { P = p2; break; }
-    }
-    if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
-    int Kp = (K + P - 1) / P;
-    if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
-    // spare accumulator slots per part for very popular columns (build_layout splits them)
-    h->hot_extra = h->opt_hot_split ? std::min(64, TS_MAX_KP - Kp) : 0;
-    Kp += h->hot_extra;
-    h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
-    h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
-    int R = 2048;
-    h->geo = P > 4 ? 1 : 0;
-    h->run_len_est = na > 0 ? (double)(h->nnz - nu) / (double)na / P : 0.0;   // entries per ambiguous row and part
-    if (h->use_fused && na > 0) {
-      // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
-      double mean_len = (double)(h->nnz - nu) / (double)na;
-      // row SLOTS per block: ~7 % above the average a register tile takes, so blocks end on the
-      // tile's capacity, not on R (the exchange cost depends on R, hence not more than needed)
-      // geometry: teams of 5-8 have one; smaller teams switch to three exchange waves when the rows
-      // are so short that 512 row slots cannot fill the register tile and the pass is bound by the
-      // exchange (fp64 entries; with score codes the 14th data wave is worth more)
-      h->geo = P > 4 ? 1 : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > fz_rmax(0) && !fz_wants_codes(h)) ? 2 : 0);
-      if (h->opt_geo >= 0 && P <= 4) h->geo = h->opt_geo == 2 ? 2 : 0;
-      double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
-      const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
-      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2048 - 2 * Kp * 8 - lut_bytes) / ((FZ_YR + 2) * 8));
-      R = (int)std::min<double>(r, rmax);
-      R = std::max(64, (R + 63) / 64 * 64);
-      R = std::min(R, rmax / 8 * 8);
-    }
-    if (h->opt_R > 0) R = (int)h->opt_R;
-    h->R = R;
-  }
-  if (h->R > 65536 || h->R < 64) TSEM_FAIL(TSEM_ERR_ARG, "block_rows must be in [64, 65536]");
-  h->nb = (na + h->R - 1) / h->R;
-  h->N_amb_pad = std::max<int64_t>(1, h->nb) * h->R;
+  if (int rc = choose_geometry(h)) return rc;
   TSEM_ALLOC(h->d_amb_row, na);
   TSEM_ALLOC(h->d_amb_wcode_c, na);                       // per compact row; build_layout makes the slot copy
   TSEM_ALLOC(h->d_uni_col, nu);
@@ -1553,10 +1619,10 @@ static int build_layout(tsem_ctx* h) {
     TSEM_HIP(hipGetLastError());
     {
       size_t tb = 0;
-      (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_cnt, d_off, nch + 1, h->stream);
+      TSEM_HIP(rocprim::exclusive_scan(nullptr, tb, d_cnt, d_off, (int64_t)0, (size_t)(nch + 1), rocprim::plus<int64_t>(), h->stream));
       void* tmp = nullptr;
       TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
-      (void)hipcub::DeviceScan::ExclusiveSum(tmp, tb, d_cnt, d_off, nch + 1, h->stream);
+      TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_cnt, d_off, (int64_t)0, (size_t)(nch + 1), rocprim::plus<int64_t>(), h->stream));
       int flag = 0;
       TSEM_HIP(hipMemcpyAsync(&nb, d_off + nch, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
       TSEM_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1774,8 +1840,9 @@ int tsem_get_params(tsem_ctx* h, int which, double* pi, double* theta) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  const double* sp = which == TSEM_Z_PREV ? h->d_pi_prev : h->d_pi;
-  const double* st = which == TSEM_Z_PREV ? h->d_theta_prev : h->d_theta;
+  if (which == TSEM_Z_FIRST && !h->d_pi_first) TSEM_FAIL(TSEM_ERR_ARG, "no EM run yet: pi_init / theta_init are not set");
+  const double* sp = which == TSEM_Z_FIRST ? h->d_pi_first : (which == TSEM_Z_PREV ? h->d_pi_prev : h->d_pi);
+  const double* st = which == TSEM_Z_FIRST ? h->d_theta_first : (which == TSEM_Z_PREV ? h->d_theta_prev : h->d_theta);
   if (pi) TSEM_HIP(hipMemcpy(pi, sp, sizeof(double) * h->K, hipMemcpyDeviceToHost));
   if (theta) TSEM_HIP(hipMemcpy(theta, st, sizeof(double) * h->K, hipMemcpyDeviceToHost));
   return TSEM_OK;
@@ -1799,12 +1866,12 @@ int tsem_bind_reduce_buffer(tsem_ctx* h, void* dptr, int64_t count) {
 // ---------------------------------------------------------------------------
 // EM pass / update / lnl
 // ---------------------------------------------------------------------------
-static int launch_phase1(tsem_ctx* h, const double* ctab, int64_t b0 = 0, int64_t b1 = -1) {
+static int launch_phase1(tsem_ctx* h, const double* ctab, int64_t b0 = 0, int64_t b1 = -1, bool em = false) {
   if (h->nb == 0) return TSEM_OK;
   if (b1 < 0) b1 = h->nb;
   const size_t lds1 = (size_t)(h->Kp + h->R) * 8;
   k_phase1<512><<<h->G1 * h->P, 512, lds1, h->stream>>>(h->P, h->Kp, h->R, b0, b1, h->G1, h->N_amb_pad, h->d_sb_off,
-                                                        h->d_pval, h->d_prc, ctab, h->d_ypart);
+                                                        h->d_pval, h->d_prc, ctab, h->d_ypart, em ? h->d_ctl : nullptr);
   TSEM_HIP(hipGetLastError());
   return TSEM_OK;
 }
@@ -1841,6 +1908,7 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
   A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg; A.sorted = h->sorted_layout ? 1 : 0;
   A.sync = h->d_xflags;
   A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.dbg = (int)h->opt_dbg;
+  A.ctl = h->d_ctl;
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
   const size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
   if (mode && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
@@ -1867,9 +1935,9 @@ int tsem_em_pass(tsem_ctx* h) {
     const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : h->nb;
     for (int64_t b0 = 0; b0 < h->nb; b0 += chunk) {
       const int64_t b1 = std::min(h->nb, b0 + chunk);
-      if (int rc = launch_phase1(h, h->d_ctab, b0, b1)) return rc;
+      if (int rc = launch_phase1(h, h->d_ctab, b0, b1, true)) return rc;
       k_phase2_em<1024><<<h->G2 * h->P, 1024, lds2, h->stream>>>(h->P, h->Kp, h->R, b0, b1, h->G2, b0 > 0 ? 1 : 0,
-          h->N_amb_pad, h->d_sb_off, h->d_pval, h->d_prc, h->d_ctab, h->d_ypart, h->d_amb_wcode, h->d_lut, h->d_partial);
+          h->N_amb_pad, h->d_sb_off, h->d_pval, h->d_prc, h->d_ctab, h->d_ypart, h->d_amb_wcode, h->d_lut, h->d_partial, h->d_ctl);
     }
     TSEM_HIP(hipGetLastError());
   }
@@ -1877,10 +1945,10 @@ int tsem_em_pass(tsem_ctx* h) {
   h->em_launches += 1;
   if (fused_done) {
     k_colreduce<<<cdiv64(h->Kpad, 64), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
-                                                            h->d_xflags, h->P);
+                                                            h->d_xflags, h->P, h->d_ctl);
   } else if (h->nb > 0) {
     k_colreduce<<<cdiv64(h->Kpad, 64), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
-                                                            nullptr, h->P);
+                                                            nullptr, h->P, h->d_ctl);
   } else {
     TSEM_HIP(hipMemsetAsync(h->d_red, 0, sizeof(double) * (h->K + 2), h->stream));
   }
@@ -1888,7 +1956,7 @@ int tsem_em_pass(tsem_ctx* h) {
   return TSEM_OK;
 }
 
-static int launch_update(tsem_ctx* h, double* d_diff_slot) {
+static int launch_update(tsem_ctx* h, double* d_diff_slot, bool chunked = false, double eps = 0.0, int use_lnl = 0) {
   const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;   // model.py:696-697
   const double tden = h->W_amb + tpw * h->K, pden = h->W_tot + ppw * h->K;      // model.py:732,738
   const int nblk = std::min(1024, cdiv64(h->K, 256));
@@ -1898,7 +1966,10 @@ static int launch_update(tsem_ctx* h, double* d_diff_slot) {
     TSEM_HIP(hipMemsetAsync(h->d_fz_aux, 0, sizeof(uint32_t) * 4, h->stream));
   }
   const bool clean = h->use_fused && h->d_xflags && h->fused_launched;
-  k_update<<<nblk, 256, 0, h->stream>>>(h->K, h->d_red, h->d_pisum0, tpw, tden, ppw, pden, h->d_pi, h->d_theta,
+  UpdCtl C;
+  C.ctl = chunked ? h->d_ctl : nullptr; C.eps = eps; C.use_lnl = use_lnl;
+  C.pi_first = h->first_pending ? h->d_pi_first : nullptr; C.theta_first = h->first_pending ? h->d_theta_first : nullptr;
+  k_update<<<nblk, 256, 0, h->stream>>>(C, h->K, h->d_red, h->d_pisum0, tpw, tden, ppw, pden, h->d_pi, h->d_theta,
                                         h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab, h->d_ctab_prev,
                                         h->d_twin_rep, part, d_diff_slot, h->d_fz_aux,
                                         clean ? h->d_xflags : nullptr, h->d_fz_aux + 2,
@@ -1909,16 +1980,59 @@ static int launch_update(tsem_ctx* h, double* d_diff_slot) {
   return TSEM_OK;
 }
 
-static int check_fused_error(tsem_ctx* h) {
-  if (!h->use_fused || !h->d_xflags || !h->fused_launched) return TSEM_OK;
+// the error word of the fused kernel: live, or what k_update / k_keep_err saved before zeroing it.  Clears it.
+static int take_fused_error(tsem_ctx* h, uint32_t* word) {
+  *word = 0;
+  if (!h->d_xflags || !h->fused_launched) return TSEM_OK;
   uint32_t ee[2] = {0, 0}, kept[2] = {0, 0};
   TSEM_HIP(hipMemcpyAsync(ee, h->d_xflags + 9, 8, hipMemcpyDeviceToHost, h->stream));
   if (h->d_fz_aux) TSEM_HIP(hipMemcpyAsync(kept, h->d_fz_aux + 2, 8, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  const uint32_t e = ee[0] | kept[0];                     // live words, or what k_update saved before zeroing them
+  *word = ee[0] | kept[0];
   h->last_slow_path = h->fz_clean ? kept[1] : ee[1];
-  if (e) TSEM_FAIL(TSEM_ERR_TIMEOUT, "fused EM kernel: hand-off watchdog fired (code " + std::to_string(e) +
-                   "): a team member was not co-resident or a flag never arrived");
+  if (*word) {
+    TSEM_HIP(hipMemsetAsync(h->d_xflags + 9, 0, 4, h->stream));
+    if (h->d_fz_aux) TSEM_HIP(hipMemsetAsync(h->d_fz_aux + 2, 0, 4, h->stream));
+  }
+  return TSEM_OK;
+}
+
+int tsem_fallback_twopass(tsem_ctx* h) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (!h->use_fused) return TSEM_OK;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  uint32_t e = 0;
+  (void)take_fused_error(h, &e);
+  h->em_kernel = TSEM_EMK_TWOPASS;
+  h->opt_format = 1;                                       // the two-pass kernels read fp64 entries
+  h->opt_dbg &= ~(int64_t)(32 | 64);
+  if (int rc = choose_geometry(h)) return rc;
+  if (int rc = build_layout(h)) return rc;
+  // the permuted pi*theta tables follow the new column map
+  TSEM_ALLOC(h->d_ctab, h->Kpad); TSEM_ALLOC(h->d_ctab_prev, h->Kpad);
+  TSEM_HIP(hipMemsetAsync(h->d_ctab, 0, sizeof(double) * h->Kpad, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_ctab_prev, 0, sizeof(double) * h->Kpad, h->stream));
+  k_make_ctab<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_pi, h->d_theta, h->d_colmap, h->Kp, h->d_ctab);
+  k_make_ctab<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab_prev);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  h->n_fallbacks += 1;
+  fprintf(stderr, "libtelescope_em: the persistent EM kernel could not keep its workgroups co-resident (watchdog code %u); "
+                  "continuing with the two-pass kernels\n", e);
+  return TSEM_OK;
+}
+
+int tsem_recover_timeout(tsem_ctx* h, int32_t* switched) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (switched) *switched = 0;
+  uint32_t mine = 0;
+  if (int rc = take_fused_error(h, &mine)) return rc;
+  if (mine && h->use_fused) {
+    if (int rc = tsem_fallback_twopass(h)) return rc;
+    if (switched) *switched = 1;
+  }
   return TSEM_OK;
 }
 
@@ -1926,17 +2040,19 @@ int tsem_em_update(tsem_ctx* h, double* diff_est) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
   if (int rc = launch_update(h, h->d_diffs)) return rc;
+  h->first_pending = false;
   if (diff_est) {
     TSEM_HIP(hipMemcpyAsync(diff_est, h->d_diffs, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
-    if (int rc = check_fused_error(h)) return rc;
+    // negative: the (all-reduced) error flag was up, so no rank committed this iteration
+    if (*diff_est < 0.0)
+      TSEM_FAIL(TSEM_ERR_TIMEOUT, "EM pass: the hand-off watchdog of the fused kernel fired on some rank; parameters "
+                                  "left untouched (tsem_fallback_twopass, then redo the pass)");
   }
   return TSEM_OK;
 }
 
-int tsem_lnl_pass(tsem_ctx* h) {
-  if (!h || !h->have_model) return TSEM_ERR_ARG;
-  if (int rc = ensure_device(h)) return rc;
+static int launch_lnl(tsem_ctx* h) {
   int na = 0, nu = 0;
   if (h->nb > 0 && h->use_fused) {
     if (int rc = launch_fused(h, 1, nullptr)) return rc;
@@ -1960,6 +2076,12 @@ int tsem_lnl_pass(tsem_ctx* h) {
   return TSEM_OK;
 }
 
+int tsem_lnl_pass(tsem_ctx* h) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  return launch_lnl(h);
+}
+
 int tsem_read_reduce(tsem_ctx* h, double* out, int64_t offset, int64_t count) {
   if (!h || !h->have_model || !out || offset < 0 || offset + count > h->K + 2) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
@@ -1968,17 +2090,131 @@ int tsem_read_reduce(tsem_ctx* h, double* out, int64_t offset, int64_t count) {
   return TSEM_OK;
 }
 
-int tsem_em_steps(tsem_ctx* h, int32_t n, double* diffs_out) {
-  if (!h || !h->have_model || n < 0 || n > TS_DIFF_RING) return TSEM_ERR_ARG;
-  for (int i = 0; i < n; ++i) {
-    if (int rc = tsem_em_pass(h)) return rc;
-    if (int rc = launch_update(h, h->d_diffs + i)) return rc;
+#define TSEM_NCCL(call)                                                          \
+  do {                                                                           \
+    ncclResult_t r_ = (call);                                                    \
+    if (r_ != ncclSuccess) {                                                     \
+      h->err = std::string(#call) + ": " + ncclGetErrorString(r_);               \
+      return TSEM_ERR_HIP;                                                       \
+    }                                                                            \
+  } while (0)
+
+// the per-iteration exchange: ONE sum all-reduce of the per-locus column sums + the error flag
+static int comm_allreduce_red(tsem_ctx* h, int64_t offset, int64_t count) {
+  if (!h->comm || !h->comm->nccl) return TSEM_OK;
+  TSEM_NCCL(ncclAllReduce(h->d_red + offset, h->d_red + offset, (size_t)count, ncclDouble, ncclSum, h->comm->nccl, h->stream));
+  return TSEM_OK;
+}
+
+static int ensure_ctl(tsem_ctx* h) {
+  if (h->d_ctl) return TSEM_OK;
+  TSEM_ALLOC(h->d_ctl, 8); TSEM_ALLOC(h->d_ctld, 8); TSEM_ALLOC(h->d_lnls, TS_DIFF_RING);
+  TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 32, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_ctld, 0, 64, h->stream));
+  return TSEM_OK;
+}
+
+// the lnl of the iteration just committed, all-reduced, into d_ctld[1] (value) / d_ctld[2] (error flag)
+static int enqueue_lnl_reduce(tsem_ctx* h) {
+  if (int rc = launch_lnl(h)) return rc;
+  k_lnl_slots<<<1, 1, 0, h->stream>>>(h->d_red + h->K, (h->use_fused && h->nb > 0) ? h->d_xflags : nullptr, h->d_ctld + 1);
+  TSEM_HIP(hipGetLastError());
+  if (h->comm && h->comm->nccl)
+    TSEM_NCCL(ncclAllReduce(h->d_ctld + 1, h->d_ctld + 1, 2, ncclDouble, ncclSum, h->comm->nccl, h->stream));
+  return TSEM_OK;
+}
+
+int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likelihood, int32_t first,
+                  int32_t* n_done, int32_t* stopped, double* diffs_out, double* lnls_out) {
+  if (!h || !h->have_model || n_max < 0 || n_max > TS_DIFF_RING) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (int rc = ensure_ctl(h)) return rc;
+  if (first) {
+    const double inf = INFINITY;                           // model.py:683: self.lnl = inf before the first iteration
+    TSEM_HIP(hipMemcpyAsync(h->d_ctld, &inf, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!h->d_pi_first) { TSEM_ALLOC(h->d_pi_first, h->K); TSEM_ALLOC(h->d_theta_first, h->K); }
+    h->first_pending = true;
   }
-  if (diffs_out && n) {
-    TSEM_HIP(hipMemcpyAsync(diffs_out, h->d_diffs, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  int done = 0, retries = 0;
+  bool stop = false, lnl_pending = false;
+  while (done < n_max && !stop) {
+    // enqueue everything that is left; the device stops itself
+    TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 8, h->stream));
+    const int base = done, want = n_max - done;
+    if (lnl_pending) {                                     // the lnl pass of the last committed iteration timed out
+      if (int rc = enqueue_lnl_reduce(h)) return rc;
+      k_lnl_check<<<1, 1, 0, h->stream>>>(h->d_ctl, h->d_ctld, h->d_ctld + 1, epsilon, h->d_lnls + base - 1);
+      TSEM_HIP(hipGetLastError());
+    }
+    for (int i = 0; i < want; ++i) {
+      if (int rc = tsem_em_pass(h)) return rc;
+      if (int rc = comm_allreduce_red(h, 0, h->K + 2)) return rc;
+      if (int rc = launch_update(h, h->d_diffs + base + i, true, epsilon, use_likelihood)) return rc;
+      h->first_pending = false;                            // (a failed first update is redone below with the flag restored)
+      if (use_likelihood) {
+        if (int rc = enqueue_lnl_reduce(h)) return rc;
+        k_lnl_check<<<1, 1, 0, h->stream>>>(h->d_ctl, h->d_ctld, h->d_ctld + 1, epsilon, h->d_lnls + base + i);
+        TSEM_HIP(hipGetLastError());
+      }
+    }
+    uint32_t ctl[2] = {0, 0};
+    TSEM_HIP(hipMemcpyAsync(ctl, h->d_ctl, 8, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
+    done = base + (int)ctl[1];
+    lnl_pending = false;
+    if (ctl[0] == 1u) { stop = true; break; }
+    if (ctl[0] == 2u || ctl[0] == 3u) {                    // some rank's fused pass timed out: nobody committed that step
+      if (++retries > 3) TSEM_FAIL(TSEM_ERR_TIMEOUT, "EM pass: repeated hand-off time-outs");
+      uint32_t mine = 0;
+      if (int rc = take_fused_error(h, &mine)) return rc;
+      if (mine) { if (int rc = tsem_fallback_twopass(h)) return rc; }
+      if (first && done == 0 && ctl[0] == 2u) h->first_pending = true;
+      lnl_pending = ctl[0] == 3u;
+      continue;
+    }
+    if (h->use_fused) {                                    // belt and braces: an error word the flags did not carry
+      uint32_t mine = 0;
+      if (int rc = take_fused_error(h, &mine)) return rc;
+      if (mine) TSEM_FAIL(TSEM_ERR_TIMEOUT, "fused EM kernel: hand-off watchdog fired (code " + std::to_string(mine) + ")");
+    }
   }
-  return check_fused_error(h);
+  if (n_done) *n_done = done;
+  if (stopped) *stopped = stop ? 1 : 0;
+  if (done && diffs_out) TSEM_HIP(hipMemcpy(diffs_out, h->d_diffs, sizeof(double) * done, hipMemcpyDeviceToHost));
+  if (done && lnls_out && use_likelihood) TSEM_HIP(hipMemcpy(lnls_out, h->d_lnls, sizeof(double) * done, hipMemcpyDeviceToHost));
+  TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 8, h->stream));     // passes launched outside a chunk must not see a stale stop flag
+  return TSEM_OK;
+}
+
+int tsem_em_steps(tsem_ctx* h, int32_t n, double* diffs_out) {
+  int32_t done = 0;
+  return tsem_em_chunk(h, n, 0.0, 0, 0, &done, nullptr, diffs_out, nullptr);
+}
+
+// the final log-likelihood (model.py:800-801), all-reduced; redone on the two-pass kernels after a time-out
+static int final_lnl(tsem_ctx* h, double* lnl) {
+  if (int rc = ensure_ctl(h)) return rc;
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = enqueue_lnl_reduce(h)) return rc;
+    double v[2] = {0, 0};
+    TSEM_HIP(hipMemcpyAsync(v, h->d_ctld + 1, 16, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (v[1] > 0.0) {
+      if (attempt >= 2) TSEM_FAIL(TSEM_ERR_TIMEOUT, "lnl pass: repeated hand-off time-outs");
+      uint32_t mine = 0;
+      if (int rc = take_fused_error(h, &mine)) return rc;
+      if (mine) { if (int rc = tsem_fallback_twopass(h)) return rc; }
+      continue;
+    }
+    *lnl = v[0];
+    return TSEM_OK;
+  }
+}
+
+int tsem_final_lnl(tsem_ctx* h, double* lnl) {
+  if (!h || !h->have_model || !lnl) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  return final_lnl(h, lnl);
 }
 
 int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likelihood, int32_t* n_iter,
@@ -1986,34 +2222,102 @@ int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likel
                 double* theta_init) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   int inum = 0;
-  bool conv = false, reached = false;
+  bool conv = false;
   double lnl = INFINITY;
-  while (!(conv || reached)) {               // model.py:771-797
-    if (int rc = tsem_em_pass(h)) return rc;
-    double diff = 0.0;
-    if (int rc = tsem_em_update(h, &diff)) return rc;
-    ++inum;
-    if (inum == 1) { if (int rc = tsem_get_params(h, TSEM_Z_CUR, pi_init, theta_init)) return rc; }
-    if (diffs) diffs[inum - 1] = diff;
-    if (use_likelihood) {
-      if (int rc = tsem_lnl_pass(h)) return rc;
-      double l = 0.0;
-      if (int rc = tsem_read_reduce(h, &l, h->K, 1)) return rc;
-      conv = fabs(l - lnl) < epsilon;
-      lnl = l;
-      if (lnls) lnls[inum - 1] = l;
-    } else {
-      conv = diff < epsilon;
+  do {                                        // model.py:771-797: at least one iteration
+    const int want = std::max(1, std::min(8, max_iter - inum));
+    int32_t done = 0, stopped = 0;
+    std::vector<double> d(want), l(want);
+    if (int rc = tsem_em_chunk(h, want, epsilon, use_likelihood, inum == 0, &done, &stopped, d.data(), l.data())) return rc;
+    for (int i = 0; i < done; ++i) {
+      if (diffs && inum + i < std::max(1, max_iter)) diffs[inum + i] = d[i];
+      if (lnls && use_likelihood && inum + i < std::max(1, max_iter)) lnls[inum + i] = l[i];
+      if (use_likelihood) lnl = l[i];
     }
-    reached = inum >= max_iter;
-  }
-  if (!use_likelihood) {                     // model.py:800-801
-    if (int rc = tsem_lnl_pass(h)) return rc;
-    if (int rc = tsem_read_reduce(h, &lnl, h->K, 1)) return rc;
+    inum += done;
+    conv = stopped != 0;
+  } while (!conv && inum < max_iter);
+  if (pi_init || theta_init) { if (int rc = tsem_get_params(h, TSEM_Z_FIRST, pi_init, theta_init)) return rc; }
+  if (!use_likelihood) {                      // model.py:800-801
+    if (int rc = final_lnl(h, &lnl)) return rc;
   }
   if (n_iter) *n_iter = inum;
   if (converged) *converged = conv ? 1 : 0;
   if (lnl_out) *lnl_out = lnl;
+  return TSEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// communicator (RCCL over xGMI; one per process / GPU)
+// ---------------------------------------------------------------------------
+static std::string g_comm_err;
+const char* tsem_comm_last_error(void) { return g_comm_err.c_str(); }
+
+int tsem_comm_unique_id(void* id128) {
+  if (!id128) return TSEM_ERR_ARG;
+  static_assert(sizeof(ncclUniqueId) == TSEM_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) { g_comm_err = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r); return TSEM_ERR_HIP; }
+  memcpy(id128, &id, sizeof(id));
+  return TSEM_OK;
+}
+
+int tsem_comm_create(tsem_comm** out, int device, const void* id128, int rank, int world) {
+  if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return TSEM_ERR_ARG;
+  *out = nullptr;
+  if (hipSetDevice(device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return TSEM_ERR_HIP; }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  tsem_comm* c = new tsem_comm();
+  c->device = device; c->rank = rank; c->world = world;
+  ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
+  if (r != ncclSuccess) { g_comm_err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); delete c; return TSEM_ERR_HIP; }
+  *out = c;
+  return TSEM_OK;
+}
+
+void tsem_comm_destroy(tsem_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->d_stage) (void)hipFree(c->d_stage);
+  if (c->nccl) (void)ncclCommDestroy(c->nccl);
+  delete c;
+}
+
+int tsem_comm_attach(tsem_ctx* h, tsem_comm* c) {
+  if (!h) return TSEM_ERR_ARG;
+  if (c && c->device != h->device) TSEM_FAIL(TSEM_ERR_ARG, "communicator and handle are on different devices");
+  h->comm = c;
+  return TSEM_OK;
+}
+
+int tsem_comm_allreduce(tsem_ctx* h, int64_t offset, int64_t count) {
+  if (!h || !h->have_model || offset < 0 || count < 0 || offset + count > h->K + 2) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  return comm_allreduce_red(h, offset, count);
+}
+
+int tsem_comm_allreduce_host(tsem_comm* c, void* data, int64_t count, int dtype) {
+  if (!c || !c->nccl || (!data && count) || count < 0 || dtype < 0 || dtype > 3) return TSEM_ERR_ARG;
+  if (count == 0) return TSEM_OK;
+  if (hipSetDevice(c->device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return TSEM_ERR_HIP; }
+  const size_t bytes = (size_t)count * 8;
+  if (c->stage_bytes < bytes) {
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    c->d_stage = nullptr; c->stage_bytes = 0;
+    if (hipMalloc(&c->d_stage, bytes) != hipSuccess) { g_comm_err = "hipMalloc failed (all-reduce staging)"; return TSEM_ERR_NOMEM; }
+    c->stage_bytes = bytes;
+  }
+  const ncclDataType_t dt = dtype == 1 ? ncclUint64 : (dtype == 3 ? ncclInt64 : ncclDouble);
+  const ncclRedOp_t op = dtype >= 2 ? ncclMax : ncclSum;
+  hipError_t e = hipMemcpy(c->d_stage, data, bytes, hipMemcpyHostToDevice);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) r = ncclAllReduce(c->d_stage, c->d_stage, (size_t)count, dt, op, c->nccl, nullptr);
+  if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(nullptr);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpy(data, c->d_stage, bytes, hipMemcpyDeviceToHost);
+  if (r != ncclSuccess) { g_comm_err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return TSEM_ERR_HIP; }
+  if (e != hipSuccess) { g_comm_err = std::string("all-reduce staging: ") + hipGetErrorString(e); return TSEM_ERR_HIP; }
   return TSEM_OK;
 }
 
@@ -2023,6 +2327,12 @@ int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likel
 static int rowpass_args(tsem_ctx* h, int which, RowPassArgs& A) {
   A.N = h->N; A.K = h->K; A.indptr = h->d_indptr; A.indices = h->d_indices; A.raw = h->d_raw; A.lut = h->d_lut;
   A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr; A.group = nullptr; A.colmap = nullptr; A.col_of_pc = nullptr; A.P = 0; A.Kp = 0; A.Hs = 0;
+  A.zin = nullptr;
+  if (which == TSEM_Z_USER) {
+    if (!h->d_user_z) TSEM_FAIL(TSEM_ERR_ARG, "TSEM_Z_USER without tsem_set_user_z");
+    A.pi = h->d_pi; A.theta = h->d_theta; A.zin = h->d_user_z;
+    return TSEM_OK;
+  }
   if (which == TSEM_Z_INITIAL) { A.pi = nullptr; A.theta = nullptr; }
   else if (which == TSEM_Z_PREV) { A.pi = h->d_pi_prev; A.theta = h->d_theta_prev; }
   else if (which == TSEM_Z_CUR) { A.pi = h->d_pi; A.theta = h->d_theta; }
@@ -2050,6 +2360,15 @@ int tsem_export_z(tsem_ctx* h, int which, double* z) {
   RowPassArgs A;
   if (int rc = rowpass_args(h, which, A)) return rc;
   return export_z_with(h, A, z);
+}
+
+int tsem_set_user_z(tsem_ctx* h, const double* z) {
+  if (!h || !h->d_indptr) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (!z) { dfree(h->d_user_z); return TSEM_OK; }
+  TSEM_ALLOC(h->d_user_z, h->nnz);
+  if (h->nnz) TSEM_HIP(hipMemcpy(h->d_user_z, z, sizeof(double) * h->nnz, hipMemcpyHostToDevice));
+  return TSEM_OK;
 }
 
 int tsem_estep(tsem_ctx* h, const double* pi, const double* theta, double* z) {
@@ -2159,6 +2478,8 @@ int tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat) 
   TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
   A.colsums = d_cs;
   if (h->N) k_mstep_rows<<<rowpass_grid(h), 256, 0, h->stream>>>(A, d_z);
+  if (h->comm && h->comm->nccl)                             // row-sharded: thetasum over all ranks (model.py:731)
+    TSEM_NCCL(ncclAllReduce(d_cs, d_cs, (size_t)h->K, ncclDouble, ncclSum, h->comm->nccl, h->stream));
   const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;
   k_hats<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, d_cs, h->d_pisum0, tpw, h->W_amb + tpw * h->K, ppw,
                                                   h->W_tot + ppw * h->K, h->d_tmp_pi, h->d_tmp_theta);
@@ -2185,6 +2506,8 @@ int tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* 
   if (h->N) k_lnl_rows<<<grid, 256, 0, h->stream>>>(A, d_z, h->d_lnl_part);
   k_sum_parts<<<1, 256, 0, h->stream>>>(h->d_lnl_part, h->N ? grid : 0, h->d_lnl_part, 0, h->d_lnl_part + 8000);
   TSEM_HIP(hipGetLastError());
+  if (h->comm && h->comm->nccl)
+    TSEM_NCCL(ncclAllReduce(h->d_lnl_part + 8000, h->d_lnl_part + 8000, 1, ncclDouble, ncclSum, h->comm->nccl, h->stream));
   TSEM_HIP(hipMemcpyAsync(lnl, h->d_lnl_part + 8000, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
   (void)hipFree(d_z);

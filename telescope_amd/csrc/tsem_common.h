@@ -5,6 +5,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "telescope_em.h"
 
 #define TSEM_HIP(call)                                                           \
@@ -124,6 +126,7 @@ struct tsem_ctx {
   // ---- parameters ----
   double *d_pi = nullptr, *d_theta = nullptr, *d_pi_prev = nullptr, *d_theta_prev = nullptr;
   double *d_ctab = nullptr, *d_ctab_prev = nullptr;  // [Kpad] permuted pi*theta
+  double* d_user_z = nullptr;       // [nnz] caller-assigned z (TSEM_Z_USER), NaN = not in z's pattern
   double* d_red = nullptr;          // reduce buffer (K+2), internal or bound
   double* d_red_own = nullptr;
   int64_t red_count = 0;
@@ -137,6 +140,17 @@ struct tsem_ctx {
   bool fz_clean = false;            // sync words and exchange ring are zero (k_update cleaned them after the last pass)
   uint32_t* d_xerr = nullptr;
 
+  // ---- device-side loop control (tsem_em_chunk) ----
+  uint32_t* d_ctl = nullptr;        // [0] stop: 0 run, 1 converged, 2 a rank's EM pass timed out, 3 ... its lnl pass  [1] iterations committed
+  double* d_ctld = nullptr;         // [0] lnl of the previous iteration  [1..2] lnl reduce slots (value, error flag)
+  double* d_lnls = nullptr;         // [TS_DIFF_RING]
+  double *d_pi_first = nullptr, *d_theta_first = nullptr;   // params after the first iteration of the run (model.py:776-778)
+  bool first_pending = false;       // the next committed update saves them
+  int64_t n_fallbacks = 0;          // time-outs answered by switching to the two-pass kernels
+
+  // ---- communicator (row-sharded runs) ----
+  tsem_comm* comm = nullptr;
+
   // ---- instrumentation ----
   std::vector<hipEvent_t> ev;       // pairs
   size_t ev_used = 0;
@@ -145,3 +159,10 @@ struct tsem_ctx {
 };
 
 constexpr int TS_DIFF_RING = 65536;
+
+struct tsem_comm {
+  ncclComm_t nccl = nullptr;
+  int device = 0, rank = 0, world = 1;
+  void* d_stage = nullptr;          // staging buffer of tsem_comm_allreduce_host
+  size_t stage_bytes = 0;
+};

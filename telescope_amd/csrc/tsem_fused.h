@@ -86,7 +86,9 @@ struct FusedArgs {
   double* partial;      // [team slots][P*Kp], zero-filled before launch
   double* xchg;         // [team][FZ_XS][P][R] tagged granules, zero-filled before launch
   uint32_t* sync;       // zero-filled before launch
+  const uint32_t* ctl;  // device-side loop control (tsem_em_chunk): ctl[0] != 0 -> the run has stopped, return at once
   int dbg;              // bit0: skip partner loads (timing experiments only; wrong results)
+                        // bit5 / bit6: behave like a hand-off time-out in the EM / lnl pass (tests of the recovery path)
   unsigned long long* prof;   // optional per-step timestamps of team 0 / member 0
   int prof_blocks;
 };
@@ -359,6 +361,11 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   const int tid = threadIdx.x;
   uint32_t* const sync = A.sync;
   uint32_t* const err = sync + 9;
+  if (A.ctl && fz_ld_u32(A.ctl) != 0u) return;            // stopped by an earlier update kernel of this chunk
+  if (A.dbg & (MODE == 0 ? 32 : 64)) {                    // test hook: what a watchdog time-out leaves behind
+    if (blockIdx.x == 0 && tid == 0) atomicOr(err, 2u);
+    return;
+  }
 
   // ---- team formation from the hardware XCC id --------------------------------
   unsigned xcc;

@@ -1,4 +1,4 @@
-"""Row-sharded EM across GPUs: one process per GPU, torch.distributed plumbing.
+"""Row-sharded EM across GPUs: one process per GPU.
 
 Fragments (rows) are independent given (pi, theta), so each rank owns a
 contiguous row range of the score matrix.  Exchange steps:
@@ -7,15 +7,23 @@ contiguous row range of the score matrix.  Exchange steps:
              sum  : total/ambiguous weight, pisum0[K]           (model.py:691-699)
              max  : largest fragment weight                       (model.py:696-697)
              sum  : column signatures (u64 wrap-around)           (twin detection)
-  every iter sum  : per-locus column sums thetasum[K]             (model.py:731)
-                    -> ONE all-reduce of K doubles (240 KB at K=30k) on RCCL/xGMI
-  lnl        sum  : one scalar
+  every iter sum  : per-locus column sums thetasum[K] + an error flag
+                    -> ONE all-reduce of K+2 doubles (240 KB at K=30k) on RCCL/xGMI
+  lnl        sum  : one scalar (+ flag)
   reassign   sum  : K-vector per mode; `choose` gathers best-hit counts to
                     rank 0, which alone consumes the legacy RNG stream.
 
-backend "nccl" is RCCL on ROCm; "gloo" runs the same host logic on CPU tensors
-(tests/test_distributed_gloo.py).  torch is plumbing only: it owns the reduce
-tensor and the process group; all arithmetic is in libtelescope_em.so.
+Two transports:
+
+* backend "nccl" (= RCCL on ROCm): the LIBRARY owns its RCCL communicator
+  (`tsem_comm_*`, include/telescope_em.h).  torch.distributed only ships the 128-byte
+  id from rank 0 to the others and carries the two object collectives of `choose`; the
+  per-iteration all-reduce is issued by libtelescope_em.so itself on the engine's
+  stream, between the EM pass and the parameter update, with no host round trip
+  (`Engine.em_chunk`), and the setup / reassign sums go through the same communicator.
+* backend "gloo": the same host logic on CPU tensors, with a tests-only engine
+  standing in for the device (tests/test_distributed_gloo.py).  The reduce buffer is
+  then a CPU tensor that torch all-reduces in place between `em_pass` and `em_update`.
 """
 import os
 
@@ -39,7 +47,7 @@ def shard_bounds(n_rows, world, rank=None, indptr=None):
 
 
 class Comm(object):
-    """Thin wrapper over an initialised torch.distributed process group."""
+    """An initialised torch.distributed process group + (on GPUs) the library's RCCL communicator."""
 
     def __init__(self, device=None, group=None):
         import torch
@@ -49,15 +57,26 @@ class Comm(object):
         self._torch, self._dist, self.group = torch, dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        self.lib = None                       # _lib.LibComm: the library's own communicator
+        self.in_library = False               # the attached engine all-reduces by itself (Engine.em_chunk)
         if self.backend == 'nccl':
             self.device = int(os.environ.get('LOCAL_RANK', 0)) if device is None else device
             self.tdev = torch.device('cuda', self.device)
             torch.cuda.set_device(self.device)
+            from ._lib import LibComm
+            ids = [LibComm.unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0, group=group, device=self.tdev)
+            self.lib = LibComm(self.device, ids[0], self.rank, self.world)
         else:
             self.device = 0 if device is None else device
             self.tdev = torch.device('cpu')
         self._red = None
         self._eng = None
+
+    def close(self):
+        if self.lib is not None:
+            self.lib.close()
+            self.lib = None
 
     # ---- small host-side collectives (setup / reporting) --------------------
     def _allreduce_np(self, a, op, dtype):
@@ -66,19 +85,27 @@ class Comm(object):
         return t.cpu().numpy()
 
     def max_scalar(self, v):
+        if self.lib is not None:
+            return int(self.lib.allreduce([v], 'i64', 'max')[0])
         return int(self._allreduce_np(np.array([v], np.int64), self._dist.ReduceOp.MAX,
                                       self._torch.int64)[0])
 
     def sum_array(self, a):
+        if self.lib is not None:
+            return self.lib.allreduce(a, 'f64', 'sum').reshape(np.shape(a))
         return self._allreduce_np(np.asarray(a, np.float64), self._dist.ReduceOp.SUM,
                                   self._torch.float64)
 
     def max_array(self, a):
+        if self.lib is not None:
+            return self.lib.allreduce(a, 'f64', 'max').reshape(np.shape(a))
         return self._allreduce_np(np.asarray(a, np.float64), self._dist.ReduceOp.MAX,
                                   self._torch.float64)
 
     def sum_array_u64(self, a):
         """Wrap-around integer sums (two's complement int64 == uint64 mod 2^64)."""
+        if self.lib is not None:
+            return self.lib.allreduce(a, 'u64', 'sum').reshape(np.shape(a))
         a = np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)
         out = self._allreduce_np(a, self._dist.ReduceOp.SUM, self._torch.int64)
         return out.view(np.uint64)
@@ -95,21 +122,34 @@ class Comm(object):
         return out[0]
 
     def barrier(self):
-        self._dist.barrier(group=self.group)
+        if self.lib is not None:
+            self.lib.allreduce([0.0], 'f64', 'sum')
+        else:
+            self._dist.barrier(group=self.group)
 
     # ---- the per-iteration exchange ---------------------------------------------
     def attach(self, engine, n_cols):
-        """Give the engine a reduce buffer that torch can all-reduce in place, and
-        make the engine launch on torch's current stream so the collective is
-        ordered after the EM pass without a host sync."""
-        t = self._torch
-        self._red = t.zeros(n_cols + 2, dtype=t.float64, device=self.tdev)
+        """Real engine on RCCL: hand it the library communicator — it then all-reduces its own reduce
+        buffer inside `em_chunk` and nothing below is used.  Otherwise (gloo + the tests-only engine):
+        give the engine a reduce buffer that torch can all-reduce in place."""
         self._eng = engine
+        if self.lib is not None and hasattr(engine, 'comm_attach'):
+            engine.comm_attach(self.lib.handle)
+            self.in_library = True
+            return
+        from ._lib import Engine
+        if isinstance(engine, Engine):
+            raise RuntimeError('a HIP engine needs the nccl (RCCL) backend: its reduce buffer lives in HBM and the %s '
+                               'backend reduces host tensors' % self.backend)
+        t = self._torch
+        self.in_library = False
+        self._red = t.zeros(n_cols + 2, dtype=t.float64, device=self.tdev)
         engine.bind_reduce_buffer(self._red.data_ptr(), n_cols + 2)
-        if self.backend == 'nccl':
-            engine.set_stream(t.cuda.current_stream(self.tdev).cuda_stream)
 
     def allreduce_device(self, engine, offset=0, count=None):
+        if self.in_library:
+            engine.comm_allreduce(offset, count)
+            return
         red = self._red if count is None else self._red[offset:offset + count]
         self._dist.all_reduce(red, op=self._dist.ReduceOp.SUM, group=self.group)
 

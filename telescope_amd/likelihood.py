@@ -23,7 +23,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib
-from ._lib import Engine, EngineError, Z_CUR, Z_INITIAL, Z_PREV  # noqa: F401
+from ._lib import Engine, EngineError, Z_CUR, Z_FIRST, Z_INITIAL, Z_PREV, Z_USER  # noqa: F401
 
 REASSIGN_METHODS = ('exclude', 'choose', 'average', 'conf', 'unique', 'all')
 _MASK_DTYPE = {'exclude': np.int8, 'choose': np.int8, 'average': np.float64,
@@ -38,9 +38,13 @@ def score_lut(max_score, scale_factor=100.):
     return np.expm1((r * (1. / max_score)) * scale_factor)
 
 
+EM_CHUNK = 8      # iterations enqueued per host synchronisation (Engine.em_chunk decides convergence on the device)
+
+
 class _NullComm(object):
     """Single-rank stand-in for distributed.Comm."""
     rank, world = 0, 1
+    in_library = True     # nothing to exchange: the engine runs whole chunks of iterations by itself
 
     def max_scalar(self, v):
         return v
@@ -205,7 +209,9 @@ class TelescopeLikelihood(object):
 
     @z.setter
     def z(self, value):
+        """A caller-assigned z (the reference's `reassign` reads whatever `self.z` holds, model.py:837)."""
         self._z, self._z_which = value, None
+        self._user_z_loaded = False
 
     def _need_raw(self):
         if self._raw is None:
@@ -224,8 +230,8 @@ class TelescopeLikelihood(object):
         np.cumsum(np.bincount(rows, minlength=self.N), out=indptr[1:])
         return sp.csr_matrix((zdata[keep], r.indices[keep], indptr), shape=r.shape)
 
-    def _align(self, z):
-        """Values of sparse z laid out on Q's CSR pattern (0 where z has no entry)."""
+    def _align(self, z, fill=0.0):
+        """Values of sparse z laid out on Q's CSR pattern (`fill` where z has no entry)."""
         r = self._need_raw()
         z = sp.csr_matrix(z)
         if z.shape != r.shape:
@@ -239,7 +245,7 @@ class TelescopeLikelihood(object):
         pos = np.searchsorted(kq, kz)
         if np.any(pos >= len(kq)) or np.any(kq[np.minimum(pos, len(kq) - 1)] != kz):
             raise ValueError('z has entries outside the score matrix pattern')
-        out = np.zeros(r.nnz)
+        out = np.full(r.nnz, fill, dtype=np.float64)
         out[pos] = z.data
         return out
 
@@ -252,15 +258,16 @@ class TelescopeLikelihood(object):
     def mstep(self, z):
         """model.py:724-742."""
         lg.debug('started m-step')
-        if self.comm.world > 1:
-            raise NotImplementedError('public mstep(z) is single-rank; em() is the sharded path')
-        return self._eng.mstep(self._align(z))
+        if self.comm.world > 1 and not getattr(self.comm, 'in_library', False):
+            raise NotImplementedError('sharded mstep(z) needs the library communicator (nccl backend)')
+        return self._eng.mstep(self._align(z))    # row-sharded: the library sums thetasum over the ranks
 
     def calculate_lnl(self, z, pi, theta):
         """model.py:744-760."""
         lg.debug('started lnl')
         cur = self._eng.calc_lnl(self._align(z), pi, theta)
-        cur = float(self.comm.sum_array(np.array([cur]))[0])
+        if self.comm.world > 1 and not getattr(self.comm, 'in_library', False):
+            cur = float(self.comm.sum_array(np.array([cur]))[0])
         lg.debug('completed lnl')
         return cur
 
@@ -268,38 +275,64 @@ class TelescopeLikelihood(object):
     def em(self, use_likelihood=False, loglev=lg.WARNING, save_memory=True):
         """model.py:762-806 — same control flow, log lines and final state.
 
-        One fused E+M device pass per iteration; multi-rank runs all-reduce the
-        per-locus column sums between the pass and the parameter update.
+        One fused E+M device pass per iteration.  The engine runs CHUNKS of iterations without a host
+        round trip (`Engine.em_chunk`): pass, all-reduce of the per-locus column sums over the library's
+        RCCL communicator (row-sharded runs), update, and — decided on the device — the convergence
+        test; kernels enqueued behind the converging iteration return at once, so the state after the
+        call is the reference's.  The log lines of a chunk are emitted when it returns.
         """
         inum, converged, reached_max = 0, False, False
         msgD = 'Iteration {:d}, diff={:.5g}'
         msgL = 'Iteration {:d}, lnl= {:.5e}, diff={:.5g}'
         from time import perf_counter
         eng, comm, K = self._eng, self.comm, self.K
+        chunked = getattr(comm, 'in_library', False) and hasattr(eng, 'em_chunk')
+        timeouts = 0
         while not (converged or reached_max):
             xtime = perf_counter()
-            eng.em_pass()                       # estep + mstep column sums (local rows)
-            comm.allreduce_device(eng, 0, K)    # sum over ranks (RCCL), no-op single rank
-            diff_est = eng.em_update()          # theta_hat, pi_hat, |pi_hat - pi|_1
-            inum += 1
-            if inum == 1:
-                self.pi_init, self.theta_init = eng.get_params(Z_CUR)
-            if use_likelihood:
-                _lnl = self._device_lnl()
-                diff_lnl = abs(_lnl - self.lnl)
-                lg.log(loglev, msgL.format(inum, _lnl, diff_est))
-                converged = diff_lnl < self.epsilon
-                self.lnl = _lnl
+            if chunked:
+                want = max(1, min(EM_CHUNK, self.max_iter - inum))
+                diffs, lnls, converged = eng.em_chunk(want, self.epsilon, use_likelihood, first=(inum == 0))
+                for i, diff_est in enumerate(diffs):
+                    inum += 1
+                    if use_likelihood:
+                        self.lnl = float(lnls[i])
+                        lg.log(loglev, msgL.format(inum, self.lnl, diff_est))
+                    else:
+                        lg.log(loglev, msgD.format(inum, diff_est))
             else:
-                lg.log(loglev, msgD.format(inum, diff_est))
-                converged = diff_est < self.epsilon
+                # host-driven exchange (gloo / in-process communicators): one iteration per round trip
+                eng.em_pass()                       # estep + mstep column sums (local rows)
+                comm.allreduce_device(eng, 0, K + 1)   # sum over ranks; slot K carries the time-out flag
+                try:
+                    diff_est = eng.em_update()      # theta_hat, pi_hat, |pi_hat - pi|_1
+                except EngineError as exc:          # a rank's persistent kernel timed out: nobody committed
+                    timeouts += 1
+                    if exc.code != _lib.ERR_TIMEOUT or timeouts > 3:
+                        raise
+                    eng.recover_timeout()           # that rank switches to the two-pass kernels
+                    continue
+                inum += 1
+                if inum == 1:
+                    self.pi_init, self.theta_init = eng.get_params(Z_CUR)
+                if use_likelihood:
+                    _lnl = self._device_lnl()
+                    diff_lnl = abs(_lnl - self.lnl)
+                    lg.log(loglev, msgL.format(inum, _lnl, diff_est))
+                    converged = diff_lnl < self.epsilon
+                    self.lnl = _lnl
+                else:
+                    lg.log(loglev, msgD.format(inum, diff_est))
+                    converged = diff_est < self.epsilon
             reached_max = inum >= self.max_iter
             lg.debug("time: {}".format(perf_counter() - xtime))
+        if chunked:
+            self.pi_init, self.theta_init = eng.get_params(Z_FIRST)
         self.pi, self.theta = eng.get_params(Z_CUR)
         self._z, self._z_which = None, Z_PREV   # z of the last E-step, exported on demand
         _con = 'converged' if converged else 'terminated'
         if not use_likelihood:
-            self.lnl = self._device_lnl()
+            self.lnl = eng.final_lnl() if chunked else self._device_lnl()
         self.n_iter, self.converged = inum, converged
         lg.log(loglev, 'EM {:s} after {:d} iterations.'.format(_con, inum))
         lg.log(loglev, 'Final log-likelihood: {:f}.'.format(self.lnl))
@@ -318,7 +351,10 @@ class TelescopeLikelihood(object):
         if self._z_which is None:
             if self._z is None:
                 raise ValueError('reassign() before em(): no posteriors yet')
-            raise NotImplementedError('reassign() on a caller-assigned z is not supported')
+            if not getattr(self, '_user_z_loaded', False):   # a caller assigned tl.z: the device reads it as is
+                self._eng.set_user_z(self._align(self._z, fill=np.nan))
+                self._user_z_loaded = True
+            return Z_USER
         return self._z_which
 
     def _picks(self, which):

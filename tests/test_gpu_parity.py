@@ -270,8 +270,8 @@ def test_em_is_reproducible_and_blocksize_independent(gpu_device):
 
 
 def test_rccl_comm_path_single_rank(gpu_device):
-    """The N > 1 plumbing on a real GPU with a 1-rank RCCL group: torch-owned reduce tensor bound
-    into the engine, launches on torch's stream, in-place all-reduce between pass and update."""
+    """The N > 1 plumbing on a real GPU with a 1-rank RCCL group (the library's own communicator, created from
+    an id shipped over torch.distributed; see also tests/test_gpu_round2.py)."""
     import socket
     import torch
     import torch.distributed as dist
@@ -292,6 +292,7 @@ def test_rccl_comm_path_single_rank(gpu_device):
             np.random.seed(int(c['seed']))
             assert np.array_equal(tl.reassign_colsums('choose'), c['ra_choose_0_colsum'])
             assert np.array_equal(tl.reassign_colsums('exclude'), c['ra_exclude_0_colsum'])
+        comm.close()
     finally:
         dist.destroy_process_group()
 
