@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--fused-dbg', type=int, default=0)
     ap.add_argument('--sorted-fill', type=int, default=-1, help='sub-block order: 1 row order, 0 strand-transposed (-1 auto)')
     ap.add_argument('--geometry', type=int, default=-1, help='fused kernel geometry of teams of 1-4: 0 or 2 (-1 auto)')
+    ap.add_argument('--deconflict', type=int, default=1, help='0: plain entry order inside rows (experiments)')
     ap.add_argument('--parts', type=int, default=0, help='column parts per team (0 = fewest that fit LDS)')
     ap.add_argument('--hot-split', type=int, default=1, help='0: one accumulator slot per column (experiments)')
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
@@ -182,6 +183,7 @@ def main():
     if args.fused_dbg:
         eng.set_option('fused_dbg', args.fused_dbg)
     eng.set_option('hot_split', args.hot_split)
+    eng.set_option('deconflict', args.deconflict)
     t_setup = time.perf_counter()
     eng.generate(r0, r1, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
     tl = TelescopeLikelihood.from_engine(eng, Opts(args.steps), comm)

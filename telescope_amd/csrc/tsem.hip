@@ -491,6 +491,72 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
   }
 }
 
+// Conflict-aware entry order INSIDE the rows of the row-ordered layout (score codes).  The column scatter of the
+// fused kernel (ds_add_f64 into the part's accumulators) is served in four groups of 16 lanes, each at 2 clk x the
+// largest number of lanes whose slots agree modulo 16 (tools/ubench/lds.hip: 16 slots distinct mod 32 but pairwise
+// equal mod 16 cost 16 clk, distinct mod 16 cost 8, random 24.5); SQ_LDS_BANK_CONFLICT is a third of the LDS-array
+// cycles of the pass (profiles/r02_lds_counters.txt).  One such group and instruction covers the entries at
+// positions = j (mod 4) of a WINDOW of 64 consecutive entries (16 lanes x 4 entries; sub-blocks are padded to 64,
+// so windows never straddle them).  Any order inside a row is valid, so every window is walked once, row segment
+// by row segment, and each position takes — among the entries of its row that are still unplaced — the one whose
+// slot class is rarest so far in its (window, j) bin: mean worst multiplicity 3.1 -> 2.2 (the bound for a fixed
+// row order is ~2.1: a window holds ~8 entries of its most popular class).  One thread per window; windows are
+// independent.  The padding at the end of a sub-block (code 0) stays where it is.
+constexpr int DC_NT = 128;
+__global__ __launch_bounds__(DC_NT) void k_sb_deconflict(int64_t n_win, uint32_t* __restrict__ prc, uint16_t* __restrict__ pcode) {
+  __shared__ uint32_t sp[DC_NT * 65];                      // [window][64 (+1: lanes walk their windows bank-conflict-free)]
+  __shared__ uint32_t sc[DC_NT * 65];
+  for (int64_t w0 = (int64_t)blockIdx.x * DC_NT; w0 < n_win; w0 += (int64_t)gridDim.x * DC_NT) {
+    const int64_t base = w0 * 64;
+    const int nw = (int)min((int64_t)DC_NT, n_win - w0);
+    for (int t = threadIdx.x; t < nw * 64; t += DC_NT) {
+      sp[(t >> 6) * 65 + (t & 63)] = prc[base + t];
+      sc[(t >> 6) * 65 + (t & 63)] = pcode[base + t];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nw) {
+      uint32_t* const Pw = sp + threadIdx.x * 65;
+      uint32_t* const Cw = sc + threadIdx.x * 65;
+      unsigned long long h[4] = {0ull, 0ull, 0ull, 0ull};  // per instruction slot j: 16 four-bit counters, one per class
+      int i = 0;
+      while (i < 64 && Cw[i] != 0u) {
+        const uint32_t row = Pw[i] >> 16;
+        int e = i + 1;
+        while (e < 64 && (Pw[e] >> 16) == row && Cw[e] != 0u) ++e;
+        for (int pos = i; pos < e - 1; ++pos) {             // (the last entry of the segment has no choice)
+          const int j = pos & 3;
+          const unsigned long long hj = j == 0 ? h[0] : (j == 1 ? h[1] : (j == 2 ? h[2] : h[3]));
+          int best = pos; unsigned bl = 99u;
+          for (int k = pos; k < e && bl; ++k) {
+            const unsigned l = (unsigned)(hj >> ((Pw[k] & 15u) * 4u)) & 15u;
+            if (l < bl) { bl = l; best = k; }
+          }
+          if (best != pos) {
+            const uint32_t tp = Pw[pos], tc = Cw[pos];
+            Pw[pos] = Pw[best]; Cw[pos] = Cw[best]; Pw[best] = tp; Cw[best] = tc;
+          }
+          const unsigned long long inc = (bl < 15u ? 1ull : 0ull) << ((Pw[pos] & 15u) * 4u);
+          if (j == 0) h[0] += inc; else if (j == 1) h[1] += inc; else if (j == 2) h[2] += inc; else h[3] += inc;
+        }
+        {                                                  // count the segment's last entry too
+          const int pos = e - 1, j = pos & 3;
+          const unsigned long long hj = j == 0 ? h[0] : (j == 1 ? h[1] : (j == 2 ? h[2] : h[3]));
+          const unsigned l = (unsigned)(hj >> ((Pw[pos] & 15u) * 4u)) & 15u;
+          const unsigned long long inc = (l < 15u ? 1ull : 0ull) << ((Pw[pos] & 15u) * 4u);
+          if (j == 0) h[0] += inc; else if (j == 1) h[1] += inc; else if (j == 2) h[2] += inc; else h[3] += inc;
+        }
+        i = e;
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nw * 64; t += DC_NT) {
+      prc[base + t] = sp[(t >> 6) * 65 + (t & 63)];
+      pcode[base + t] = (uint16_t)sc[(t >> 6) * 65 + (t & 63)];
+    }
+    __syncthreads();
+  }
+}
+
 // ============================================================================
 // EM hot loop — two-pass form (phase 1: partial row sums; phase 2: scatter)
 // ============================================================================
@@ -1155,6 +1221,9 @@ template <int P> static fz_fn fz_pick(int mode, int fmt, int geo) {
 }
 static int fz_fmt(const tsem_ctx* h) { return h->fmt_code ? 1 : (h->fmt_wcode ? 2 : 0); }
 static fz_fn fz_kernel(int P, int mode, int fmt, int geo) {
+#ifdef TSEM_FAST_BUILD                                     // kernel experiments (tools/ab.sh): teams of 4 only, 1/8 of the build time
+  return P == 4 ? fz_pick<4>(mode, fmt, geo) : nullptr;
+#else
   switch (P) {
     case 1: return fz_pick<1>(mode, fmt, geo); case 2: return fz_pick<2>(mode, fmt, geo);
     case 3: return fz_pick<3>(mode, fmt, geo); case 4: return fz_pick<4>(mode, fmt, geo);
@@ -1162,6 +1231,7 @@ static fz_fn fz_kernel(int P, int mode, int fmt, int geo) {
     case 7: return fz_pick<7>(mode, fmt, geo); case 8: return fz_pick<8>(mode, fmt, geo);
     default: return nullptr;
   }
+#endif
 }
 
 // code16 entry format: only with the fused kernel, and only while the score table is small enough to
@@ -1173,7 +1243,7 @@ static bool fz_wants_codes(const tsem_ctx* h) {
   return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048 && (h->opt_format == 2 || h->run_len_est >= 4.0);
 }
 static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
-  return (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192 + (codes ? (size_t)h->lut_len * 8 : 0);
+  return (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0);
 }
 
 static void free_layout(tsem_ctx* h) {
@@ -1257,6 +1327,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "hot_split") h->opt_hot_split = v;
   else if (k == "geometry") h->opt_geo = v;
   else if (k == "sorted_fill") h->opt_sorted = v;
+  else if (k == "deconflict") h->opt_deconflict = v;
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
     if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
@@ -1443,7 +1514,7 @@ static int choose_geometry(tsem_ctx* h) {
       if (h->opt_geo >= 0 && P <= 4) h->geo = h->opt_geo == 2 ? 2 : 0;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
-      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2048 - 2 * Kp * 8 - lut_bytes) / ((FZ_YR + 2) * 8));
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - 2 * Kp * 8 - lut_bytes) / ((FZ_YR + 2) * 8));
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
       R = std::min(R, rmax / 8 * 8);
@@ -1707,17 +1778,22 @@ static int build_layout(tsem_ctx* h) {
     TSEM_ALLOC(h->d_pval, off);
     TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
   }
-  // Row order pays when the runs are long and the LDS is the limit (score codes): 40 nnz/row at P = 4
-  // 4.70 -> 4.06 ms; with runs of ~5 entries or with fp64 entries (HBM-bound) the plain order is as
-  // fast or faster (fewer VALU instructions): measured matrix in DESIGN.md 9.
+  // Row order pays when the LDS is the limit (score codes) and a row has >= 4 entries per part: 40 nnz/row at
+  // P = 4 4.46 -> 3.57 ms, 20 nnz/row 2.73 -> 2.38 ms, but 10 nnz/row 2.23 -> 2.80 ms; with fp64 entries (bound by
+  // the memory path) the plain order is as fast or faster: gpurun_out/sweep_r02a.log, DESIGN.md 9.
   const double run_len = na > 0 ? (double)(h->nnz - h->N_uni) / (double)na / P : 0.0;
   h->sorted_layout = h->use_fused && R * P <= 512 * 8 &&   // (the fill kernel keeps R x P counters in LDS)
-                     (h->opt_sorted >= 0 ? h->opt_sorted != 0 : (h->fmt_code && run_len >= 8.0));
+                     (h->opt_sorted >= 0 ? h->opt_sorted != 0 : (h->fmt_code && run_len >= 4.0));
   if (nb && h->sorted_layout) {
     k_sb_fill_sorted<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
                                                          d_pc ? d_bs : nullptr, d_pc);
     TSEM_HIP(hipGetLastError());
+    if (h->fmt_code && h->opt_deconflict && off >= 64) {
+      const int64_t n_win = off / 64;
+      k_sb_deconflict<<<(unsigned)std::min<int64_t>(n_win / DC_NT + 1, (int64_t)h->n_cu * 8), DC_NT, 0, h->stream>>>(n_win, h->d_prc, h->d_pcode);
+      TSEM_HIP(hipGetLastError());
+    }
   } else if (nb) {
     k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                   h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc);

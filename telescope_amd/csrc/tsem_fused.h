@@ -221,7 +221,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   // issue the partner / weight loads of block k and the offset fetch of block ko (never branched around)
   auto issue = [&](Gen& g, int64_t k, int64_t ko) {
     {
-      const bool ok = offw && lane < 2 && ko >= 4 && ko < nblk;
+      const bool ok = offw && lane < 2 && ko >= 5 && ko < nblk;
       g.off = __builtin_amdgcn_raw_buffer_load_b32(qrsrc, ok ? (unsigned)(((team + ko * T) * P + p + lane) * 4) : FZ_OOB, 0, 0);
     }
     const bool kv = k >= 0 && k < nblk;
@@ -258,7 +258,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   };
   // combine block k from generation g: s = w * recip0(sum of the P partials), fixed order
   auto combine = [&](Gen& g, int64_t k, int64_t ko) {
-    if (offw && lane < 2 && ko >= 4 && ko < nblk) offs[(ko & 7) * 2 + lane] = g.off;   // blocks 0..3: prologue
+    if (offw && lane < 2 && ko >= 5 && ko < nblk) offs[(ko & 7) * 2 + lane] = g.off;   // blocks 0..4: prologue
     if (k < 0 || k >= nblk) return;
     const unsigned long long tag = tag_of(k);
 #pragma unroll
@@ -304,7 +304,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   int64_t i = 0;
   if (A.dbg & 8) {                                      // timing experiment: exchange waves only keep the barriers
     for (; i < nsteps; ++i) {
-      if (offw && lane < 2) { const int64_t ko = i + FZ_DL + 1; if (ko >= 4 && ko < nblk) offs[(ko & 7) * 2 + lane] = A.sb_q32[(team + ko * T) * P + p + lane]; }
+      if (offw && lane < 2) { const int64_t ko = i + FZ_DL + 2; if (ko >= 5 && ko < nblk) offs[(ko & 7) * 2 + lane] = A.sb_q32[(team + ko * T) * P + p + lane]; }
       __syncthreads();
     }
     return;
@@ -333,9 +333,11 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     // the publish must enter the memory pipe BEFORE this step's loads (partners read it a step later)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 2);         // ahead of the data waves' burst(i+2)
+    // sub-block offsets: fetched at step i for block i+5, parked in LDS at step i+1, read by the data waves
+    // during step i+2 (anywhere in the step: they carry them to step i+3 in SGPRs), used by burst(i+5) at step i+3
+    issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 3);         // ahead of the data waves' burst(i+2)
     if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
-    combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 1);       // issued one step ago, behind burst(i)
+    combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 2);       // issued one step ago, behind burst(i)
     if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
     if (A.prof && team == 0 && p == 0 && lane == 0 && X.xw == 1 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 9] = clock64();
     __syncthreads();
@@ -426,12 +428,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     return (unsigned long long)((((k / FZ_XS) & 1) ^ 1));
   };
   uint32_t* offs = reinterpret_cast<uint32_t*>(ibox + 16);   // [8][2] sub-block quad ranges (ring), LDS
-  double* lutS = reinterpret_cast<double*>(ibox + 32);       // FMT 1: score table [lut_len]
+  double* dum = reinterpret_cast<double*>(ibox + 32);        // [64] one slot per lane: where idle lanes send their (zero) atomics
+  double* lutS = dum + 64;                                   // FMT 1: score table [lut_len]
+  if (tid < 64) dum[tid] = 0.0;
   if (FMT != 0)
     for (int t = tid; t < A.lut_len; t += FZ_NT) lutS[t] = A.lut[t];
   const int64_t nsteps = nblk + FZ_LAG + 1;               // last scatter is block nblk-1 at step nblk+3
-  // prologue: offsets of blocks 0..3 straight into LDS
-  if (tid < 8) {
+  // prologue: offsets of blocks 0..4 straight into LDS
+  if (tid < 10) {
     const int64_t k = tid >> 1;
     if (k < nblk) offs[tid] = A.sb_q32[(team + k * T) * P + p + (tid & 1)];
   }
@@ -540,22 +544,86 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     FzRegs r6 = r0;
 #endif
     int64_t i = 0;
-    // step i: `rs` is the set of block i-LAG (scattered, then refilled with block i+2); `rp` the set of block i
-    auto step = [&](FzRegs& rs, FzRegs& rp) {
-      const bool pr = A.prof && team == 0 && p == 0 && tid == 0 && (int)i < A.prof_blocks;
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 0] = clock64();
-      // LDS read first, while the LDS queue is empty right after the barrier
+    // step i (lnl pass): `rs` is the set of block i-LAG (scattered, then refilled with block i+2); `rp` the set of block i
+    auto step_lnl = [&](FzRegs& rs, FzRegs& rp) {
       const uint32_t oq0 = offs[((i + FZ_DL) & 7) * 2], oq1 = offs[((i + FZ_DL) & 7) * 2 + 1];
       phase2(rs, i - FZ_LAG);
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 1] = clock64();
       load_blk(rs, oq0, oq1, i + FZ_DL);
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 2] = clock64();
       phase1(rp, i);                                      // waits for burst(i), issued two steps ago
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 3] = clock64();
-      if (A.prof && team == 0 && p == 0 && tid == FZ_DT - 64 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 8] = clock64();
       __syncthreads();
+      ++i;
+    };
+    // step i (EM pass).  The LDS is the busiest unit of the step (SQ_LDS_IDX_ACTIVE 70-82 % of the kernel time,
+    // profiles/r02_lds_counters.txt) and its queue is deep, so every LDS round trip a wave WAITS for costs
+    // hundreds of cycles.  Hence: (1) all gathers of the step — row factors s of block i-LAG, score table and
+    // pi*theta entries of block i, the offsets of the next burst — are issued back to back at the top: ONE
+    // round trip per step instead of three; (2) the row-sum atomics of block i go first and the four column
+    // scatters of block i-LAG LAST, unconditionally (idle lanes send 0.0 to a private dummy slot), and the wave
+    // enters the barrier as soon as all but those four have completed (`s_waitcnt lgkmcnt(4)`; LDS operations of
+    // a wave complete in order): nobody reads the column accumulators before the kernel ends, so the scatters
+    // drain behind the barrier while the next step's gathers queue up, and the LDS never runs dry at a barrier.
+    uint32_t oqa = offs[FZ_DL * 2], oqb = offs[FZ_DL * 2 + 1];            // offsets of burst(DL), used at step 0
+    const int lane_id = tid & 63;
+    auto step_em = [&](FzRegs& rs, FzRegs& rp) {
+      const bool pr = A.prof && team == 0 && p == 0 && tid == 0 && (int)i < A.prof_blocks;
+      if (pr) A.prof[i * FZ_PROF_SLOTS + 0] = clock64();
+      const int64_t k2 = i - FZ_LAG;
+      // ---- gathers ----
+      const uint32_t on0 = offs[((i + FZ_DL + 1) & 7) * 2], on1 = offs[((i + FZ_DL + 1) & 7) * 2 + 1];   // burst of the NEXT step
+      const bool idle2 = rs.rc.x == 0xFFFFFFFFu;
+      const uint32_t a0 = idle2 ? 0u : rs.rc.x, a1 = rs.rc.y, a2 = rs.rc.z, a3 = rs.rc.w;
+      const double* sb = s + (k2 & 1) * R;
+      const double s0 = sb[a0 >> 16], s1 = sb[a1 >> 16], s2 = sb[a2 >> 16], s3 = sb[a3 >> 16];
+      double2 q0 = rp.v0, q1 = rp.v1;
+      if (FMT == 1) {                                     // Q from the score table: the same fp64 the fp64 layout stores
+        q0 = make_double2(lutS[rp.cd.x & 0xFFFFu], lutS[rp.cd.x >> 16]);
+        q1 = make_double2(lutS[rp.cd.y & 0xFFFFu], lutS[rp.cd.y >> 16]);
+      }
+      const double c0 = c[rp.rc.x & 0xFFFF], c1 = c[rp.rc.y & 0xFFFF], c2 = c[rp.rc.z & 0xFFFF], c3 = c[rp.rc.w & 0xFFFF];
+      // ---- phase 1 of block i: numerators stay in the set, partial row sums into y(i) ----
+      // (padding has code 0 / value 0 -> numerator 0: no branch needed around the products)
+      const bool idle = FMT == 1 ? (rp.cd.x | rp.cd.y) == 0u
+                                 : (rp.v0.x == 0.0) & (rp.v0.y == 0.0) & (rp.v1.x == 0.0) & (rp.v1.y == 0.0);
+      const double m0 = q0.x * c0, m1 = q0.y * c1, m2 = q1.x * c2, m3 = q1.y * c3;
+      rp.v0 = make_double2(m0, m1); rp.v1 = make_double2(m2, m3);
+      double* yb = y + (i & (FZ_YR - 1)) * R;
+      if (pr) A.prof[i * FZ_PROF_SLOTS + 1] = clock64();
+      if (A.sorted) {
+        fz_row_sums(yb, idle, rp.rc.x >> 16, rp.rc.y >> 16, rp.rc.z >> 16, rp.rc.w >> 16, m0, m1, m2, m3);
+      } else {                                            // strand-transposed order: neighbouring entries never share a row
+        double* d = dum + lane_id;
+        lds_add(idle ? d : &yb[rp.rc.x >> 16], m0); lds_add(idle ? d : &yb[rp.rc.y >> 16], m1);
+        lds_add(idle ? d : &yb[rp.rc.z >> 16], m2); lds_add(idle ? d : &yb[rp.rc.w >> 16], m3);
+      }
+      if (idle) rp.rc.x = 0xFFFFFFFFu;
+      if (pr) A.prof[i * FZ_PROF_SLOTS + 3] = clock64();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 2 of block i-LAG: w*z into the part's column accumulators; ALWAYS four atomics, issued last ----
+      {
+        const uint32_t dj = (uint32_t)(dum - acc) + (uint32_t)lane_id;   // the lane's dummy slot as an index into acc[]
+        const uint32_t j0 = idle2 ? dj : (a0 & 0xFFFFu), j1 = idle2 ? dj : (a1 & 0xFFFFu);
+        const uint32_t j2 = idle2 ? dj : (a2 & 0xFFFFu), j3 = idle2 ? dj : (a3 & 0xFFFFu);
+        lds_add(&acc[j0], rs.v0.x * s0);
+        lds_add(&acc[j1], rs.v0.y * s1);
+        lds_add(&acc[j2], rs.v1.x * s2);
+        lds_add(&acc[j3], rs.v1.y * s3);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      load_blk(rs, oqa, oqb, i + FZ_DL);                  // the set is free again: refill it with block i+DL
+      if (pr) A.prof[i * FZ_PROF_SLOTS + 2] = clock64();
+      if (A.prof && team == 0 && p == 0 && tid == FZ_DT - 64 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 8] = clock64();
+      __builtin_amdgcn_s_waitcnt(0xC47F);                 // lgkmcnt(4): everything but the four scatters above has completed
+      oqa = __builtin_amdgcn_readfirstlane(on0); oqb = __builtin_amdgcn_readfirstlane(on1);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       if (pr) A.prof[i * FZ_PROF_SLOTS + 4] = clock64();
       ++i;
+    };
+    auto step = [&](FzRegs& rs, FzRegs& rp) {
+      if (MODE == 1) step_lnl(rs, rp); else step_em(rs, rp);
     };
     load_blk(r0, offs[0], offs[1], 0);
     load_blk(r1, offs[2], offs[3], 1);

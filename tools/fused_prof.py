@@ -19,7 +19,7 @@ eng.set_option('fused_prof', 1)
 eng.em_steps(1, False)
 t = eng.fused_prof().astype(np.int64)
 print(eng.layout_info())
-names = ['start', 'P2 done', 'burst issued', 'P1 done', 'barrier', 'x:combined', 'x:start', 'x:issued', 'P1 done w13', 'x1:combined']
+names = ['start', 'ops gathered', 'burst issued', 'P1 atomics', 'barrier', 'x:combined', 'x:start', 'x:issued', 'w13 pre-wait', 'x1:combined']
 base = t[4, 0]
 print('cycles relative to block start (blocks 4..11); clock ~2.1-2.4 GHz (shader clock / s_memtime)')
 print('%-6s' % 'blk' + ''.join('%13s' % n for n in names) + '%12s' % 'blk total')

@@ -38,6 +38,13 @@ __global__ __launch_bounds__(1024) void k(int H, int iters, int act, double* out
   if (MODE == 13) {                                  // 2 lanes of every 16 share a class, otherwise distinct
     for (int j = 0; j < 4; ++j) idx[j] = (uint32_t)(((mix(tid * 4 + j) % (H / 32)) * 32 + ((lane % 16) / 2) * 2 + 16 * ((lane / 16) & 1)) % H);
   }
+  if (MODE == 14) {                                  // 16 lanes: distinct mod 32, but lanes l and l+8 collide mod 16
+    for (int j = 0; j < 4; ++j) idx[j] = (uint32_t)(((mix(tid * 4 + j) % (H / 32)) * 32 + ((lane % 16) < 8 ? (lane % 8) : (lane % 8) + 16)) % H);
+  }
+  if (MODE == 15 || MODE == 16) {                    // gathers: class = lane % 32 (MODE 15) / lane % 16 (MODE 16: lanes l, l+16 collide), random row
+    const int md = MODE == 15 ? 32 : 16;
+    for (int j = 0; j < 4; ++j) idx[j] = (uint32_t)(((mix(tid * 4 + j) % (H / 32)) * 32 + (lane % md)) % H);
+  }
   const bool on = (MODE == 2 || MODE == 6) ? ((mix(lane * 77u + 5u) & 63u) < (unsigned)act) : true;
   double a = 0.0;
   __syncthreads();
@@ -47,9 +54,9 @@ __global__ __launch_bounds__(1024) void k(int H, int iters, int act, double* out
       a += tab[idx[0]] + tab[idx[1]] + tab[idx[2]] + tab[idx[3]];
     } else if (MODE == 6) {
       if (on) a += tab[idx[0]] + tab[idx[1]] + tab[idx[2]] + tab[idx[3]];
-    } else if (MODE == 9) {
+    } else if (MODE == 9 || MODE == 15 || MODE == 16) {
       a += tab[idx[0]] + tab[idx[1]] + tab[idx[2]] + tab[idx[3]];
-    } else if (MODE == 1 || MODE == 3 || MODE == 8 || MODE == 10 || MODE == 11 || MODE == 12 || MODE == 13) {
+    } else if (MODE == 1 || MODE == 3 || MODE == 8 || MODE == 10 || MODE == 11 || MODE == 12 || MODE == 13 || MODE == 14) {
       lds_add(&tab[idx[0]], 1.0); lds_add(&tab[idx[1]], 1.0); lds_add(&tab[idx[2]], 1.0); lds_add(&tab[idx[3]], 1.0);
     } else if (MODE == 2) {
       if (on) { lds_add(&tab[idx[0]], 1.0); lds_add(&tab[idx[1]], 1.0); lds_add(&tab[idx[2]], 1.0); lds_add(&tab[idx[3]], 1.0); }
@@ -108,5 +115,8 @@ int main() {
   run<11>("ds_add_f64 class = lane % 16, random row", 7424, 64);
   run<12>("ds_add_f64 class = lane % 32, random row", 7424, 64);
   run<13>("ds_add_f64 pairs share a class in each 16 lanes", 7424, 64);
+  run<14>("ds_add_f64 16 lanes distinct mod 32, pairs equal mod 16", 7424, 64);
+  run<15>("gather b64 class = lane % 32, random row", 7424, 64);
+  run<16>("gather b64 class = lane % 16 (l, l+16 collide)", 7424, 64);
   return 0;
 }
