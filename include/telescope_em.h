@@ -73,6 +73,9 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *                  has <= 2048 entries), 1 fp64 Q values, 2 codes (error if not possible)
  *   "hot_split"    1 (default): very popular columns get several accumulator slots
  *   "row_offset"   global index of this rank's first row (synthetic generator, column signatures)
+ *   "deconflict"   1 (default): conflict-aware entry order inside the rows of the row-ordered code layout
+ *   "em_precision" 1: the EM pass in fp32 arithmetic (row sums, posteriors and column sums in fp32) — a
+ *                  DIAGNOSTIC for the fp32-vs-fp64 tolerance sweep of BASELINE config 3, not a product path
  *   "fused_dbg", "fused_prof", "chunk_blocks"     timing experiments */
 int  tsem_set_option(tsem_ctx* h, const char* key, int64_t value);
 int  tsem_synchronize(tsem_ctx* h);

@@ -1118,6 +1118,54 @@ __global__ void k_hats(int K, const double* __restrict__ ts, const double* __res
   pi_hat[j] = ((pisum0[j] + ts[j]) + pi_pw) / pi_den;
 }
 
+// ---- reduced-precision EM pass (BASELINE config 3: the fp32 leg of the tolerance sweep) -------------
+// A DIAGNOSTIC, not a product path: the E-step products, the row sums, the posteriors and the column sums are all
+// fp32.  Q = expm1(100 s / max) reaches 2.7e43 > FLT_MAX, so the score table is scaled by 2^-64
+// (exact) before rounding to fp32, and pi*theta by 1 / max_j(pi*theta) (z is invariant under both); products
+// that still underflow are lost — which is what the sweep is there to measure.  One 16-lane group per row of the
+// canonical CSR, fp32 global atomics for the column sums.
+constexpr int F32_SHIFT = 64;
+__global__ void k_cmax(int K, const double* __restrict__ pi, const double* __restrict__ theta, unsigned long long* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double v = j < K ? pi[j] * theta[j] : 0.0;
+  v = sg_max<64>(v);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(v));   // non-negative doubles order like integers
+}
+__global__ void k_make_c32(int K, const double* __restrict__ pi, const double* __restrict__ theta,
+                           const unsigned long long* __restrict__ cmax, float* __restrict__ c32) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  const double m = __longlong_as_double((long long)*cmax);
+  c32[j] = (float)((pi[j] * theta[j]) / (m > 0.0 ? m : 1.0));
+}
+__global__ void k_lut32(int n, const double* __restrict__ lut, float* __restrict__ lut32) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lut32[i] = (float)ldexp(lut[i], -F32_SHIFT);
+}
+__global__ __launch_bounds__(256) void k_em_rows_f32(int64_t N, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const uint16_t* __restrict__ raw, const float* __restrict__ lut32, const float* __restrict__ c32, float* __restrict__ colsums) {
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
+    const int64_t s = indptr[row], e = indptr[row + 1];
+    if (e - s < 2) continue;                               // unique rows feed pi through pisum0 only (model.py:699)
+    float y = 0.f, w = 0.f;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) { const float q = lut32[raw[k]]; y += q * c32[indices[k]]; w = fmaxf(w, q); }
+#pragma unroll
+    for (int o = RP_SUB / 2; o > 0; o >>= 1) { y += __shfl_xor(y, o, RP_SUB); w = fmaxf(w, __shfl_xor(w, o, RP_SUB)); }
+    float r = 1.f / y;
+    if (isinf(r)) r = 0.f;                                 // recip0, sparse_plus.py:16-22
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      const float v = ((lut32[raw[k]] * c32[indices[k]]) * r) * w;
+      if (v != 0.f) unsafeAtomicAdd(&colsums[indices[k]], v);
+    }
+  }
+}
+__global__ void k_red_from_f32(int K, const float* __restrict__ colsums, double* __restrict__ red) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < K) red[j] = ldexp((double)colsums[j], F32_SHIFT);
+  if (j == 0) { red[K] = 0.0; red[K + 1] = 0.0; }
+}
+
 // ---- csr_matrix_plus primitives on fp64 CSR --------------------------------
 __global__ __launch_bounds__(256) void k_norm_rows(int64_t N, const int64_t* __restrict__ indptr,
                                                    const double* __restrict__ data, double* __restrict__ out) {
@@ -1258,6 +1306,7 @@ static void free_matrix(tsem_ctx* h) {
   free_layout(h);
   dfree(h->d_pi); dfree(h->d_theta); dfree(h->d_pi_prev); dfree(h->d_theta_prev);
   dfree(h->d_ctab); dfree(h->d_ctab_prev); dfree(h->d_red_own); dfree(h->d_tmp_pi); dfree(h->d_tmp_theta);
+  dfree(h->d_c32); dfree(h->d_cs32); dfree(h->d_lut32);
   dfree(h->d_ctl); dfree(h->d_ctld); dfree(h->d_lnls); dfree(h->d_pi_first); dfree(h->d_theta_first); dfree(h->d_user_z);
   h->first_pending = false;
   h->d_red = nullptr;
@@ -1328,6 +1377,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "geometry") h->opt_geo = v;
   else if (k == "sorted_fill") h->opt_sorted = v;
   else if (k == "deconflict") h->opt_deconflict = v;
+  else if (k == "em_precision") h->opt_precision = v;
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
     if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
@@ -1346,6 +1396,7 @@ int tsem_synchronize(tsem_ctx* h) {
 static int set_lut(tsem_ctx* h, const double* lut, int32_t lut_len) {
   if (!lut || lut_len <= 0 || lut_len > 65536) TSEM_FAIL(TSEM_ERR_ARG, "lut must have 1..65536 entries");
   h->lut_len = lut_len;
+  dfree(h->d_lut32); dfree(h->d_c32); dfree(h->d_cs32);      // (the fp32 diagnostic tables follow the score table)
   h->lut_host.assign(lut, lut + lut_len);
   TSEM_ALLOC(h->d_lut, lut_len);
   TSEM_HIP(hipMemcpy(h->d_lut, lut, sizeof(double) * lut_len, hipMemcpyHostToDevice));
@@ -1997,9 +2048,29 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
   return TSEM_OK;
 }
 
+static int rowpass_grid(tsem_ctx* h);
+// the fp32 diagnostic pass (option "em_precision" = 1): same outputs as tsem_em_pass, fp32 arithmetic
+static int em_pass_f32(tsem_ctx* h) {
+  const int K = h->K;
+  if (!h->d_c32) {
+    TSEM_ALLOC(h->d_c32, K); TSEM_ALLOC(h->d_cs32, K); TSEM_ALLOC(h->d_lut32, h->lut_len);
+    k_lut32<<<cdiv64(h->lut_len, 256), 256, 0, h->stream>>>(h->lut_len, h->d_lut, h->d_lut32);
+  }
+  unsigned long long* cmax = reinterpret_cast<unsigned long long*>(h->d_lnl_part + 12000);
+  TSEM_HIP(hipMemsetAsync(cmax, 0, 8, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_cs32, 0, sizeof(float) * K, h->stream));
+  k_cmax<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, cmax);
+  k_make_c32<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, cmax, h->d_c32);
+  if (h->N) k_em_rows_f32<<<rowpass_grid(h), 256, 0, h->stream>>>(h->N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut32, h->d_c32, h->d_cs32);
+  k_red_from_f32<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_cs32, h->d_red);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
 int tsem_em_pass(tsem_ctx* h) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
+  if (h->opt_precision == 1) return em_pass_f32(h);
   hipEvent_t* pair = nullptr;
   if (int rc = begin_timing(h, &pair)) return rc;
   bool fused_done = false;

@@ -96,6 +96,8 @@ struct tsem_ctx {
   double* d_pval = nullptr;         // [nnz_pad]  Q values (fp64 entry format)
   uint16_t* d_pcode = nullptr;      // [nnz_pad]  raw score codes (code16 entry format: Q = lut[code])
   int64_t opt_sorted = -1;          // -1 auto, 0: strand-transposed sub-blocks, 1: row-ordered sub-blocks (fused layout)
+  int64_t opt_precision = 0;        // 1: the EM pass in fp32 arithmetic (diagnostic for the config-3 tolerance sweep)
+  float *d_c32 = nullptr, *d_cs32 = nullptr, *d_lut32 = nullptr;
   int64_t opt_deconflict = 1;       // 1: conflict-aware entry order inside the rows of the row-ordered code layout (k_sb_deconflict)
   int64_t opt_geo = -1;             // -1 auto; 0 / 2 force the geometry of teams of 1-4 (experiments)
   double run_len_est = 0.0;         // mean entries per ambiguous row and column part (set by tsem_rowstats)

@@ -30,12 +30,21 @@ _MASK_DTYPE = {'exclude': np.int8, 'choose': np.int8, 'average': np.float64,
                'conf': np.float64, 'unique': np.uint8, 'all': np.uint8}
 
 
-def score_lut(max_score, scale_factor=100.):
+def score_lut(max_score, scale_factor=100., mantissa_bits=53):
     """Q for every raw score 0..max_score with the reference's numpy expression
     (model.py:653 via sparse_plus.py:89-91: `raw.multiply(1./max).multiply(100.).expm1()`),
-    so Q is bit-identical to the reference's."""
+    so Q is bit-identical to the reference's.
+
+    `mantissa_bits` < 53 rounds every Q to that many significant bits (24 = what an fp32 value format
+    would store, 11 = fp16, 8 = bf16; the exponent range stays fp64's, i.e. a power-of-two scale is
+    assumed): the STORAGE-precision leg of BASELINE config 3's tolerance sweep (tools/precision_sweep.py).
+    The product default is 53: exact."""
     r = np.arange(int(max_score) + 1, dtype=np.uint16)
-    return np.expm1((r * (1. / max_score)) * scale_factor)
+    q = np.expm1((r * (1. / max_score)) * scale_factor)
+    if mantissa_bits < 53:
+        m, e = np.frexp(q)
+        q = np.ldexp(np.round(np.ldexp(m, mantissa_bits)), e - mantissa_bits)
+    return q
 
 
 EM_CHUNK = 8      # iterations enqueued per host synchronisation (Engine.em_chunk decides convergence on the device)
@@ -130,7 +139,9 @@ class TelescopeLikelihood(object):
         local_max = int(raw.data.max()) if raw.nnz else 0
         self.max_score = self.comm.max_scalar(local_max)             # model.py:640 (global)
         self.scale_factor = 100.                                     # model.py:652
-        self._lut = score_lut(self.max_score, self.scale_factor) if self.max_score > 0 \
+        engine_options = dict(engine_options or {})
+        self._mantissa_bits = int(engine_options.pop('lut_mantissa_bits', 53))   # host-side knob, see score_lut
+        self._lut = score_lut(self.max_score, self.scale_factor, self._mantissa_bits) if self.max_score > 0 \
             else np.zeros(1)
 
         self.epsilon = opts.em_epsilon                               # model.py:661-662
@@ -149,16 +160,17 @@ class TelescopeLikelihood(object):
         self._setup_model()
 
     @classmethod
-    def from_engine(cls, engine, opts, comm=None):
+    def from_engine(cls, engine, opts, comm=None, lut_mantissa_bits=53):
         """Wrap an engine whose score matrix is already resident (device-generated)."""
         self = cls.__new__(cls)
+        self._mantissa_bits = int(lut_mantissa_bits)
         self.comm = comm if comm is not None else _NullComm()
         self.raw_scores = self._raw = None
         self._eng = engine
         self.N, self.K, _ = engine.dims()
         self.max_score = self.comm.max_scalar(engine.max_score())   # model.py:640 (global)
         self.scale_factor = 100.
-        self._lut = score_lut(self.max_score) if self.max_score > 0 else np.zeros(1)
+        self._lut = score_lut(self.max_score, mantissa_bits=self._mantissa_bits) if self.max_score > 0 else np.zeros(1)
         engine.set_lut(self._lut)
         self.epsilon, self.max_iter = opts.em_epsilon, opts.max_iter
         self.pi_prior, self.theta_prior = opts.pi_prior, opts.theta_prior
