@@ -60,7 +60,9 @@ def parse():
     ap.add_argument('--fused-dbg', type=int, default=0)
     ap.add_argument('--sorted-fill', type=int, default=-1, help='sub-block order: 1 row order, 0 strand-transposed (-1 auto)')
     ap.add_argument('--geometry', type=int, default=-1, help='fused kernel geometry of teams of 1-4: 0 or 2 (-1 auto)')
-    ap.add_argument('--deconflict', type=int, default=1, help='0: plain entry order inside rows (experiments)')
+    ap.add_argument('--kernel-timing', type=int, default=4,
+                    help='HIP events around every n-th EM pass of the timed region (roofline.kernel_ms); 0 = none')
+    ap.add_argument('--deconflict', type=int, default=0, help='1: conflict-aware entry order inside rows (library option, default off)')
     ap.add_argument('--parts', type=int, default=0, help='column parts per team (0 = fewest that fit LDS)')
     ap.add_argument('--hot-split', type=int, default=1, help='0: one accumulator slot per column (experiments)')
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
@@ -70,6 +72,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-layout', action='store_true',
                     help='skip the second measurement with 2-byte score codes (N=1, default --value-format only)')
+    ap.add_argument('--no-precision-sweep', action='store_true',
+                    help='skip the fp32-vs-fp64 tolerance sweep of BASELINE config 3 (N=1 only; ~10 s)')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the multi-rank code path (RCCL group, per-iteration all-reduce) even at world size 1')
     return ap.parse_args()
@@ -184,6 +188,7 @@ def main():
         eng.set_option('fused_dbg', args.fused_dbg)
     eng.set_option('hot_split', args.hot_split)
     eng.set_option('deconflict', args.deconflict)
+    eng.set_option('kernel_timing', args.kernel_timing)
     t_setup = time.perf_counter()
     eng.generate(r0, r1, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
     tl = TelescopeLikelihood.from_engine(eng, Opts(args.steps), comm)
@@ -245,7 +250,7 @@ def main():
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC, profiles/pmc_traffic.json)',
-            'kernel': 'EM pass k_em_fused (rank 0 shard)', 'kernel_ms': k_ms,
+            'kernel': 'EM pass k_em_fused (rank 0 shard)', 'kernel_ms': k_ms, 'kernel_launches_timed': ks['em_launches'],
             'limiter': ('LDS atomics/gathers (2-byte score codes halve the HBM bytes)'
                         if info.get('value_bytes') == 2 else 'HBM stream + exchange traffic'),
             'algo_bytes_per_launch': ks['algo_bytes_per_pass'],
@@ -262,6 +267,7 @@ def main():
         tl2 = TelescopeLikelihood.from_engine(eng2, Opts(args.steps), None)
         info2 = eng2.layout_info()
         if info2.get('value_bytes') == 2:
+            eng2.set_option('kernel_timing', args.kernel_timing)
             eng2.em_chunk(max(1, args.warmup), 0.0, False)
             eng2.kernel_stats(reset=True)
             eng2.synchronize()
@@ -312,6 +318,18 @@ def main():
         out['parity_on_sample'] = {k: cb[k] for k in ('lnl_ref', 'lnl_gpu', 'lnl_rel_delta', 'pi_max_rel_delta',
                                                       'final_count_mismatches', 'final_conf_max_rel_delta',
                                                       'sample_rows', 'iters', 'converged_run')}
+    if world == 1 and not args.no_precision_sweep:
+        # BASELINE config 3 (10M x 30k x ~40): error of reduced-precision storage / accumulation against fp64
+        try:
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import logging
+            import precision_sweep
+            logging.disable(logging.WARNING)
+            out['precision_sweep'] = precision_sweep.sweep(rows=min(10_000_000, args.rows), cols=args.cols,
+                                                           nnz_row=args.nnz_row, iters=30)
+            logging.disable(logging.NOTSET)
+        except Exception as e:   # noqa: BLE001 — never let the extra block break the bench line
+            out['precision_sweep'] = dict(error=repr(e))
     _shutdown(comm)
     try:   # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line
         import ctypes

@@ -73,7 +73,10 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *                  has <= 2048 entries), 1 fp64 Q values, 2 codes (error if not possible)
  *   "hot_split"    1 (default): very popular columns get several accumulator slots
  *   "row_offset"   global index of this rank's first row (synthetic generator, column signatures)
- *   "deconflict"   1 (default): conflict-aware entry order inside the rows of the row-ordered code layout
+ *   "kernel_timing" n: HIP events around every n-th EM pass for tsem_kernel_stats (default 1, 0 = off)
+ *   "deconflict"   1: conflict-aware entry order inside the rows of the row-ordered code layout (LDS bank
+ *                  conflicts of the column scatter 3.2 -> 2.4 lanes per class: -5 % per EM pass, +14 ms of setup at
+ *                  2e9 entries, i.e. worth it beyond ~70 iterations; default 0)
  *   "em_precision" 1: the EM pass in fp32 arithmetic (row sums, posteriors and column sums in fp32) — a
  *                  DIAGNOSTIC for the fp32-vs-fp64 tolerance sweep of BASELINE config 3, not a product path
  *   "fused_dbg", "fused_prof", "chunk_blocks"     timing experiments */
@@ -231,11 +234,12 @@ int  tsem_csr_scale(int device, int mode, int64_t n_rows, int32_t n_cols, const 
                     const double* data, double* out);
 
 /* ---- instrumentation ------------------------------------------------------ */
-/* HIP-event time (ms) and launch count of the dominant EM kernel(s) since the
- * last call with reset=1; algorithmic bytes one EM pass reads.  */
+/* HIP-event time (ms) and number of TIMED launches of the dominant EM kernel(s) since the
+ * last call with reset=1 (option "kernel_timing" = n times every n-th pass, 0 none; default 1);
+ * algorithmic bytes one EM pass reads.  */
 int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launches,
                        int64_t* algo_bytes_per_pass);
-int  tsem_layout_info(tsem_ctx* h, int64_t* info16);
+int  tsem_layout_info(tsem_ctx* h, int64_t* info20);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
 /* the packed local row / local column words of one sub-block of the blocked layout (layout studies) */

@@ -497,63 +497,100 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
 // equal mod 16 cost 16 clk, distinct mod 16 cost 8, random 24.5); SQ_LDS_BANK_CONFLICT is a third of the LDS-array
 // cycles of the pass (profiles/r02_lds_counters.txt).  One such group and instruction covers the entries at
 // positions = j (mod 4) of a WINDOW of 64 consecutive entries (16 lanes x 4 entries; sub-blocks are padded to 64,
-// so windows never straddle them).  Any order inside a row is valid, so every window is walked once, row segment
-// by row segment, and each position takes — among the entries of its row that are still unplaced — the one whose
-// slot class is rarest so far in its (window, j) bin: mean worst multiplicity 3.1 -> 2.2 (the bound for a fixed
-// row order is ~2.1: a window holds ~8 entries of its most popular class).  One thread per window; windows are
-// independent.  The padding at the end of a sub-block (code 0) stays where it is.
-constexpr int DC_NT = 128;
-__global__ __launch_bounds__(DC_NT) void k_sb_deconflict(int64_t n_win, uint32_t* __restrict__ prc, uint16_t* __restrict__ pcode) {
-  __shared__ uint32_t sp[DC_NT * 65];                      // [window][64 (+1: lanes walk their windows bank-conflict-free)]
-  __shared__ uint32_t sc[DC_NT * 65];
-  for (int64_t w0 = (int64_t)blockIdx.x * DC_NT; w0 < n_win; w0 += (int64_t)gridDim.x * DC_NT) {
-    const int64_t base = w0 * 64;
-    const int nw = (int)min((int64_t)DC_NT, n_win - w0);
-    for (int t = threadIdx.x; t < nw * 64; t += DC_NT) {
-      sp[(t >> 6) * 65 + (t & 63)] = prc[base + t];
-      sc[(t >> 6) * 65 + (t & 63)] = pcode[base + t];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < nw) {
-      uint32_t* const Pw = sp + threadIdx.x * 65;
-      uint32_t* const Cw = sc + threadIdx.x * 65;
-      unsigned long long h[4] = {0ull, 0ull, 0ull, 0ull};  // per instruction slot j: 16 four-bit counters, one per class
-      int i = 0;
-      while (i < 64 && Cw[i] != 0u) {
-        const uint32_t row = Pw[i] >> 16;
-        int e = i + 1;
-        while (e < 64 && (Pw[e] >> 16) == row && Cw[e] != 0u) ++e;
-        for (int pos = i; pos < e - 1; ++pos) {             // (the last entry of the segment has no choice)
-          const int j = pos & 3;
-          const unsigned long long hj = j == 0 ? h[0] : (j == 1 ? h[1] : (j == 2 ? h[2] : h[3]));
-          int best = pos; unsigned bl = 99u;
-          for (int k = pos; k < e && bl; ++k) {
-            const unsigned l = (unsigned)(hj >> ((Pw[k] & 15u) * 4u)) & 15u;
-            if (l < bl) { bl = l; best = k; }
-          }
-          if (best != pos) {
-            const uint32_t tp = Pw[pos], tc = Cw[pos];
-            Pw[pos] = Pw[best]; Cw[pos] = Cw[best]; Pw[best] = tp; Cw[best] = tc;
-          }
-          const unsigned long long inc = (bl < 15u ? 1ull : 0ull) << ((Pw[pos] & 15u) * 4u);
-          if (j == 0) h[0] += inc; else if (j == 1) h[1] += inc; else if (j == 2) h[2] += inc; else h[3] += inc;
-        }
-        {                                                  // count the segment's last entry too
-          const int pos = e - 1, j = pos & 3;
-          const unsigned long long hj = j == 0 ? h[0] : (j == 1 ? h[1] : (j == 2 ? h[2] : h[3]));
-          const unsigned l = (unsigned)(hj >> ((Pw[pos] & 15u) * 4u)) & 15u;
-          const unsigned long long inc = (l < 15u ? 1ull : 0ull) << ((Pw[pos] & 15u) * 4u);
-          if (j == 0) h[0] += inc; else if (j == 1) h[1] += inc; else if (j == 2) h[2] += inc; else h[3] += inc;
-        }
-        i = e;
+// so windows never straddle them).  Any order inside a row is valid, so every window is walked once and each
+// position takes, among itself and the next two entries of the same row, the one whose slot class is rarest so
+// far in its (window, j) bin: mean worst multiplicity 3.2 -> 2.3 (two look-ahead entries already give what a search
+// over the whole row gives; the bound for a fixed row order is ~2.1, a window holds ~8 entries of its most popular
+// class).  One thread per window, windows are independent; the walk is fully unrolled, so every index is static and
+// the 64 four-bit classes, the row boundaries, the four 16-counter histograms and the permutation itself are
+// packed in registers — no LDS, no memory access, no divergent loop.  The permutation is applied while copying
+// the window into fresh arrays.  The padding at the end of a sub-block (code 0) stays where it is.
+constexpr int DC_NT = 256;
+__global__ __launch_bounds__(DC_NT) void k_sb_deconflict(int64_t n_win, const uint32_t* __restrict__ prc_in, const uint16_t* __restrict__ code_in,
+                                                          uint32_t* __restrict__ prc_out, uint16_t* __restrict__ code_out) {
+  for (int64_t w = (int64_t)blockIdx.x * DC_NT + threadIdx.x; w < n_win; w += (int64_t)gridDim.x * DC_NT) {
+    const int64_t base = w * 64;
+    const uint4* pin = reinterpret_cast<const uint4*>(prc_in + base);
+    const uint2* cin = reinterpret_cast<const uint2*>(code_in + base);
+    uint32_t W[8] = {0, 0, 0, 0, 0, 0, 0, 0};              // class (slot mod 16) of entry i: nibble i & 7 of W[i >> 3]
+    uint32_t pm[16];                                       // source index of position i: byte i & 3 of pm[i >> 2]
+    unsigned long long cont = 0ull;                        // bit i: entry i continues the row of entry i-1 (and neither is padding)
+    uint32_t prev_row = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const uint4 a = pin[q];
+      const uint2 cd = cin[q];
+      const uint32_t wd[4] = {a.x, a.y, a.z, a.w};
+      const uint32_t cv[4] = {cd.x & 0xFFFFu, cd.x >> 16, cd.y & 0xFFFFu, cd.y >> 16};
+      pm[q] = (uint32_t)(4 * q) * 0x01010101u + 0x03020100u;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = q * 4 + t;
+        W[i >> 3] |= (wd[t] & 15u) << ((i & 7) * 4);
+        const uint32_t row = cv[t] != 0u ? (wd[t] >> 16) : 0xFFFFFFFEu - (uint32_t)i;   // padding never continues anything
+        if (row == prev_row) cont |= 1ull << i;
+        prev_row = row;
       }
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < nw * 64; t += DC_NT) {
-      prc[base + t] = sp[(t >> 6) * 65 + (t & 63)];
-      pcode[base + t] = (uint16_t)sc[(t >> 6) * 65 + (t & 63)];
+    unsigned long long h[4] = {0ull, 0ull, 0ull, 0ull};   // per instruction slot j: 16 four-bit counters, one per class
+#pragma unroll
+    for (int pos = 0; pos < 64; ++pos) {
+      const int j = pos & 3;
+      const uint32_t c0 = (W[pos >> 3] >> ((pos & 7) * 4)) & 15u;
+      uint32_t best = 0u, cb = c0, lb = (uint32_t)(h[j] >> (c0 * 4u)) & 15u;
+      if (pos + 1 < 64) {
+        const bool ok1 = (cont >> (pos + 1)) & 1ull;
+        const uint32_t c1 = (W[(pos + 1) >> 3] >> (((pos + 1) & 7) * 4)) & 15u;
+        const uint32_t l1 = (uint32_t)(h[j] >> (c1 * 4u)) & 15u;
+        if (ok1 && l1 < lb) { best = 1u; cb = c1; lb = l1; }
+        if (pos + 2 < 64) {
+          const bool ok2 = ok1 && ((cont >> (pos + 2)) & 1ull);
+          const uint32_t c2 = (W[(pos + 2) >> 3] >> (((pos + 2) & 7) * 4)) & 15u;
+          const uint32_t l2 = (uint32_t)(h[j] >> (c2 * 4u)) & 15u;
+          if (ok2 && l2 < lb) { best = 2u; cb = c2; lb = l2; }
+        }
+      }
+      // swap entry pos with entry pos + best: classes and source indices (all positions are compile-time constants)
+      {
+        const uint32_t b0 = (pm[pos >> 2] >> ((pos & 3) * 8)) & 0xFFu;
+        if (pos + 1 < 64) {
+          const uint32_t m1c = 15u << (((pos + 1) & 7) * 4), m1p = 0xFFu << (((pos + 1) & 3) * 8);
+          const uint32_t b1 = (pm[(pos + 1) >> 2] >> (((pos + 1) & 3) * 8)) & 0xFFu;
+          uint32_t bsel = b0;
+          if (best == 1u) {
+            W[(pos + 1) >> 3] = (W[(pos + 1) >> 3] & ~m1c) | (c0 << (((pos + 1) & 7) * 4));
+            pm[(pos + 1) >> 2] = (pm[(pos + 1) >> 2] & ~m1p) | (b0 << (((pos + 1) & 3) * 8));
+            bsel = b1;
+          }
+          if (pos + 2 < 64) {
+            const uint32_t m2c = 15u << (((pos + 2) & 7) * 4), m2p = 0xFFu << (((pos + 2) & 3) * 8);
+            const uint32_t b2 = (pm[(pos + 2) >> 2] >> (((pos + 2) & 3) * 8)) & 0xFFu;
+            if (best == 2u) {
+              W[(pos + 2) >> 3] = (W[(pos + 2) >> 3] & ~m2c) | (c0 << (((pos + 2) & 7) * 4));
+              pm[(pos + 2) >> 2] = (pm[(pos + 2) >> 2] & ~m2p) | (b0 << (((pos + 2) & 3) * 8));
+              bsel = b2;
+            }
+          }
+          const uint32_t m0c = 15u << ((pos & 7) * 4), m0p = 0xFFu << ((pos & 3) * 8);
+          W[pos >> 3] = (W[pos >> 3] & ~m0c) | (cb << ((pos & 7) * 4));
+          pm[pos >> 2] = (pm[pos >> 2] & ~m0p) | (bsel << ((pos & 3) * 8));
+        }
+      }
+      h[j] += (unsigned long long)(lb < 15u ? 1u : 0u) << (cb * 4u);
     }
-    __syncthreads();
+    // apply: out[pos] = in[source of pos] (the window was read a moment ago: these gathers hit L1 / L2)
+    uint4* pout = reinterpret_cast<uint4*>(prc_out + base);
+    uint2* cout = reinterpret_cast<uint2*>(code_out + base);
+#pragma unroll
+    for (int q4 = 0; q4 < 16; ++q4) {
+      const uint32_t pb = pm[q4];
+      const uint32_t s0 = pb & 0xFFu, s1 = (pb >> 8) & 0xFFu, s2 = (pb >> 16) & 0xFFu, s3 = pb >> 24;
+      uint4 o; uint2 oc;
+      o.x = prc_in[base + s0]; o.y = prc_in[base + s1]; o.z = prc_in[base + s2]; o.w = prc_in[base + s3];
+      oc.x = (uint32_t)code_in[base + s0] | ((uint32_t)code_in[base + s1] << 16);
+      oc.y = (uint32_t)code_in[base + s2] | ((uint32_t)code_in[base + s3] << 16);
+      pout[q4] = o; cout[q4] = oc;
+    }
   }
 }
 
@@ -707,27 +744,45 @@ __global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ a,
 __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double* __restrict__ partial,
                             const int32_t* __restrict__ col_of_pc, const uint32_t* __restrict__ colmap,
                             double* __restrict__ red, int K, const uint32_t* __restrict__ sync, int P,
-                            const uint32_t* __restrict__ ctl) {
-  __shared__ double part[4][64];
+                            const uint32_t* __restrict__ ctl, unsigned long long* __restrict__ fz_xchg, int64_t fz_xchg_n) {
+  // the fused kernel's exchange ring must be zero at its next launch: cleared here, by the ~950 blocks of the
+  // kernel that follows every fused pass (no launch of its own, no fence: the next fused launch is a kernel boundary away)
+  if (fz_xchg) {
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    u64x2_t* const x2 = reinterpret_cast<u64x2_t*>(fz_xchg);                  // (hipMalloc alignment; the ring holds an even number of words)
+    const u64x2_t zz = {0ull, 0ull};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < fz_xchg_n / 2; i += (int64_t)gridDim.x * blockDim.x)
+      x2[i] = zz;
+  }
+  // 32 slots x 8 interleaved slices of the team axis per block: 8 independent loads per thread in flight (the
+  // kernel is latency-bound: 64 teams x 30k slots = 15 MB; 13.6 us with 4 slices of 16 loads, r01 profile)
+  constexpr int NS = 8, NC = 32;
+  __shared__ double part[NS][NC];
   if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the run has stopped
   if (sync) {
     int t = 0;
     for (int x = 0; x < 8; ++x) t += (int)(sync[x] / (uint32_t)P);
     G = min(G, t);
   }
-  const int pcl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int pc = blockIdx.x * 64 + pcl;
+  const int pcl = threadIdx.x % NC, slice = threadIdx.x / NC;
+  const int pc = blockIdx.x * NC + pcl;
   if (blockIdx.x == 0 && threadIdx.x == 0) { red[K] = (sync && sync[9]) ? 1.0 : 0.0; red[K + 1] = 0.0; }
   const int col = pc < Kpad ? col_of_pc[pc] : -1;        // -1: padding, or a secondary slot of a split column
   double s = 0.0;
   if (col >= 0) {
     const int copies = 1 << ((colmap[col] >> 13) & 7u);
-    for (int g = slice; g < G; g += 4)
-      for (int c = 0; c < copies; ++c) s += partial[(int64_t)g * Kpad + pc + c];
+    if (copies == 1) {
+#pragma unroll 8
+      for (int g = slice; g < G; g += NS) s += partial[(int64_t)g * Kpad + pc];
+    } else {
+      for (int g = slice; g < G; g += NS)
+        for (int c = 0; c < copies; ++c) s += partial[(int64_t)g * Kpad + pc + c];
+    }
   }
   part[slice][pcl] = s;
   __syncthreads();
-  if (slice == 0 && col >= 0) red[col] = (part[0][pcl] + part[1][pcl]) + (part[2][pcl] + part[3][pcl]);
+  if (slice == 0 && col >= 0)                            // fixed order -> deterministic given the partials
+    red[col] = ((part[0][pcl] + part[1][pcl]) + (part[2][pcl] + part[3][pcl])) + ((part[4][pcl] + part[5][pcl]) + (part[6][pcl] + part[7][pcl]));
 }
 
 __global__ void k_keep_err(const uint32_t* sync, uint32_t* errlog) { errlog[0] |= sync[9]; errlog[1] = sync[10]; }
@@ -756,8 +811,7 @@ __global__ __launch_bounds__(256) void k_update(UpdCtl C, int K, const double* _
   // the fused kernel's sync words and exchange ring must be zero at its next launch: do it here (this
   // kernel runs once per EM pass, after the pass) instead of three memsets in front of every launch
   if (fz_sync) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < fz_xchg_n; i += (int64_t)gridDim.x * blockDim.x)
-      fz_xchg[i] = 0ull;
+    (void)fz_xchg; (void)fz_xchg_n;                        // (the ring itself is cleared by k_colreduce)
     if (blockIdx.x == 0 && threadIdx.x < 16) {            // FZ_SYNC_WORDS
       if (threadIdx.x == 9) atomicOr(&fz_errlog[0], fz_sync[9]);          // keep the error word / miss counter for the host
       if (threadIdx.x == 10) fz_errlog[1] = fz_sync[10];
@@ -1378,6 +1432,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "sorted_fill") h->opt_sorted = v;
   else if (k == "deconflict") h->opt_deconflict = v;
   else if (k == "em_precision") h->opt_precision = v;
+  else if (k == "kernel_timing") h->opt_timing = v;
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
     if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
@@ -1842,8 +1897,14 @@ static int build_layout(tsem_ctx* h) {
     TSEM_HIP(hipGetLastError());
     if (h->fmt_code && h->opt_deconflict && off >= 64) {
       const int64_t n_win = off / 64;
-      k_sb_deconflict<<<(unsigned)std::min<int64_t>(n_win / DC_NT + 1, (int64_t)h->n_cu * 8), DC_NT, 0, h->stream>>>(n_win, h->d_prc, h->d_pcode);
+      uint32_t* prc2 = nullptr; uint16_t* code2 = nullptr;
+      TSEM_ALLOC(prc2, off); TSEM_ALLOC(code2, off);
+      k_sb_deconflict<<<(unsigned)std::min<int64_t>(n_win / DC_NT + 1, (int64_t)h->n_cu * 32), DC_NT, 0, h->stream>>>(
+          n_win, h->d_prc, h->d_pcode, prc2, code2);
       TSEM_HIP(hipGetLastError());
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      (void)hipFree(h->d_prc); (void)hipFree(h->d_pcode);
+      h->d_prc = prc2; h->d_pcode = code2;
     }
   } else if (nb) {
     k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
@@ -2005,6 +2066,10 @@ static int launch_phase1(tsem_ctx* h, const double* ctab, int64_t b0 = 0, int64_
 
 static int begin_timing(tsem_ctx* h, hipEvent_t** pair) {
   *pair = nullptr;
+  // option "kernel_timing" = n: HIP events around every n-th EM pass (0 = never, default 1).  An event pair costs
+  // the stream several microseconds per iteration (profiles/r02_comm_overhead.txt): the Python host switches it
+  // off for em(), bench.py samples every 4th launch of the timed region.
+  if (h->opt_timing <= 0 || (h->em_launches % h->opt_timing) != 0) return TSEM_OK;
   if (h->ev_used + 2 > 8192) return TSEM_OK;
   while (h->ev.size() < h->ev_used + 2) {
     hipEvent_t e;
@@ -2013,6 +2078,7 @@ static int begin_timing(tsem_ctx* h, hipEvent_t** pair) {
   }
   *pair = &h->ev[h->ev_used];
   h->ev_used += 2;
+  h->em_timed += 1;
   TSEM_HIP(hipEventRecord((*pair)[0], h->stream));
   return TSEM_OK;
 }
@@ -2091,11 +2157,13 @@ int tsem_em_pass(tsem_ctx* h) {
   if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
   h->em_launches += 1;
   if (fused_done) {
-    k_colreduce<<<cdiv64(h->Kpad, 64), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
-                                                            h->d_xflags, h->P, h->d_ctl);
+    k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                            h->d_xflags, h->P, h->d_ctl,
+                                                            h->P > 1 ? reinterpret_cast<unsigned long long*>(h->d_xchg) : nullptr,
+                                                            h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
   } else if (h->nb > 0) {
-    k_colreduce<<<cdiv64(h->Kpad, 64), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
-                                                            nullptr, h->P, h->d_ctl);
+    k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                            nullptr, h->P, h->d_ctl, nullptr, 0);
   } else {
     TSEM_HIP(hipMemsetAsync(h->d_red, 0, sizeof(double) * (h->K + 2), h->stream));
   }
@@ -2761,12 +2829,12 @@ int tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launche
   }
   h->ev_used = 0;
   if (em_ms) *em_ms = h->em_ms_acc;
-  if (em_launches) *em_launches = h->em_launches;
+  if (em_launches) *em_launches = h->em_timed;             // launches that were timed (option "kernel_timing")
   // one EM pass must read every stored entry of the ambiguous rows once:
   // 4 B packed local row/col + the value AS STORED (8 B fp64 Q, or a 2 B score code) per entry,
   // + 2 B row weight code per row
   if (algo_bytes) *algo_bytes = h->nnz_amb * (h->fmt_code ? 6 : 12) + h->N_amb * 2;
-  if (reset) { h->em_ms_acc = 0; h->em_launches = 0; }
+  if (reset) { h->em_ms_acc = 0; h->em_launches = 0; h->em_timed = 0; }
   return TSEM_OK;
 }
 
@@ -2811,6 +2879,8 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[4] = h->N_amb; info[5] = h->N_uni; info[6] = h->nnz_amb; info[7] = h->nnz_pad;
   info[8] = h->n_twin_cols; info[9] = h->G1; info[10] = h->G2; info[11] = h->use_fused ? 1 : 0;
   info[12] = h->last_slow_path; info[13] = h->max_subblock; info[14] = h->fmt_code ? 2 : 8; info[15] = h->n_hot_cols;
+  info[16] = h->use_fused ? (int64_t)fz_lds_bytes(h, fz_fmt(h) != 0) : 0;   // dynamic LDS per workgroup of the fused kernel
+  info[17] = h->sorted_layout ? 1 : 0; info[18] = h->geo; info[19] = h->n_fallbacks;
   return TSEM_OK;
 }
 

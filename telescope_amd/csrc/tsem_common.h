@@ -96,9 +96,11 @@ struct tsem_ctx {
   double* d_pval = nullptr;         // [nnz_pad]  Q values (fp64 entry format)
   uint16_t* d_pcode = nullptr;      // [nnz_pad]  raw score codes (code16 entry format: Q = lut[code])
   int64_t opt_sorted = -1;          // -1 auto, 0: strand-transposed sub-blocks, 1: row-ordered sub-blocks (fused layout)
+  int64_t opt_timing = 1;           // HIP events around every n-th EM pass (tsem_kernel_stats); 0 = none
   int64_t opt_precision = 0;        // 1: the EM pass in fp32 arithmetic (diagnostic for the config-3 tolerance sweep)
   float *d_c32 = nullptr, *d_cs32 = nullptr, *d_lut32 = nullptr;
-  int64_t opt_deconflict = 1;       // 1: conflict-aware entry order inside the rows of the row-ordered code layout (k_sb_deconflict)
+  int64_t opt_deconflict = 0;       // 1: conflict-aware entry order inside the rows of the row-ordered code layout (k_sb_deconflict):
+                                    //    -5 % per EM pass for +14 ms of setup at 50M x 40 (pays after ~70 iterations), hence opt-in
   int64_t opt_geo = -1;             // -1 auto; 0 / 2 force the geometry of teams of 1-4 (experiments)
   double run_len_est = 0.0;         // mean entries per ambiguous row and column part (set by tsem_rowstats)
   bool sorted_layout = false;       // sub-blocks stored in row order (k_sb_fill_sorted)
@@ -158,7 +160,7 @@ struct tsem_ctx {
   std::vector<hipEvent_t> ev;       // pairs
   size_t ev_used = 0;
   double em_ms_acc = 0;
-  int64_t em_launches = 0;
+  int64_t em_launches = 0, em_timed = 0;
 };
 
 constexpr int TS_DIFF_RING = 65536;

@@ -300,6 +300,8 @@ class TelescopeLikelihood(object):
         eng, comm, K = self._eng, self.comm, self.K
         chunked = getattr(comm, 'in_library', False) and hasattr(eng, 'em_chunk')
         timeouts = 0
+        if chunked and not getattr(self, 'keep_kernel_timing', False):
+            eng.set_option('kernel_timing', 0)  # per-pass HIP events are for benchmarks (Engine.kernel_stats), not for em()
         while not (converged or reached_max):
             xtime = perf_counter()
             if chunked:

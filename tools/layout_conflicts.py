@@ -1,6 +1,7 @@
-"""LDS bank-conflict profile of the blocked layout: for the wave instructions of a few sub-blocks, the
-largest number of lanes of a 16-lane group on one fp64 bank pair (column mod 32 for the accumulator
-scatter / pi*theta gather, row mod 32 for the row-sum scatter).  python tools/layout_conflicts.py [k=v ...]"""
+"""LDS conflict profile of the blocked layout: for the wave instructions of a few sub-blocks, the largest number
+of lanes of a 16-lane group whose slots agree modulo 16 (the granularity at which ds_add_f64 serialises:
+tools/ubench/lds.hip) — columns for the accumulator scatter, rows for the row-sum scatter — and modulo 32 within 32
+lanes for the pi*theta gather (ds_read_b64).  python tools/layout_conflicts.py [k=v ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
@@ -16,7 +17,7 @@ for a in sys.argv[1:]:
 eng.generate(0, 2_000_000, 30000, synthetic.poisson_cdf_u32(40), 42, 1, 0.0)
 tl = TelescopeLikelihood.from_engine(eng, O())
 info = eng.layout_info()
-col_max, row_max, row_dup = [], [], []
+col_max, row_max, row_dup, col32 = [], [], [], []
 for b in range(10, 40):
     for p in range(info['P']):
         w = eng.debug_subblock(b, p)
@@ -25,9 +26,16 @@ for b in range(10, 40):
         for j in range(4):
             cols, rows = g[:, :, j] & 0xFFFF, g[:, :, j] >> 16
             for x in range(g.shape[0]):
-                col_max.append(np.bincount(cols[x] & 31, minlength=32).max())
-                row_max.append(np.bincount(rows[x] & 31, minlength=32).max())
+                col_max.append(np.bincount(cols[x] & 15, minlength=16).max())
+                row_max.append(np.bincount(rows[x] & 15, minlength=16).max())
                 row_dup.append(np.unique(rows[x], return_counts=True)[1].max())
+        g32 = w[:len(w) // 128 * 128].reshape(-1, 32, 4)
+        for j in range(4):
+            for x in range(g32.shape[0]):
+                cc = g32[x, :, j] & 0xFFFF
+                u = np.unique(cc)                                   # equal addresses broadcast
+                col32.append(np.bincount(u & 31, minlength=32).max())
 print(info)
-print('mean over 16-lane groups of the worst bank-pair load:  columns %.2f   rows %.2f   (same row in one group: %.2f)'
+print('mean over 16-lane groups of the worst class (mod 16) multiplicity:  columns %.2f   rows %.2f   (same row in one group: %.2f)'
       % (np.mean(col_max), np.mean(row_max), np.mean(row_dup)))
+print('mean over 32-lane groups of the worst bank-pair (mod 32) load of the column gather: %.2f' % np.mean(col32))

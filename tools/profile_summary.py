@@ -21,11 +21,18 @@ def short(name):
     return name.split('(')[0].replace('void ', '')
 
 
+WARMUP = 2          # launches of the EM kernel before bench.py's timed region (--warmup 2 in tools/profile.sh)
+
+
 def kernel_table(path):
     agg = defaultdict(list)
     meta = {}
-    for r in csv.DictReader(open(path)):
+    seen = defaultdict(int)
+    for r in sorted(csv.DictReader(open(path)), key=lambda r: int(r['Start_Timestamp'])):
         k = short(r['Kernel_Name'])
+        seen[k] += 1
+        if k.startswith('k_em_fused') and seen[k] <= WARMUP:
+            continue                                        # timed launches only: the summary then reproduces bench's kernel_ms
         agg[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
         meta[k] = (int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), r['Workgroup_Size_X'], r['LDS_Block_Size'],
                    int(r['VGPR_Count']) + int(r['Accum_VGPR_Count']), r['SGPR_Count'])
@@ -59,11 +66,14 @@ def main():
     src, prefix = sys.argv[1], sys.argv[2]
     one = lambda pat: sorted(glob.glob(os.path.join(src, pat)))[0]
     bench = json.load(open(os.path.join(src, 'bench.json')))
-    cmd = 'python bench.py --steps 6 --warmup 2 --no-cpu-baseline'
+    cmd = 'python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-sweep'
     kl, avg = kernel_table(one('trace/*/*_kernel_trace.csv'))
     with open(os.path.join(ROOT, 'profiles', prefix + '_fused_kernel_stats.txt'), 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats -- %s   (default workload; the run times the headline fp64\n'
-                '# layout k_em_fused<4, 0, 2, 0> and then the 2-byte-code layout k_em_fused<4, 0, 1, 0>;\n# template arguments: team size, mode (0 EM / 1 lnl), entry format, geometry)\n' % cmd)
+                '# layout k_em_fused<4, 0, 2, 0> and then the 2-byte-code layout k_em_fused<4, 0, 1, 0>;\n# template arguments: team size, mode (0 EM / 1 lnl), entry format, geometry)\n'
+                '# k_em_fused rows: the %d warm-up launches of each engine are left out (timed launches only).  lds_B is the STATIC\n'
+                '# allocation; the fused kernel allocates its LDS dynamically: %s B per workgroup (tsem.hip fz_lds_bytes).\n'
+                % (cmd, WARMUP, bench['config']['layout'].get('lds_bytes', 'n/a')))
         f.write('\n'.join(kl) + '\n')
     fl, fetch = pmc_table(one('fetch/*/*_counter_collection.csv'), 'FETCH_SIZE')
     wl, write = pmc_table(one('write/*/*_counter_collection.csv'), 'WRITE_SIZE')
