@@ -73,6 +73,8 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *                  has <= 2048 entries), 1 fp64 Q values, 2 codes (error if not possible)
  *   "hot_split"    1 (default): very popular columns get several accumulator slots
  *   "row_offset"   global index of this rank's first row (synthetic generator, column signatures)
+ *   "report_shortcuts" 1 (default): tsem_reassign answers `all` (initial) and `unique` from counts taken at
+ *                  setup instead of a pass over the matrix (the same numbers; 0 forces the pass)
  *   "kernel_timing" n: HIP events around every n-th EM pass for tsem_kernel_stats (default 1, 0 = off)
  *   "deconflict"   1: conflict-aware entry order inside the rows of the row-ordered code layout (LDS bank
  *                  conflicts of the column scatter 3.2 -> 2.4 lanes per class: -5 % per EM pass, +14 ms of setup at
@@ -213,6 +215,10 @@ int  tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat)
 int  tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* theta, double* lnl);
 /* rows' best-hit counts for `choose` (sparse_plus.py:117-129): nbest[i] */
 int  tsem_best_counts(tsem_ctx* h, int which, int32_t* nbest /* n_rows */);
+/* the same, compacted on the device: only the rows with SEVERAL best hits (the ones `choose` draws a random
+ * number for, sparse_plus.py:147-149), in row order: rows[i] = local row index, counts[i] = its number of best hits.
+ * *n = how many there are; if n > cap nothing is copied and TSEM_ERR_ARG is returned (call again with cap >= n). */
+int  tsem_best_ties(tsem_ctx* h, int which, int64_t cap, int32_t* rows, int32_t* counts, int64_t* n);
 /* reassign(method, thresh, initial).sum(0) (model.py:808-865,435-457) -> colsums[K]
  * (local rows); optional per-entry mask aligned to the CSR pattern (nnz doubles,
  * NULL to skip).  `picks[i]` (choose only) = ordinal of the chosen best hit. */

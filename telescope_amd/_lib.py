@@ -120,6 +120,7 @@ def lib():
     L.tsem_mstep.argtypes = [vp, vp, vp, vp]
     L.tsem_calc_lnl.argtypes = [vp, vp, vp, vp, C.POINTER(dbl)]
     L.tsem_best_counts.argtypes = [vp, C.c_int, vp]
+    L.tsem_best_ties.argtypes = [vp, C.c_int, i64, vp, vp, C.POINTER(i64)]
     L.tsem_reassign.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, vp]
     L.tsem_reassign_groups.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, C.c_int32, vp]
     L.tsem_csr_norm_rows.argtypes = [C.c_int, i64, vp, vp, vp]
@@ -359,6 +360,20 @@ class Engine(object):
         nb = np.empty(n, np.int32)
         self._ck(self._L.tsem_best_counts(self._h, which, ptr(nb)))
         return nb
+
+    def best_ties(self, which):
+        """(rows, counts) of the rows with several best hits, in row order (compacted on the device)."""
+        n = C.c_int64()
+        cap = 1 << 16
+        while True:
+            rows, counts = np.empty(cap, np.int32), np.empty(cap, np.int32)
+            rc = self._L.tsem_best_ties(self._h, which, cap, ptr(rows), ptr(counts), C.byref(n))
+            if rc == OK:
+                return rows[:n.value].copy(), counts[:n.value].copy()
+            if rc == ERR_ARG and n.value > cap:
+                cap = int(n.value)
+                continue
+            self._ck(rc)
 
     def reassign(self, method, thresh, which, picks=None, want_mask=False):
         n, k, nnz = self.dims()

@@ -16,6 +16,8 @@
 //   scatter of the hot loop goes through LDS.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __re
     const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
     const double* __restrict__ lut, uint16_t* __restrict__ row_code, uint8_t* __restrict__ row_class,
     double* __restrict__ wsum_part /* [grid][2] */, uint32_t* __restrict__ maxcode,
-    double* __restrict__ pisum0) {
+    double* __restrict__ pisum0, uint32_t* __restrict__ ucount /* [K] unique rows with a positive score per column; [K] = 1 if any stored score is 0 */,
+    int K) {
   __shared__ double scratch[16];
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB;
   const int subs = blockDim.x / RS_SUB;
@@ -192,8 +195,10 @@ __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __re
   for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
     int64_t s = indptr[row], e = indptr[row + 1];
     int m = 0;
-    for (int64_t k = s + lane; k < e; k += RS_SUB) m = max(m, (int)raw[k]);
+    bool zero = false;
+    for (int64_t k = s + lane; k < e; k += RS_SUB) { const int r = (int)raw[k]; m = max(m, r); zero |= r == 0; }
     m = sg_max_i<RS_SUB>(m);
+    if (zero) ucount[K] = 1u;                              // (a stored score of 0: the shortcuts of tsem_reassign do not apply)
     int64_t len = e - s;
     if (lane == 0) {
       double w = (len > 0) ? lut[m] : 0.0;
@@ -202,7 +207,10 @@ __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __re
       row_code[row] = (uint16_t)m;
       row_class[row] = (len > 1) ? 2 : (len == 1 ? 1 : 0);
       mymax = max(mymax, m);
-      if (len == 1) unsafeAtomicAdd(&pisum0[indices[s]], lut[raw[s]]);
+      if (len == 1) {
+        unsafeAtomicAdd(&pisum0[indices[s]], lut[raw[s]]);
+        if (raw[s]) atomicAdd(&ucount[indices[s]], 1u);
+      }
     }
   }
   double bt = block_sum(wt, scratch);
@@ -929,6 +937,8 @@ struct RowPassArgs {
   const double* pi;      // null => initial (c == 1)
   const double* theta;
   const double* zin;     // non-null: the caller's z (TSEM_Z_USER), aligned to the CSR pattern, NaN = no entry; used as is
+  const double* cnat;    // pi[j] * theta[j] per column (natural order): ONE gather per entry of an ambiguous row instead of two
+  int lut_len;           // the score table is staged in LDS ([lut_len] doubles in front of the hot slots)
   int method;
   double thresh;
   const int32_t* picks;
@@ -941,25 +951,31 @@ struct RowPassArgs {
   const uint32_t* colmap; const int32_t* col_of_pc; int P, Kp, Hs;
 };
 
-template <int MODE>
+// METH >= 0 fixes the reassign method at compile time (the per-entry switch and the reductions a method does not
+// need disappear: the pass is bound by instruction issue, ~300 per four rows); METH = -1 reads it from the arguments.
+template <int MODE, int METH = -1>
 __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
-  extern __shared__ double hot[];                          // [P][Hs] (REASSIGN with A.Hs > 0)
+  const int method = METH >= 0 ? METH : A.method;
+  extern __shared__ double rp_lds[];                       // [lut_len] score table | [P][Hs] hot slots (REASSIGN with A.Hs > 0)
+  double* const lutS = rp_lds;
+  double* const hot = rp_lds + A.lut_len;
   const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
   const bool initial = (A.pi == nullptr);
   const int nhot = MODE == RP_REASSIGN ? A.P * A.Hs : 0;
-  if (nhot) {
-    for (int t = threadIdx.x; t < nhot; t += blockDim.x) hot[t] = 0.0;
-    __syncthreads();
-  }
+  // The pass is bound by vector-memory INSTRUCTIONS (every gather touches 64 cache lines): the score table
+  // comes from LDS and pi*theta from one precomputed table, 3 instead of 5 vector-memory instructions per round
+  for (int t = threadIdx.x; t < A.lut_len; t += blockDim.x) lutS[t] = A.lut[t];
+  for (int t = threadIdx.x; t < nhot; t += blockDim.x) hot[t] = 0.0;
+  __syncthreads();
   for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < A.N; row += (int64_t)gridDim.x * subs) {
     const int64_t s = A.indptr[row], e = A.indptr[row + 1];
     const bool amb = (e - s) > 1;
     auto numer = [&](int64_t k) -> double {
       if (A.zin) return A.zin[k];
-      double q = A.lut[A.raw[k]];
+      double q = A.lut_len ? lutS[A.raw[k]] : A.lut[A.raw[k]];
       if (initial) return q;
       int col = A.indices[k];
-      double c = amb ? A.pi[col] * A.theta[col] : A.pi[col];
+      double c = amb ? A.cnat[col] : A.pi[col];              // cnat[col] = pi[col] * theta[col]: the same product, formed once per column
       return q * c;
     };
     if (e - s <= 4 * RP_SUB) {
@@ -996,12 +1012,12 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
         continue;
       }
       double vsum = 0.0;
-      if (A.method == TSEM_RA_CONF) {
+      if (method == TSEM_RA_CONF) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (inp[i] && n[i] * r >= A.thresh) vsum += n[i] * r;
         vsum = sg_sum<RP_SUB>(vsum);
       }
-      const int pick = (A.method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[row] : 0;
+      const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[row] : 0;
       const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
       int base = 0;
 #pragma unroll
@@ -1014,7 +1030,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
         const int ord = base + __popc(grp & ((1u << lane) - 1u));
         base += __popc(grp);
         double val = 0.0;
-        switch (A.method) {
+        switch (method) {
           case TSEM_RA_EXCLUDE: val = (best && nb == 1) ? 1.0 : 0.0; break;
           case TSEM_RA_CHOOSE:  val = (best && ord == pick) ? 1.0 : 0.0; break;
           case TSEM_RA_AVERAGE: val = best ? 1.0 * recip0((double)nb) : 0.0; break;
@@ -1072,7 +1088,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
     }
     // ---- reassign ----
     double vsum = 0.0;
-    if (A.method == TSEM_RA_CONF) {
+    if (method == TSEM_RA_CONF) {
       for (int64_t k = s + lane; k < e; k += RP_SUB) {
         double n = numer(k);
         double z = n * r;
@@ -1080,7 +1096,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       }
       vsum = sg_sum<RP_SUB>(vsum);
     }
-    const int pick = (A.method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[row] : 0;
+    const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[row] : 0;
     const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
     int base = 0;
     for (int64_t k0 = s; k0 < e; k0 += RP_SUB) {
@@ -1095,7 +1111,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       int ord = base + __popc(grp & ((1u << lane) - 1u));
       base += __popc(grp);
       double val = 0.0;
-      switch (A.method) {
+      switch (method) {
         case TSEM_RA_EXCLUDE: val = (best && nb == 1) ? 1.0 : 0.0; break;
         case TSEM_RA_CHOOSE:  val = (best && ord == pick) ? 1.0 : 0.0; break;
         case TSEM_RA_AVERAGE: val = best ? 1.0 * recip0((double)nb) : 0.0; break;
@@ -1356,11 +1372,11 @@ static void free_layout(tsem_ctx* h) {
 static void free_matrix(tsem_ctx* h) {
   dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_raw); dfree(h->d_lut);
   dfree(h->d_amb_row); dfree(h->d_amb_wcode); dfree(h->d_amb_wcode_c); dfree(h->d_slot_row); dfree(h->d_uni_col); dfree(h->d_uni_code);
-  dfree(h->d_pisum0); dfree(h->d_twin_rep);
+  dfree(h->d_pisum0); dfree(h->d_twin_rep); dfree(h->d_ucount); dfree(h->d_colcount);
   free_layout(h);
   dfree(h->d_pi); dfree(h->d_theta); dfree(h->d_pi_prev); dfree(h->d_theta_prev);
   dfree(h->d_ctab); dfree(h->d_ctab_prev); dfree(h->d_red_own); dfree(h->d_tmp_pi); dfree(h->d_tmp_theta);
-  dfree(h->d_c32); dfree(h->d_cs32); dfree(h->d_lut32);
+  dfree(h->d_c32); dfree(h->d_cs32); dfree(h->d_lut32); dfree(h->d_cnat);
   dfree(h->d_ctl); dfree(h->d_ctld); dfree(h->d_lnls); dfree(h->d_pi_first); dfree(h->d_theta_first); dfree(h->d_user_z);
   h->first_pending = false;
   h->d_red = nullptr;
@@ -1433,6 +1449,8 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "deconflict") h->opt_deconflict = v;
   else if (k == "em_precision") h->opt_precision = v;
   else if (k == "kernel_timing") h->opt_timing = v;
+  else if (k == "report_shortcuts") h->opt_shortcuts = v;
+  else if (k == "rowpass_wgs") h->opt_rowpass_wgs = v;
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
     if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
@@ -1616,7 +1634,9 @@ static int choose_geometry(tsem_ctx* h) {
       // geometry: teams of 5-8 have one; smaller teams switch to three exchange waves when the rows
       // are so short that 512 row slots cannot fill the register tile and the pass is bound by the
       // exchange (fp64 entries; with score codes the 14th data wave is worth more)
-      h->geo = P > 4 ? 1 : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > fz_rmax(0) && !fz_wants_codes(h)) ? 2 : 0);
+      // (r02 sweep, fp64 entries, 50M rows: 10 nnz/row 2.11 -> 1.68 ms with geometry 2, 20 nnz/row 2.69 -> 2.71 ms:
+      // the third exchange wave pays once the tile would need more than ~1.8x the 512 row slots of geometry 0)
+      h->geo = P > 4 ? 1 : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > 1.8 * fz_rmax(0) && !fz_wants_codes(h)) ? 2 : 0);
       if (h->opt_geo >= 0 && P <= 4) h->geo = h->opt_geo == 2 ? 2 : 0;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
@@ -1649,12 +1669,14 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   const int grid = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (N + 15) / 16));
   TSEM_ALLOC(d_wpart, 2 * grid);
   TSEM_ALLOC(h->d_pisum0, K);
+  TSEM_ALLOC(h->d_ucount, K + 1);
+  TSEM_HIP(hipMemsetAsync(h->d_ucount, 0, sizeof(uint32_t) * (K + 1), h->stream));
   TSEM_HIP(hipMemsetAsync(h->d_pisum0, 0, sizeof(double) * K, h->stream));
   TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
   TSEM_HIP(hipMemsetAsync(d_wpart, 0, sizeof(double) * 2 * grid, h->stream));
   if (N)
     k_rowstats<<<grid, 256, 0, h->stream>>>(N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, d_code, d_cls,
-                                           d_wpart, h->d_maxcode, h->d_pisum0);
+                                           d_wpart, h->d_maxcode, h->d_pisum0, h->d_ucount, K);
   TSEM_HIP(hipGetLastError());
   std::vector<double> wpart(2 * grid);
   uint32_t maxcode = 0;
@@ -1683,7 +1705,9 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     TSEM_HIP(hipMemcpyAsync(col_count, d_cnt, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipMemcpyAsync(col_hash, d_hash, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
-    (void)hipFree(d_cnt); (void)hipFree(d_hash);
+    dfree(h->d_colcount);
+    h->d_colcount = d_cnt;                                 // LOCAL stored entries per column: reassign('all', initial) of this rank
+    (void)hipFree(d_hash);
   }
   // compact ambiguous and unique rows
   TSEM_ALLOC(d_fa, N + 1); TSEM_ALLOC(d_fu, N + 1);
@@ -2006,12 +2030,14 @@ int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, cons
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipStreamSynchronize(h->stream));
   h->have_model = true;
+  h->em_cur = h->em_prev = true;                           // pi = theta = 1/K
   return TSEM_OK;
 }
 
 int tsem_set_params(tsem_ctx* h, const double* pi, const double* theta) {
   if (!h || !h->have_model || !pi || !theta) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
+  h->em_prev = h->em_cur; h->em_cur = false;               // arbitrary values (possibly 0): no shortcut in tsem_reassign
   const int K = h->K;
   TSEM_HIP(hipMemcpyAsync(h->d_pi_prev, h->d_pi, sizeof(double) * K, hipMemcpyDeviceToDevice, h->stream));
   TSEM_HIP(hipMemcpyAsync(h->d_theta_prev, h->d_theta, sizeof(double) * K, hipMemcpyDeviceToDevice, h->stream));
@@ -2192,6 +2218,7 @@ static int launch_update(tsem_ctx* h, double* d_diff_slot, bool chunked = false,
                                         h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
   TSEM_HIP(hipGetLastError());
   if (clean) h->fz_clean = true;
+  h->em_prev = h->em_cur; h->em_cur = true;                // (a skipped update — stop flag, time-out — leaves older, equally valid M-step values)
   return TSEM_OK;
 }
 
@@ -2539,10 +2566,23 @@ int tsem_comm_allreduce_host(tsem_comm* c, void* data, int64_t count, int dtype)
 // ---------------------------------------------------------------------------
 // results
 // ---------------------------------------------------------------------------
+__global__ void k_cnat(int K, const double* __restrict__ pi, const double* __restrict__ theta, double* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < K) out[j] = pi[j] * theta[j];
+}
+// pi*theta per column for the row passes (A.pi / A.theta must be set)
+static int make_cnat(tsem_ctx* h, RowPassArgs& A) {
+  if (!h->d_cnat) TSEM_ALLOC(h->d_cnat, h->K);
+  k_cnat<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, A.pi, A.theta, h->d_cnat);
+  TSEM_HIP(hipGetLastError());
+  A.cnat = h->d_cnat;
+  return TSEM_OK;
+}
+
 static int rowpass_args(tsem_ctx* h, int which, RowPassArgs& A) {
   A.N = h->N; A.K = h->K; A.indptr = h->d_indptr; A.indices = h->d_indices; A.raw = h->d_raw; A.lut = h->d_lut;
   A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr; A.group = nullptr; A.colmap = nullptr; A.col_of_pc = nullptr; A.P = 0; A.Kp = 0; A.Hs = 0;
-  A.zin = nullptr;
+  A.zin = nullptr; A.cnat = nullptr; A.lut_len = h->lut_len <= 2048 ? h->lut_len : 0;   // (larger tables stay in global memory)
   if (which == TSEM_Z_USER) {
     if (!h->d_user_z) TSEM_FAIL(TSEM_ERR_ARG, "TSEM_Z_USER without tsem_set_user_z");
     A.pi = h->d_pi; A.theta = h->d_theta; A.zin = h->d_user_z;
@@ -2553,6 +2593,7 @@ static int rowpass_args(tsem_ctx* h, int which, RowPassArgs& A) {
   else if (which == TSEM_Z_CUR) { A.pi = h->d_pi; A.theta = h->d_theta; }
   else TSEM_FAIL(TSEM_ERR_ARG, "bad `which`");
   if (which != TSEM_Z_INITIAL && !h->have_model) TSEM_FAIL(TSEM_ERR_ARG, "model not set");
+  if (A.pi) { if (int rc = make_cnat(h, A)) return rc; }
   return TSEM_OK;
 }
 static int rowpass_grid(tsem_ctx* h) { return (int)std::min<int64_t>(8192, std::max<int64_t>(1, (h->N + 15) / 16)); }
@@ -2561,7 +2602,7 @@ static int export_z_with(tsem_ctx* h, RowPassArgs& A, double* z) {
   double* d_z = nullptr;
   TSEM_ALLOC(d_z, h->nnz);
   A.zout = d_z;
-  if (h->N) k_rowpass<RP_EXPORT_Z><<<rowpass_grid(h), 256, 0, h->stream>>>(A);
+  if (h->N) k_rowpass<RP_EXPORT_Z><<<rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
   if (h->nnz) TSEM_HIP(hipMemcpyAsync(z, d_z, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
@@ -2594,6 +2635,7 @@ int tsem_estep(tsem_ctx* h, const double* pi, const double* theta, double* z) {
   RowPassArgs A;
   if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
   A.pi = h->d_tmp_pi; A.theta = h->d_tmp_theta;
+  if (int rc = make_cnat(h, A)) return rc;
   return export_z_with(h, A, z);
 }
 
@@ -2605,12 +2647,62 @@ int tsem_best_counts(tsem_ctx* h, int which, int32_t* nbest) {
   int32_t* d_nb = nullptr;
   TSEM_ALLOC(d_nb, h->N);
   A.nbest = d_nb;
-  if (h->N) k_rowpass<RP_BEST><<<rowpass_grid(h), 256, 0, h->stream>>>(A);
+  if (h->N) k_rowpass<RP_BEST><<<rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
   if (h->N) TSEM_HIP(hipMemcpyAsync(nbest, d_nb, sizeof(int32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
   (void)hipFree(d_nb);
   return TSEM_OK;
+}
+
+struct TiedRow {                                            // predicate of tsem_best_ties: rows with several best hits
+  const int32_t* nb;
+  __device__ bool operator()(const int32_t& i) const { return nb[i] > 1; }
+};
+__global__ void k_gather_i32(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ src, int32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+
+int tsem_best_ties(tsem_ctx* h, int which, int64_t cap, int32_t* rows, int32_t* counts, int64_t* n_out) {
+  if (!h || !h->d_indptr || !n_out || cap < 0 || (cap && (!rows || !counts))) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  *n_out = 0;
+  if (h->N == 0) return TSEM_OK;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  int32_t *d_nb = nullptr, *d_rows = nullptr, *d_cnt = nullptr;
+  unsigned long long* d_n = nullptr;
+  TSEM_ALLOC(d_nb, h->N); TSEM_ALLOC(d_rows, h->N); TSEM_ALLOC(d_n, 1);
+  A.nbest = d_nb;
+  k_rowpass<RP_BEST><<<rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  size_t tb = 0;
+  TiedRow pred{d_nb};
+  rocprim::counting_iterator<int32_t> first(0);
+  TSEM_HIP(rocprim::select(nullptr, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
+  void* tmp = nullptr;
+  TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+  TSEM_HIP(rocprim::select(tmp, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
+  unsigned long long n = 0;
+  TSEM_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(tmp);
+  *n_out = (int64_t)n;
+  int rc = TSEM_OK;
+  if ((int64_t)n > cap) {
+    h->err = "tsem_best_ties: more tied rows than the caller's arrays hold (call again with the returned count)";
+    rc = TSEM_ERR_ARG;
+  } else if (n) {
+    TSEM_ALLOC(d_cnt, n);
+    k_gather_i32<<<cdiv64((int64_t)n, 256), 256, 0, h->stream>>>((int64_t)n, d_rows, d_nb, d_cnt);
+    TSEM_HIP(hipMemcpyAsync(rows, d_rows, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(counts, d_cnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+  }
+  (void)hipFree(d_nb); (void)hipFree(d_rows); (void)hipFree(d_n);
+  if (d_cnt) (void)hipFree(d_cnt);
+  return rc;
 }
 
 int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks, double* colsums,
@@ -2620,6 +2712,30 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
   if (int rc = ensure_device(h)) return rc;
   RowPassArgs A;
   if (int rc = rowpass_args(h, which, A)) return rc;
+  // Two of the report's columns do not depend on the posteriors and were counted while the matrix was set up
+  // (option "report_shortcuts", default 1; the row pass gives the same numbers, tests/test_gpu_round2.py):
+  //   all, initial=True (model.py:860-862 on Q.norm(1)): one per stored entry with a positive score = the column's
+  //     entry count (every score > 0: z = q / rowsum > 0 for every entry);
+  //   unique (model.py:857-859): ceil(z) over the single-entry rows = the column's number of such rows with a positive
+  //     score — z = n * (1/n) in (0, 1] whenever n = q * pi_j is a normal positive number, which holds for the
+  //     parameters the M-step produces (pi_j >= pisum0_j / W_tot > 1e-60 for a column that has such a row).
+  if (!mask && h->opt_shortcuts && h->d_ucount && h->have_rowstats && which != TSEM_Z_USER) {
+    uint32_t has_zero = 0;
+    TSEM_HIP(hipMemcpyAsync(&has_zero, h->d_ucount + h->K, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (method == TSEM_RA_ALL && which == TSEM_Z_INITIAL && !has_zero && h->d_colcount) {
+      std::vector<unsigned long long> c(h->K);
+      TSEM_HIP(hipMemcpy(c.data(), h->d_colcount, sizeof(unsigned long long) * h->K, hipMemcpyDeviceToHost));
+      for (int j = 0; j < h->K; ++j) colsums[j] = (double)c[j];
+      return TSEM_OK;
+    }
+    if (method == TSEM_RA_UNIQUE && (which == TSEM_Z_INITIAL || (which == TSEM_Z_CUR ? h->em_cur : h->em_prev))) {
+      std::vector<uint32_t> c(h->K);
+      TSEM_HIP(hipMemcpy(c.data(), h->d_ucount, sizeof(uint32_t) * h->K, hipMemcpyDeviceToHost));
+      for (int j = 0; j < h->K; ++j) colsums[j] = (double)c[j];
+      return TSEM_OK;
+    }
+  }
   A.method = method; A.thresh = thresh;
   double *d_cs = nullptr, *d_mask = nullptr;
   int32_t* d_picks = nullptr;
@@ -2632,13 +2748,27 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
   }
   A.colsums = d_cs; A.zout = d_mask; A.picks = d_picks;
   if (h->N && h->d_colmap && h->d_col_of_pc && h->P > 0) {
-    // hot slots of every part in LDS: one 1024-thread workgroup per CU, ~150 KB of accumulators
+    // hot slots of every part in LDS.  `all` emits one value per stored entry, so it wants as many slots as fit: one
+    // 1024-thread workgroup per CU with ~150 KB of accumulators.  The other modes emit at most a few values per ROW
+    // and the pass is bound by the latency of its dependent loads (row pointers -> entries), not by atomics: two
+    // workgroups per CU (32 waves) with half the slots each (option "rowpass_wgs").
+    const int wgs = (method == TSEM_RA_ALL || h->opt_rowpass_wgs < 2) ? 1 : 2;
     A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;
-    A.Hs = std::min(h->Kp, (int)((TS_LDS_MAX - 8192) / 8 / h->P));
+    A.Hs = std::max(0, std::min(h->Kp, (int)((TS_LDS_MAX / wgs - 8192 / wgs - 1024 - A.lut_len * 8) / 8 / h->P)));
     TSEM_HIP(hipFuncSetAttribute((const void*)k_rowpass<RP_REASSIGN>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
-    k_rowpass<RP_REASSIGN><<<h->n_cu, 1024, (size_t)A.P * A.Hs * 8, h->stream>>>(A);
+    void (*kern)(RowPassArgs) = k_rowpass<RP_REASSIGN>;
+    switch (method) {
+      case TSEM_RA_EXCLUDE: kern = k_rowpass<RP_REASSIGN, TSEM_RA_EXCLUDE>; break;
+      case TSEM_RA_CHOOSE:  kern = k_rowpass<RP_REASSIGN, TSEM_RA_CHOOSE>; break;
+      case TSEM_RA_AVERAGE: kern = k_rowpass<RP_REASSIGN, TSEM_RA_AVERAGE>; break;
+      case TSEM_RA_CONF:    kern = k_rowpass<RP_REASSIGN, TSEM_RA_CONF>; break;
+      case TSEM_RA_UNIQUE:  kern = k_rowpass<RP_REASSIGN, TSEM_RA_UNIQUE>; break;
+      case TSEM_RA_ALL:     kern = k_rowpass<RP_REASSIGN, TSEM_RA_ALL>; break;
+    }
+    TSEM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+    kern<<<h->n_cu * wgs, 1024, (size_t)(A.P * A.Hs + A.lut_len) * 8, h->stream>>>(A);
   } else if (h->N) {
-    k_rowpass<RP_REASSIGN><<<rowpass_grid(h), 256, 0, h->stream>>>(A);
+    k_rowpass<RP_REASSIGN><<<rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   }
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
@@ -2672,7 +2802,7 @@ int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, cons
     if (h->N) TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
   }
   A.colsums = d_out; A.picks = d_picks; A.group = d_grp;
-  if (h->N && n_out) k_rowpass<RP_REASSIGN><<<rowpass_grid(h), 256, 0, h->stream>>>(A);
+  if (h->N && n_out) k_rowpass<RP_REASSIGN><<<rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
   if (n_out) TSEM_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));

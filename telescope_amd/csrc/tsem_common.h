@@ -80,6 +80,11 @@ struct tsem_ctx {
   // ---- model scalars (GLOBAL after set_model) ----
   double W_tot = 0, W_amb = 0, w_max = 0, pi_prior = 0, theta_prior = 0;
   double* d_pisum0 = nullptr;  // [K]
+  uint32_t* d_ucount = nullptr;            // [K+1] unique rows with a positive score per column (local); [K]: some stored score is 0
+  unsigned long long* d_colcount = nullptr;   // [K] stored entries per column (local rows)
+  bool em_cur = false, em_prev = false;    // current / previous pi, theta come from tsem_set_model or the M-step, not from tsem_set_params
+  int64_t opt_rowpass_wgs = 2;             // workgroups per CU of the reassign row pass (modes other than `all`)
+  int64_t opt_shortcuts = 1;               // tsem_reassign answers `all`(initial) and `unique` from the setup counts
   int32_t* d_twin_rep = nullptr;  // [K] representative column of each exact-twin class
   std::vector<uint64_t> col_count;  // global entries per column
   std::vector<int32_t> twin_rep_host;
@@ -137,6 +142,7 @@ struct tsem_ctx {
   int64_t red_count = 0;
   double* d_diffs = nullptr;        // [TS_DIFF_RING]
   double *d_tmp_pi = nullptr, *d_tmp_theta = nullptr;
+  double* d_cnat = nullptr;         // [K] pi*theta in column order for the CSR row passes
 
   // ---- fused-kernel exchange state ----
   double* d_xchg = nullptr;

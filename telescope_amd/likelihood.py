@@ -375,19 +375,25 @@ class TelescopeLikelihood(object):
         """Random picks for `choose`, drawn exactly like sparse_plus.py:140-154:
         one draw per row with >1 best hits, in (global) row order, on numpy's
         legacy global RandomState (seeded by the caller, telescope_assign.py:429-431)."""
-        nbest = self._eng.best_counts(which)
-        parts = self.comm.gather_rows(nbest)
+        eng = self._eng
+        if hasattr(eng, 'best_ties'):                         # compacted on the device: only the tied rows travel
+            rows, counts = eng.best_ties(which)
+        else:                                                 # (tests-only oracle engine)
+            nbest = eng.best_counts(which)
+            rows = np.flatnonzero(nbest > 1).astype(np.int32)
+            counts = nbest[rows]
+        parts = self.comm.gather_rows(counts)                 # rank order == global row order
         if self.comm.rank == 0:
-            allnb = parts[0] if len(parts) == 1 else np.concatenate(parts)
-            multi = np.flatnonzero(allnb > 1)
-            if multi.size == 0:                               # no row has a tie: nothing to draw, nothing to ship
-                parts = [None] * len(parts)
-            else:
-                picks = np.zeros(len(allnb), dtype=np.int32)
-                picks[multi] = np.random.randint(0, allnb[multi])
-                cuts = np.cumsum([len(p) for p in parts])[:-1]
-                parts = np.split(picks, cuts)
-        return self.comm.scatter_rows(parts)
+            allc = parts[0] if len(parts) == 1 else np.concatenate(parts)
+            draws = np.random.randint(0, allc) if allc.size else np.zeros(0, np.int64)
+            cuts = np.cumsum([len(p) for p in parts])[:-1]
+            parts = np.split(np.asarray(draws, dtype=np.int32), cuts)
+        mine = self.comm.scatter_rows(parts)
+        if mine is None or len(rows) == 0:                    # no row has a tie: nothing to apply
+            return None
+        picks = np.zeros(self.N, dtype=np.int32)
+        picks[rows] = mine
+        return picks
 
     def reassign_colsums(self, method, thresh=0.9, initial=False):
         """`reassign(...).sum(0).A1` (model.py:435-457) without materialising the mask."""

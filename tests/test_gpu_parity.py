@@ -358,8 +358,11 @@ def test_ragged_rows_and_kernel_variants(gpu_device):
 @pytest.mark.parametrize('method', ['conf', 'all', 'unique', 'exclude', 'choose', 'average'])
 def test_per_barcode_count_matrix(gpu_device, method):
     """scTelescope.output_report (model.py:611-625): `_assignments[_rows, :].sum(0).A1` per barcode —
-    the segmented device pass against fancy indexing on the assignment matrix."""
+    the segmented device pass against fancy indexing on the ORACLE's assignment matrix (and on the device's)."""
+    from oracle.telescope_oracle import OracleModel
     c, raw, tl, _ = run_case('bundled')
+    om = OracleModel(raw, float(c['pi_prior']), float(c['theta_prior']))
+    om.em(float(c['em_epsilon']), int(c['max_iter']), use_likelihood=bool(c['use_likelihood']))
     rng = np.random.RandomState(3)
     bc = rng.randint(0, 9, tl.N)                         # barcode 8 = reads without a barcode
     groups = [np.flatnonzero(bc == g) for g in range(8)]
@@ -370,10 +373,13 @@ def test_per_barcode_count_matrix(gpu_device, method):
     np.random.seed(int(c['seed']))
     mat = tl.reassign(method, 0.9)
     want = np.vstack([np.asarray(mat[g, :].sum(0)).ravel() for g in groups])
+    np.random.seed(int(c['seed']))
+    omat = sp.csr_matrix(om.reassign(method, 0.9))
+    owant = np.vstack([np.asarray(omat[g, :].sum(0)).ravel() for g in groups])
     if method in ('conf', 'average'):
-        assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-12) and np.allclose(got, owant, rtol=RTOL, atol=1e-12)
     else:
-        assert np.array_equal(got, want)
+        assert np.array_equal(got, want) and np.array_equal(got, owant)
 
 
 def test_device_log1p_matches_libm(gpu_device):

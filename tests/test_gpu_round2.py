@@ -450,3 +450,73 @@ def test_conflict_aware_row_order_option(gpu_device):
     assert np.allclose(res[0][1], res[1][1], rtol=1e-11, atol=0) and np.array_equal(res[0][2], res[1][2])
     assert np.array_equal(res[0][4], res[1][4])             # the same entries, another order
     assert res[1][3] < res[0][3] - 0.5, (res[0][3], res[1][3])
+
+
+# ---------------------------------------------------------------------------------------------------
+# report passes: shortcuts from the setup counts, tie compaction for `choose`
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['bundled', 'tiny_ties', 'tiny_empty_rows', 'mid_zipf_20k'])
+def test_report_shortcuts_equal_the_row_pass(gpu_device, name):
+    """`all` (initial) and `unique` are answered from counts taken at setup (tsem_reassign, option report_shortcuts);
+    the generic row pass must give the same numbers — before and after EM, and a stored score of 0 or parameters set
+    by the caller must switch the shortcut off."""
+    from conftest import case_names
+    if name not in case_names():
+        pytest.skip('no such golden case')
+    c = load_case(name)
+    raw = case_matrix(c)
+    fast, slow = _tl_for(raw, Opts(c)), _tl_for(raw, Opts(c), options=(('report_shortcuts', 0),))
+    for tl in (fast, slow):
+        tl.em()
+    for meth, init in (('all', True), ('unique', False), ('unique', True), ('all', False)):
+        a, b = fast.reassign_colsums(meth, 0.9, init), slow.reassign_colsums(meth, 0.9, init)
+        assert np.array_equal(a, b), (meth, init)
+        assert np.array_equal(a, c['ra_%s_%d_colsum' % (meth, int(init))]), (meth, init)
+    # caller-set parameters with an exact zero: the unique rows of that locus drop out of z's pattern (model.py:720)
+    pi, theta = fast.pi.copy(), fast.theta.copy()
+    j = int(np.argmax(fast.reassign_colsums('unique')))
+    pi[j] = 0.0
+    for tl in (fast, slow):
+        tl._eng.set_params(pi, theta)
+    from telescope_amd._lib import Z_CUR
+    a, _ = fast._eng.reassign('unique', 0.9, Z_CUR)
+    b, _ = slow._eng.reassign('unique', 0.9, Z_CUR)
+    assert np.array_equal(a, b) and a[j] == 0
+
+
+def test_report_shortcut_off_when_a_stored_score_is_zero(gpu_device):
+    from oracle.telescope_oracle import OracleModel
+    rng = np.random.RandomState(2)
+    dense = (rng.rand(300, 40) < 0.15) * rng.randint(1, 200, (300, 40))
+    dense[:, 0] = np.where(dense.sum(1) == 0, 7, dense[:, 0])
+    raw = sp.csr_matrix(dense.astype(np.uint16))
+    raw.data[5] = 0                                        # an explicitly stored zero score (Q = 0)
+    raw.data[11] = 0
+    tl = _tl_for(raw, Opts(max_iter=5, em_epsilon=0.0))
+    tl.em()
+    om = OracleModel(raw)
+    om.em(0.0, 5)
+    for meth, init in (('all', True), ('unique', False), ('all', False)):
+        want = np.asarray(om.reassign(meth, 0.9, initial=init).sum(0)).ravel()
+        assert np.array_equal(tl.reassign_colsums(meth, 0.9, init), want), (meth, init)
+
+
+def test_choose_ties_are_compacted_on_the_device(gpu_device):
+    """tsem_best_ties returns exactly the rows np.flatnonzero(best_counts > 1) and their counts, in row order, so the
+    legacy RNG stream is consumed as before (golden `choose` columns are checked by the reference-parity tests)."""
+    from telescope_amd._lib import Z_INITIAL, Z_PREV
+    c = load_case('tiny_ties')
+    tl = _tl_for(case_matrix(c), Opts(c))
+    tl.em()
+    for which in (Z_INITIAL, Z_PREV):
+        nb = tl._eng.best_counts(which)
+        rows, counts = tl._eng.best_ties(which)
+        assert np.array_equal(rows, np.flatnonzero(nb > 1)) and np.array_equal(counts, nb[nb > 1])
+    assert len(tl._eng.best_ties(Z_INITIAL)[0]) > 0
+    from telescope_amd import synthetic
+    ip, ix, rw = synthetic.generate(200000, 3000, 6, seed=4, dist='uniform', uniq_frac=0.0)
+    rw[:] = 150                                            # every row is one big tie under the initial z
+    t2 = _tl_for(sp.csr_matrix((rw, ix, ip), shape=(200000, 3000)), Opts(max_iter=2, em_epsilon=0.0))
+    rows, counts = t2._eng.best_ties(Z_INITIAL)            # more than the first buffer of 65536 holds
+    nb = t2._eng.best_counts(Z_INITIAL)
+    assert len(rows) > 65536 and np.array_equal(rows, np.flatnonzero(nb > 1)) and np.array_equal(counts, nb[rows])
