@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--fused-dbg', type=int, default=0)
     ap.add_argument('--sorted-fill', type=int, default=-1, help='sub-block order: 1 row order, 0 strand-transposed (-1 auto)')
     ap.add_argument('--geometry', type=int, default=-1, help='fused kernel geometry of teams of 1-4: 0 or 2 (-1 auto)')
+    ap.add_argument('--issue-early', type=int, default=-1, help='fused kernel: partner loads before (1) / after (0) the combine (-1 auto)')
     ap.add_argument('--kernel-timing', type=int, default=4,
                     help='HIP events around every n-th EM pass of the timed region (roofline.kernel_ms); 0 = none')
     ap.add_argument('--deconflict', type=int, default=0, help='1: conflict-aware entry order inside rows (library option, default off)')
@@ -189,6 +190,8 @@ def main():
     eng.set_option('hot_split', args.hot_split)
     eng.set_option('deconflict', args.deconflict)
     eng.set_option('kernel_timing', args.kernel_timing)
+    if args.issue_early >= 0:
+        eng.set_option('issue_early', args.issue_early)
     t_setup = time.perf_counter()
     eng.generate(r0, r1, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
     tl = TelescopeLikelihood.from_engine(eng, Opts(args.steps), comm)

@@ -83,6 +83,7 @@ struct tsem_ctx {
   uint32_t* d_ucount = nullptr;            // [K+1] unique rows with a positive score per column (local); [K]: some stored score is 0
   unsigned long long* d_colcount = nullptr;   // [K] stored entries per column (local rows)
   bool em_cur = false, em_prev = false;    // current / previous pi, theta come from tsem_set_model or the M-step, not from tsem_set_params
+  int64_t opt_issue = -1;                  // fused kernel, exchange wave: partner loads before the combine (1), after it (0), -1 auto
   int64_t opt_rowpass_wgs = 2;             // workgroups per CU of the reassign row pass (modes other than `all`)
   int64_t opt_shortcuts = 1;               // tsem_reassign answers `all`(initial) and `unique` from the setup counts
   int32_t* d_twin_rep = nullptr;  // [K] representative column of each exact-twin class

@@ -192,7 +192,7 @@ struct FzX {                 // context handed to the exchange wave
 };
 
 // Exchange wave of member PP of a P-member team (see k_em_fused for the schedule).
-template <int P, int PP, int MODE, int FMT, int GEO>
+template <int P, int PP, int MODE, int FMT, int GEO, int EARLY>
 __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   constexpr int p = PP;
@@ -240,16 +240,21 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       }
     }
     if (P > 1) {
+      // Validity lives in the DESCRIPTOR (an empty resource returns zeros), never in a per-lane select of the
+      // offset: the compiler turned `ok ? offset : out-of-range` into two exec-masked loads with one destination
+      // and put `s_waitcnt vmcnt(0)` between them — the exchange wave then sat behind the data waves' whole
+      // burst in the middle of its issue sequence, every step (round-2 ISA review; r02 timelines "x:issued").
+      // Lanes past the last row pair re-read row pair R-2: one more hit on a line the wave loads anyway.
+      __amdgpu_buffer_rsrc_t xr = fz_rsrc(xbase, 0, (kv && !nopart) ? (unsigned)(FZ_XS * P * R * 8) : 0u);
 #pragma unroll
       for (int j = 0; j < FZ_RP; ++j) {
-        const int r = rlo + 2 * (lane + 64 * j);
-        const bool ok = kv && r < rhi && !nopart;
+        const int r = min(rlo + 2 * (lane + 64 * j), R - 2);
 #pragma unroll
         for (int q = 0; q < P; ++q) {
           if (q == p) continue;
           // one 16-byte agent-scope (sc1, L1-bypassing) load per row pair and partner
-          const unsigned boff = ok ? (unsigned)((((k & (FZ_XS - 1)) * P + q) * R + r) * 8) : FZ_OOB;
-          fz_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, boff, 0, 16);
+          const unsigned boff = (unsigned)((((k & (FZ_XS - 1)) * P + q) * R + r) * 8);
+          fz_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xr, boff, 0, 16);
           g.pv[q < p ? q : q - 1][j].x = ((unsigned long long)t.y << 32) | t.x;
           g.pv[q < p ? q : q - 1][j].y = ((unsigned long long)t.w << 32) | t.z;
         }
@@ -319,15 +324,16 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       const int64_t kp = i - 1;
       const bool pv = kp >= 0 && kp < nblk;
       const unsigned long long tag = tag_of(kp);
+      __amdgpu_buffer_rsrc_t xs = fz_rsrc(xbase, 0, pv ? (unsigned)(FZ_XS * P * R * 8) : 0u);   // (an empty resource drops the store)
 #pragma unroll
       for (int j = 0; j < FZ_RP; ++j) {
-        const int r = rlo + 2 * (lane + 64 * j);
-        u64x2 yv = *reinterpret_cast<const u64x2*>(&y[(kp & (FZ_YR - 1)) * R + min(r, R - 2)]);
+        const int r = min(rlo + 2 * (lane + 64 * j), R - 2);   // lanes past the last row pair store row pair R-2 again (same bytes)
+        u64x2 yv = *reinterpret_cast<const u64x2*>(&y[(kp & (FZ_YR - 1)) * R + r]);
         fz_u32x4 gq;
         gq.x = ((unsigned)yv.x & ~1u) | (unsigned)tag; gq.y = (unsigned)(yv.x >> 32);
         gq.z = ((unsigned)yv.y & ~1u) | (unsigned)tag; gq.w = (unsigned)(yv.y >> 32);
-        const unsigned boff = (pv && r < rhi) ? (unsigned)((((kp & (FZ_XS - 1)) * P + p) * R + r) * 8) : FZ_OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(gq, xrsrc, boff, 0, 0);
+        const unsigned boff = (unsigned)((((kp & (FZ_XS - 1)) * P + p) * R + r) * 8);
+        __builtin_amdgcn_raw_buffer_store_b128(gq, xs, boff, 0, 0);
       }
     }
     // the publish must enter the memory pipe BEFORE this step's loads (partners read it a step later)
@@ -335,10 +341,25 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     __builtin_amdgcn_sched_barrier(0);
     // sub-block offsets: fetched at step i for block i+5, parked in LDS at step i+1, read by the data waves
     // during step i+2 (anywhere in the step: they carry them to step i+3 in SGPRs), used by burst(i+5) at step i+3
-    issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 3);         // ahead of the data waves' burst(i+2)
-    if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
-    combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 2);       // issued one step ago, behind burst(i)
-    if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
+    // Partner loads before (EARLY) or after the combine of the older generation.  The data waves issue their burst
+    // at the END of the step, so the loads are ahead of it either way.  EARLY: they return sooner and the next
+    // step's combine never waits for them — 4 % (fp64 entries, 40 per row) to 19 % (teams of 8) faster; but a
+    // partner that runs a little behind has not published yet, and a miss costs a spin of sc1 reloads: with short
+    // rows (many row slots per step) the misses grow tenfold and the pass gets up to 2x slower.  LATE: every cycle
+    // the loads wait makes a hit likelier.  A compile-time choice (with both orders behind a run-time flag the
+    // exchange wave's code got 3-15 % slower in every configuration); the host picks the instantiation by row
+    // length (launch_fused).  Same-box A/B/C: profiles/r02_ab_issue_order.txt, DESIGN.md 9.2.
+    if (EARLY) {
+      issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 3);
+      if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
+      combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 2);     // issued one step ago
+      if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
+    } else {
+      combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 2);
+      if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
+      issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 3);
+      if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
+    }
     if (A.prof && team == 0 && p == 0 && lane == 0 && X.xw == 1 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 9] = clock64();
     __syncthreads();
     ++i;
@@ -349,7 +370,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   }
 }
 
-template <int PT, int MODE, int FMT, int GEO>
+template <int PT, int MODE, int FMT, int GEO, int EARLY = 0>
 __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int P = PT;
@@ -449,14 +470,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     X.lut = lutS; X.y = y; X.s = s; X.offs = offs; X.xbase = xbase; X.err = err; X.R = R; X.team = team; X.T = T;
     X.nblk = nblk; X.nsteps = nsteps; X.lane = (tid - FZ_DT) & 63; X.xw = (tid - FZ_DT) >> 6;
     switch (p) {
-      case 0: fz_xchg<P, 0, MODE, FMT, GEO>(A, X); break;
-      case 1: if (P > 1) fz_xchg<P, (P > 1 ? 1 : 0), MODE, FMT, GEO>(A, X); break;
-      case 2: if (P > 2) fz_xchg<P, (P > 2 ? 2 : 0), MODE, FMT, GEO>(A, X); break;
-      case 3: if (P > 3) fz_xchg<P, (P > 3 ? 3 : 0), MODE, FMT, GEO>(A, X); break;
-      case 4: if (P > 4) fz_xchg<P, (P > 4 ? 4 : 0), MODE, FMT, GEO>(A, X); break;
-      case 5: if (P > 5) fz_xchg<P, (P > 5 ? 5 : 0), MODE, FMT, GEO>(A, X); break;
-      case 6: if (P > 6) fz_xchg<P, (P > 6 ? 6 : 0), MODE, FMT, GEO>(A, X); break;
-      case 7: if (P > 7) fz_xchg<P, (P > 7 ? 7 : 0), MODE, FMT, GEO>(A, X); break;
+      case 0: fz_xchg<P, 0, MODE, FMT, GEO, EARLY>(A, X); break;
+      case 1: if (P > 1) fz_xchg<P, (P > 1 ? 1 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
+      case 2: if (P > 2) fz_xchg<P, (P > 2 ? 2 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
+      case 3: if (P > 3) fz_xchg<P, (P > 3 ? 3 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
+      case 4: if (P > 4) fz_xchg<P, (P > 4 ? 4 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
+      case 5: if (P > 5) fz_xchg<P, (P > 5 ? 5 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
+      case 6: if (P > 6) fz_xchg<P, (P > 6 ? 6 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
+      case 7: if (P > 7) fz_xchg<P, (P > 7 ? 7 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
       default: break;
     }
   } else {
