@@ -1365,12 +1365,12 @@ static fz_fn fz_kernel(int P, int mode, int fmt, int geo, int early = 0) {
 }
 
 // code16 entry format: only with the fused kernel, and only while the score table is small enough to
-// sit in LDS beside the column tables (uint16 scores allow 65536 entries; alignments give a few hundred)
-// `auto` keeps fp64 entries for very short rows (< 4 entries per row and part): the pass is then bound by
-// the per-row exchange, and the fp64 layout's third exchange wave beats the smaller entries
-// (10 nnz/row at P = 4: 1.82 ms against 2.30 ms; 20 nnz/row: 2.59 against 2.68, where codes win on memory).
+// sit in LDS beside the column tables (uint16 scores allow 65536 entries; alignments give a few hundred).
+// With the round-2 exchange (branch-free, partner loads after the combine for short rows) codes in row order win
+// at every row length measured — 10 / 14 / 20 / 28 / 40 / 100 entries per row: 1.47 / 1.61 / 1.98 / 2.55 / 3.60 /
+// 3.76 ms against 1.71 / 1.96 / 2.57 / 3.26 / 4.23 / 4.39 ms with fp64 entries (profiles/r02_sweep_short.txt).
 static bool fz_wants_codes(const tsem_ctx* h) {
-  return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048 && (h->opt_format == 2 || h->run_len_est >= 4.0);
+  return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048;
 }
 static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
   return (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0);
@@ -1647,9 +1647,10 @@ static int choose_geometry(tsem_ctx* h) {
       // geometry: teams of 5-8 have one; smaller teams switch to three exchange waves when the rows
       // are so short that 512 row slots cannot fill the register tile and the pass is bound by the
       // exchange (fp64 entries; with score codes the 14th data wave is worth more)
-      // (r02 sweep, fp64 entries, 50M rows: 10 nnz/row 2.11 -> 1.68 ms with geometry 2, 20 nnz/row 2.69 -> 2.71 ms:
-      // the third exchange wave pays once the tile would need more than ~1.8x the 512 row slots of geometry 0)
-      h->geo = P > 4 ? 1 : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > 1.8 * fz_rmax(0) && !fz_wants_codes(h)) ? 2 : 0);
+      // (profiles/r02_sweep_short.txt, 50M rows, both entry formats: the third exchange wave pays once the tile
+      // needs more than ~1.25x the 512 row slots of geometry 0 — 20 entries per row: codes 2.21 -> 1.98 ms, fp64
+      // 2.63 -> 2.57; 28 per row: codes 2.55 -> 2.66, fp64 equal)
+      h->geo = P > 4 ? 1 : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > 1.25 * fz_rmax(0)) ? 2 : 0);
       if (h->opt_geo >= 0 && P <= 4) h->geo = h->opt_geo == 2 ? 2 : 0;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
@@ -1921,12 +1922,12 @@ static int build_layout(tsem_ctx* h) {
     TSEM_ALLOC(h->d_pval, off);
     TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
   }
-  // Row order pays when the LDS is the limit (score codes) and a row has >= 4 entries per part: 40 nnz/row at
-  // P = 4 4.46 -> 3.57 ms, 20 nnz/row 2.73 -> 2.38 ms, but 10 nnz/row 2.23 -> 2.80 ms; with fp64 entries (bound by
-  // the memory path) the plain order is as fast or faster: gpurun_out/sweep_r02a.log, DESIGN.md 9.
+  // Row order pays whenever the LDS is the limit (score codes): 40 entries per row at P = 4 4.44 -> 3.61 ms, 20 per
+  // row 2.30 -> 1.98 ms, 10 per row 1.67 -> 1.47 ms; with fp64 entries (bound by the memory path) the plain order
+  // is as fast: profiles/r02_sweep.txt, r02_sweep_short.txt, DESIGN.md 9.
   const double run_len = na > 0 ? (double)(h->nnz - h->N_uni) / (double)na / P : 0.0;
   h->sorted_layout = h->use_fused && R * P <= 512 * 8 &&   // (the fill kernel keeps R x P counters in LDS)
-                     (h->opt_sorted >= 0 ? h->opt_sorted != 0 : (h->fmt_code && run_len >= 4.0));
+                     (h->opt_sorted >= 0 ? h->opt_sorted != 0 : h->fmt_code);
   if (nb && h->sorted_layout) {
     k_sb_fill_sorted<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
