@@ -1328,37 +1328,25 @@ static int ensure_device(tsem_ctx* h) {
 }
 
 typedef void (*fz_fn)(FusedArgs);
-// EARLY (partner loads before the combine, tsem_fused.h) exists for the EM pass of teams of 5-8 and of teams of 1-4
-// with fp64 entries in the base geometry: where the A/B showed a gain for long rows; everything else is LATE.
-template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt, int early) {
-  if (fmt == 1) {
-    if (mode) return k_em_fused<P, 1, 1, GEO>;
-    if constexpr (GEO == 1) { if (early) return k_em_fused<P, 0, 1, GEO, 1>; }
-    return k_em_fused<P, 0, 1, GEO>;
-  }
-  if (fmt == 2) {
-    if (mode) return k_em_fused<P, 1, 2, GEO>;
-    if constexpr (GEO != 2) { if (early) return k_em_fused<P, 0, 2, GEO, 1>; }
-    return k_em_fused<P, 0, 2, GEO>;
-  }
-  if (mode) return k_em_fused<P, 1, 0, GEO>;
-  if constexpr (GEO != 2) { if (early) return k_em_fused<P, 0, 0, GEO, 1>; }
-  return k_em_fused<P, 0, 0, GEO>;
+template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
+  if (fmt == 1) return mode ? k_em_fused<P, 1, 1, GEO> : k_em_fused<P, 0, 1, GEO>;
+  if (fmt == 2) return mode ? k_em_fused<P, 1, 2, GEO> : k_em_fused<P, 0, 2, GEO>;
+  return mode ? k_em_fused<P, 1, 0, GEO> : k_em_fused<P, 0, 0, GEO>;
 }
-template <int P> static fz_fn fz_pick(int mode, int fmt, int geo, int early) {
-  if constexpr (P > 4) return fz_pick2<P, 1>(mode, fmt, early);   // teams of 5-8: one geometry
-  else return geo == 2 ? fz_pick2<P, 2>(mode, fmt, early) : fz_pick2<P, 0>(mode, fmt, early);
+template <int P> static fz_fn fz_pick(int mode, int fmt, int geo) {
+  if constexpr (P > 4) return fz_pick2<P, 1>(mode, fmt);   // teams of 5-8: one geometry
+  else return geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 0>(mode, fmt);
 }
 static int fz_fmt(const tsem_ctx* h) { return h->fmt_code ? 1 : (h->fmt_wcode ? 2 : 0); }
-static fz_fn fz_kernel(int P, int mode, int fmt, int geo, int early = 0) {
+static fz_fn fz_kernel(int P, int mode, int fmt, int geo) {
 #ifdef TSEM_FAST_BUILD                                     // kernel experiments (tools/ab.sh): teams of 4 only, 1/8 of the build time
-  return P == 4 ? fz_pick<4>(mode, fmt, geo, early) : nullptr;
+  return P == 4 ? fz_pick<4>(mode, fmt, geo) : nullptr;
 #else
   switch (P) {
-    case 1: return fz_pick<1>(mode, fmt, geo, early); case 2: return fz_pick<2>(mode, fmt, geo, early);
-    case 3: return fz_pick<3>(mode, fmt, geo, early); case 4: return fz_pick<4>(mode, fmt, geo, early);
-    case 5: return fz_pick<5>(mode, fmt, geo, early); case 6: return fz_pick<6>(mode, fmt, geo, early);
-    case 7: return fz_pick<7>(mode, fmt, geo, early); case 8: return fz_pick<8>(mode, fmt, geo, early);
+    case 1: return fz_pick<1>(mode, fmt, geo); case 2: return fz_pick<2>(mode, fmt, geo);
+    case 3: return fz_pick<3>(mode, fmt, geo); case 4: return fz_pick<4>(mode, fmt, geo);
+    case 5: return fz_pick<5>(mode, fmt, geo); case 6: return fz_pick<6>(mode, fmt, geo);
+    case 7: return fz_pick<7>(mode, fmt, geo); case 8: return fz_pick<8>(mode, fmt, geo);
     default: return nullptr;
   }
 #endif
@@ -1463,7 +1451,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "kernel_timing") h->opt_timing = v;
   else if (k == "report_shortcuts") h->opt_shortcuts = v;
   else if (k == "rowpass_wgs") h->opt_rowpass_wgs = v;
-  else if (k == "issue_early") h->opt_issue = v;
+  else if (k == "issue_early") h->opt_issue = v;       // (kept for old scripts; the exchange has one order now)
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
     if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
@@ -1974,9 +1962,8 @@ static int build_layout(tsem_ctx* h) {
         k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
       }
       for (int mode = 0; mode < 2; ++mode)
-        for (int early = 0; early < 2; ++early)
-          TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h), h->geo, early),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h), h->geo),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
     }
   }
   TSEM_HIP(hipFuncSetAttribute((const void*)k_phase1<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
@@ -2147,10 +2134,7 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
   const size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
   if (mode && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
-  // early partner loads (fz_xchg): long rows only — from 4.5 entries per row and part with teams of 1-4 (fp64 entries,
-  // 20 per row: 2.70 -> 2.62 ms; 40: 4.41 -> 4.24), from 8 with teams of 5-8 (100 per row: 5.25 -> 4.37 ms)
-  const int early = h->opt_issue >= 0 ? (int)(h->opt_issue != 0) : (h->run_len_est >= (h->P > 4 ? 8.0 : 4.5) ? 1 : 0);
-  fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h), h->geo, early);
+  fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h), h->geo);
   if (!fn) TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
   if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
   fn<<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A);

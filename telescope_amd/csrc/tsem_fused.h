@@ -192,7 +192,7 @@ struct FzX {                 // context handed to the exchange wave
 };
 
 // Exchange wave of member PP of a P-member team (see k_em_fused for the schedule).
-template <int P, int PP, int MODE, int FMT, int GEO, int EARLY>
+template <int P, int PP, int MODE, int FMT, int GEO>
 __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   constexpr int p = PP;
@@ -216,8 +216,8 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   };
   if (!(A.dbg & 16)) __builtin_amdgcn_s_setprio(3);   // few instructions, all on the critical path of the step
   struct Gen { u64x2 pv[NPART][FZ_RP]; double2 w[FZ_RP]; uint32_t wc[FZ_RP]; uint32_t off; };
-  Gen ga, gb;
-  ga.off = gb.off = 0;
+  Gen g1;
+  g1.off = 0;
   // issue the partner / weight loads of block k and the offset fetch of block ko (never branched around)
   auto issue = [&](Gen& g, int64_t k, int64_t ko) {
     {
@@ -314,9 +314,21 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     }
     return;
   }
-  auto xstep = [&](Gen& gnew, Gen& gold) {
+  auto xstep = [&]() {
     const bool pr = A.prof && team == 0 && p == 0 && lane == 0 && offw && (int)i < A.prof_blocks;
     if (pr) A.prof[i * FZ_PROF_SLOTS + 6] = clock64();
+    // ONE generation of partner values, loaded and combined in the SAME step.  The loads go out right after the
+    // publish (two steps after the partners published theirs, ahead of this step's burst of the data waves, which
+    // comes at its end); they come back through the in-order memory pipe behind the previous burst, and the wave
+    // has nothing else to do meanwhile (loads before the publish: no difference).  Round 1 and the first round-2 version kept TWO generations in flight across
+    // the barrier, alternating between two structs: the compiler could not prove the one combined last step
+    // complete on every path, put `s_waitcnt vmcnt(0..2)` in front of every second publish (whose temporaries
+    // landed on that generation's registers), and the wave sat 1000-2400 clk behind the data waves' burst before
+    // it published — every second step 500-1000 clk longer (timelines: "x:published" 60 vs 1000-2400 clk).  A
+    // single struct combined at the top of the NEXT step instead is bistable: one late combine (a partner that
+    // runs behind) delays the next issue behind the burst, whose values then come late, and so on for the rest of
+    // the pass.  Same-step is robust, needs half the registers, and the two steps between publish and load make
+    // a miss rarer (profiles/r02_ab_exchange.txt).
     // publish y(i-1): tagged granules, 16-byte stores (a tear between halves is harmless).  PLAIN
     // stores: the line stays in the XCD's L2, where the partners' sc1 loads find it (a write-through
     // sc1 store drops it from L2: measured 14 M tag misses per pass vs 0.14 M)
@@ -328,49 +340,26 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
 #pragma unroll
       for (int j = 0; j < FZ_RP; ++j) {
         const int r = min(rlo + 2 * (lane + 64 * j), R - 2);   // lanes past the last row pair store row pair R-2 again (same bytes)
-        u64x2 yv = *reinterpret_cast<const u64x2*>(&y[(kp & (FZ_YR - 1)) * R + r]);
-        fz_u32x4 gq;
-        gq.x = ((unsigned)yv.x & ~1u) | (unsigned)tag; gq.y = (unsigned)(yv.x >> 32);
-        gq.z = ((unsigned)yv.y & ~1u) | (unsigned)tag; gq.w = (unsigned)(yv.y >> 32);
+        fz_u32x4 gq = *reinterpret_cast<const fz_u32x4*>(&y[(kp & (FZ_YR - 1)) * R + r]);
+        gq.x = (gq.x & ~1u) | (unsigned)tag;
+        gq.z = (gq.z & ~1u) | (unsigned)tag;
         const unsigned boff = (unsigned)((((kp & (FZ_XS - 1)) * P + p) * R + r) * 8);
         __builtin_amdgcn_raw_buffer_store_b128(gq, xs, boff, 0, 0);
       }
     }
-    // the publish must enter the memory pipe BEFORE this step's loads (partners read it a step later)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // sub-block offsets: fetched at step i for block i+5, parked in LDS at step i+1, read by the data waves
-    // during step i+2 (anywhere in the step: they carry them to step i+3 in SGPRs), used by burst(i+5) at step i+3
-    // Partner loads before (EARLY) or after the combine of the older generation.  The data waves issue their burst
-    // at the END of the step, so the loads are ahead of it either way.  EARLY: they return sooner and the next
-    // step's combine never waits for them — 4 % (fp64 entries, 40 per row) to 19 % (teams of 8) faster; but a
-    // partner that runs a little behind has not published yet, and a miss costs a spin of sc1 reloads: with short
-    // rows (many row slots per step) the misses grow tenfold and the pass gets up to 2x slower.  LATE: every cycle
-    // the loads wait makes a hit likelier.  A compile-time choice (with both orders behind a run-time flag the
-    // exchange wave's code got 3-15 % slower in every configuration); the host picks the instantiation by row
-    // length (launch_fused).  Same-box A/B/C: profiles/r02_ab_issue_order.txt, DESIGN.md 9.2.
-    if (EARLY) {
-      issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 3);
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
-      combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 2);     // issued one step ago
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
-    } else {
-      combine(gold, i - 2 - FZ_GAP, i + FZ_DL + 2);
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
-      issue(gnew, i - 1 - FZ_GAP, i + FZ_DL + 3);
-      if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
-    }
+    if (pr) A.prof[i * FZ_PROF_SLOTS + 10] = clock64();   // (waits for the LDS reads of the publish: lgkmcnt)
+    issue(g1, i - 2 - FZ_GAP, i + FZ_DL + 2);
+    if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
+    combine(g1, i - 2 - FZ_GAP, i + FZ_DL + 2);
+    if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
     if (A.prof && team == 0 && p == 0 && lane == 0 && X.xw == 1 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 9] = clock64();
     __syncthreads();
     ++i;
   };
-  while (i < nsteps) {
-    xstep(ga, gb); if (i >= nsteps) break;
-    xstep(gb, ga);
-  }
+  while (i < nsteps) xstep();
 }
 
-template <int PT, int MODE, int FMT, int GEO, int EARLY = 0>
+template <int PT, int MODE, int FMT, int GEO>
 __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int P = PT;
@@ -470,14 +459,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     X.lut = lutS; X.y = y; X.s = s; X.offs = offs; X.xbase = xbase; X.err = err; X.R = R; X.team = team; X.T = T;
     X.nblk = nblk; X.nsteps = nsteps; X.lane = (tid - FZ_DT) & 63; X.xw = (tid - FZ_DT) >> 6;
     switch (p) {
-      case 0: fz_xchg<P, 0, MODE, FMT, GEO, EARLY>(A, X); break;
-      case 1: if (P > 1) fz_xchg<P, (P > 1 ? 1 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
-      case 2: if (P > 2) fz_xchg<P, (P > 2 ? 2 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
-      case 3: if (P > 3) fz_xchg<P, (P > 3 ? 3 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
-      case 4: if (P > 4) fz_xchg<P, (P > 4 ? 4 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
-      case 5: if (P > 5) fz_xchg<P, (P > 5 ? 5 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
-      case 6: if (P > 6) fz_xchg<P, (P > 6 ? 6 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
-      case 7: if (P > 7) fz_xchg<P, (P > 7 ? 7 : 0), MODE, FMT, GEO, EARLY>(A, X); break;
+      case 0: fz_xchg<P, 0, MODE, FMT, GEO>(A, X); break;
+      case 1: if (P > 1) fz_xchg<P, (P > 1 ? 1 : 0), MODE, FMT, GEO>(A, X); break;
+      case 2: if (P > 2) fz_xchg<P, (P > 2 ? 2 : 0), MODE, FMT, GEO>(A, X); break;
+      case 3: if (P > 3) fz_xchg<P, (P > 3 ? 3 : 0), MODE, FMT, GEO>(A, X); break;
+      case 4: if (P > 4) fz_xchg<P, (P > 4 ? 4 : 0), MODE, FMT, GEO>(A, X); break;
+      case 5: if (P > 5) fz_xchg<P, (P > 5 ? 5 : 0), MODE, FMT, GEO>(A, X); break;
+      case 6: if (P > 6) fz_xchg<P, (P > 6 ? 6 : 0), MODE, FMT, GEO>(A, X); break;
+      case 7: if (P > 7) fz_xchg<P, (P > 7 ? 7 : 0), MODE, FMT, GEO>(A, X); break;
       default: break;
     }
   } else {
@@ -632,7 +621,9 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      load_blk(rs, oqa, oqb, i + FZ_DL);                  // the set is free again: refill it with block i+DL
+      // refill the set at the END of the step.  (Issuing the burst in the middle — products and slots of phase 2 in
+      // temporaries — so that it drains before the next step's exchange loads was tried: fp64 entries 4.4 -> 5.2 ms.)
+      load_blk(rs, oqa, oqb, i + FZ_DL);
       if (pr) A.prof[i * FZ_PROF_SLOTS + 2] = clock64();
       if (A.prof && team == 0 && p == 0 && tid == FZ_DT - 64 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 8] = clock64();
       __builtin_amdgcn_s_waitcnt(0xC47F);                 // lgkmcnt(4): everything but the four scatters above has completed

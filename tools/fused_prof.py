@@ -19,10 +19,10 @@ eng.set_option('fused_prof', 1)
 eng.em_steps(1, False)
 t = eng.fused_prof().astype(np.int64)
 print(eng.layout_info())
-names = ['start', 'ops gathered', 'burst issued', 'P1 atomics', 'barrier', 'x:combined', 'x:start', 'x:issued', 'w13 pre-wait', 'x1:combined']
+names = ['start', 'ops gathered', 'burst issued', 'P1 atomics', 'barrier', 'x:combined', 'x:start', 'x:issued', 'w13 pre-wait', 'x1:combined', 'x:published']
 base = t[4, 0]
 print('cycles relative to block start (blocks 4..11); clock ~2.1-2.4 GHz (shader clock / s_memtime)')
 print('%-6s' % 'blk' + ''.join('%13s' % n for n in names) + '%12s' % 'blk total')
 for i in range(4, 24):
-    row = t[i, :10] - t[i, 0]
+    row = t[i, :11] - t[i, 0]
     print('%-6d' % i + ''.join('%13d' % v for v in row) + '%12d' % (t[i + 1, 0] - t[i, 0]))
