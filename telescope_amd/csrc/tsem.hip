@@ -1910,12 +1910,14 @@ static int build_layout(tsem_ctx* h) {
     TSEM_ALLOC(h->d_pval, off);
     TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
   }
-  // Row order pays whenever the LDS is the limit (score codes): 40 entries per row at P = 4 4.44 -> 3.61 ms, 20 per
-  // row 2.30 -> 1.98 ms, 10 per row 1.67 -> 1.47 ms; with fp64 entries (bound by the memory path) the plain order
-  // is as fast: profiles/r02_sweep.txt, r02_sweep_short.txt, DESIGN.md 9.
-  const double run_len = na > 0 ? (double)(h->nnz - h->N_uni) / (double)na / P : 0.0;
+  // Row order (row sums reduced in registers, a tenth of the LDS atomics) for every fused layout.  Score codes: 40
+  // entries per row at P = 4 4.44 -> 3.59 ms, 20 per row 2.30 -> 1.92, 10 per row 1.65 -> 1.40.  fp64 entries
+  // were indifferent to it while the exchange wave stalled behind the memory pipe (round 1: 4.62 against 4.57 ms);
+  // since the exchange is one generation per step, the step ends when the LDS queue has drained, and less LDS work
+  // shortens it for them too: 40 per row 4.33 -> 4.14 ms (0.73 of the HBM peak), teams of 8 4.42 -> 4.20, 20 per
+  // row 2.70 -> 2.48 (profiles/r02_sweep.txt, r02_sweep_short.txt).
   h->sorted_layout = h->use_fused && R * P <= 512 * 8 &&   // (the fill kernel keeps R x P counters in LDS)
-                     (h->opt_sorted >= 0 ? h->opt_sorted != 0 : h->fmt_code);
+                     (h->opt_sorted >= 0 ? h->opt_sorted != 0 : true);
   if (nb && h->sorted_layout) {
     k_sb_fill_sorted<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
