@@ -16,10 +16,10 @@
 //     flag, no drain, no fence;
 //   * a CU's vector-memory path returns data IN ORDER, so any exchange load waits
 //     for every streaming load issued before it (measured 12 k cycles).  Instead of
-//     fighting that, the exchange RIDES the stream: the partner loads of block k are
-//     issued by the data threads themselves two steps after its row sums, just
-//     before that step's prefetch burst, and consumed one step later when they
-//     return anyway;
+//     fighting that, the exchange RIDES the stream: dedicated exchange waves publish
+//     block k's partial sums one step after they were accumulated and load the partners'
+//     two steps later, right after the barrier -- ahead of that step's prefetch burst,
+//     behind the previous one -- and combine them in the same step;
 //   * each member keeps its sub-block's numerators in REGISTERS between row-sum
 //     phase (step k) and scatter phase (step k+4): a ring of 6 register sets, prefetch
 //     distance 2 steps, so every stored entry is read from HBM exactly once and the
@@ -37,9 +37,9 @@
 #pragma once
 
 constexpr int FZ_NT = 1024;            // threads per workgroup
-// Geometry (GEO): the exchange waves keep two generations of (P-1) partner values per row pair in
-// registers, so larger teams use more exchange waves with fewer row pairs per lane; short rows need
-// more row slots per block to fill the register tile.
+// Geometry (GEO): the exchange waves keep (P-1) partner values per row pair in registers, so larger
+// teams use more exchange waves with fewer row pairs per lane; short rows need more row slots per
+// block to fill the register tile.
 //   0 : 2 exchange waves x 2 row pairs per lane (R <= 512), 14 data waves   teams of 1-4
 //   1 : 3 exchange waves x 1 row pair  per lane (R <= 384), 13 data waves   teams of 5-8
 //   2 : 3 exchange waves x 2 row pairs per lane (R <= 768), 13 data waves   teams of 1-4, short rows
@@ -320,8 +320,8 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     // ONE generation of partner values, loaded and combined in the SAME step.  The loads go out right after the
     // publish (two steps after the partners published theirs, ahead of this step's burst of the data waves, which
     // comes at its end); they come back through the in-order memory pipe behind the previous burst, and the wave
-    // has nothing else to do meanwhile (loads before the publish: no difference).  Round 1 and the first round-2 version kept TWO generations in flight across
-    // the barrier, alternating between two structs: the compiler could not prove the one combined last step
+    // has nothing else to do meanwhile (loads before the publish: no difference).  Round 1 and the first round-2
+    // version kept TWO generations in flight across the barrier, alternating between two structs: the compiler could not prove the one combined last step
     // complete on every path, put `s_waitcnt vmcnt(0..2)` in front of every second publish (whose temporaries
     // landed on that generation's registers), and the wave sat 1000-2400 clk behind the data waves' burst before
     // it published — every second step 500-1000 clk longer (timelines: "x:published" 60 vs 1000-2400 clk).  A
@@ -420,16 +420,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   //   step k-2 : prefetch burst          load(k)            -> register set k % 6
   //   step k   : row sums                P1(k)              -> y[k & 3]
   //   step k+1 : publish                 granules of y(k)   (exchange waves)
-  //   step k+2 : partner loads issued    (exchange waves, before that step's burst)
-  //   step k+3 : combine                 s[k & 1] = w / sum_q y_q ; y[k & 3] = 0
+  //   step k+3 : partner loads + combine s[k & 1] = w / sum_q y_q ; y[k & 3] = 0   (exchange waves, same step)
   //   step k+4 : scatter                 P2(k), set k % 6 is then refilled with block k+6
   // one barrier per step.
   const int64_t nblk = (A.nb > team) ? (A.nb - team + T - 1) / T : 0;
   // Role split: the last 2-3 waves are exchange waves (they hold no matrix entries, so they can afford
-  // the registers for two generations of partner values); the others are data waves.  A CU's vector-
-  // memory pipe returns in order, so every exchange access is issued right after the barrier (ahead of
-  // the data waves' burst) and only waited for one step later, when the burst issued before it has
-  // landed anyway.
+  // the registers for the partner values); the others are data waves.  A CU's vector-memory pipe
+  // returns in order, so every exchange access is issued right after the barrier: ahead of the data
+  // waves' burst of this step (which they issue at its end), behind the burst of the previous one.
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   auto slot_of = [&](int64_t k, int q) -> unsigned long long* {
     return xbase + ((int64_t)(k & (FZ_XS - 1)) * P + q) * R;
@@ -583,6 +581,8 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       const bool idle2 = rs.rc.x == 0xFFFFFFFFu;
       const uint32_t a0 = idle2 ? 0u : rs.rc.x, a1 = rs.rc.y, a2 = rs.rc.z, a3 = rs.rc.w;
       const double* sb = s + (k2 & 1) * R;
+      // (Row order: gathering only the outer two row factors of a lane when no lane of the wave spans three rows
+      // — two LDS reads less per lane — was tried: the wave-uniform branch costs more than the reads, 4.20 -> 4.30 ms.)
       const double s0 = sb[a0 >> 16], s1 = sb[a1 >> 16], s2 = sb[a2 >> 16], s3 = sb[a3 >> 16];
       double2 q0 = rp.v0, q1 = rp.v1;
       if (FMT == 1) {                                     // Q from the score table: the same fp64 the fp64 layout stores
