@@ -89,7 +89,8 @@ int  tsem_synchronize(tsem_ctx* h);
  * CSR of uint16 raw scores for the rows this rank owns.  `lut[r]` is
  * Q = expm1((r * (1/max_score)) * 100.) for r = 0..lut_len-1, computed by the
  * host with the reference's numpy expression so Q is bit-identical; max_score
- * is the GLOBAL maximum (all ranks).  */
+ * is the GLOBAL maximum (all ranks).  The arrays are borrowed for the call, copied to HBM and validated there
+ * (non-decreasing row pointers, column ids in [0, n_cols), scores < lut_len): TSEM_ERR_ARG and no matrix otherwise. */
 int  tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols,
                       const int64_t* indptr, const int32_t* indices,
                       const uint16_t* raw, const double* lut, int32_t lut_len);

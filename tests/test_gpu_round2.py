@@ -520,3 +520,23 @@ def test_choose_ties_are_compacted_on_the_device(gpu_device):
     rows, counts = t2._eng.best_ties(Z_INITIAL)            # more than the first buffer of 65536 holds
     nb = t2._eng.best_counts(Z_INITIAL)
     assert len(rows) > 65536 and np.array_equal(rows, np.flatnonzero(nb > 1)) and np.array_equal(counts, nb[rows])
+
+
+def test_load_scores_validates_on_the_device(gpu_device):
+    """tsem_load_scores checks the caller's arrays after the copy, on the device: every violation is TSEM_ERR_ARG with
+    the same message the host loop of round 1 gave, and leaves the handle without a matrix."""
+    from telescope_amd._lib import Engine, EngineError
+    from telescope_amd.likelihood import score_lut
+    lut = score_lut(300)
+    indptr = np.array([0, 2, 3], np.int64); idx = np.array([0, 2, 1], np.int32); raw = np.array([150, 200, 300], np.uint16)
+    eng = Engine(0)
+    eng.load_scores(indptr, idx, raw, 3, lut)
+    assert eng.dims() == (2, 3, 3)
+    for bad_ptr, bad_idx, bad_raw, msg in (
+            (np.array([0, 3, 2], np.int64), idx, raw, 'non-decreasing'),
+            (np.array([0, 2, 3], np.int64), np.array([0, 3, 1], np.int32), raw, 'column index out of range'),
+            (np.array([0, 2, 3], np.int64), np.array([0, -1, 1], np.int32), raw, 'column index out of range'),
+            (np.array([0, 2, 3], np.int64), idx, np.array([150, 301, 300], np.uint16), 'exceeds lookup table')):
+        with pytest.raises(EngineError, match=msg):
+            eng.load_scores(bad_ptr, bad_idx, bad_raw, 3, lut)
+    eng.load_scores(indptr, idx, raw, 3, lut)               # the handle is usable afterwards

@@ -23,9 +23,9 @@ for rep in range(3):
     eng.load_scores(indptr, indices, raw, 30000, lut)
     eng.synchronize()
     best = min(best, time.perf_counter() - t0)
+print('tsem_load_scores %.1f ms = %.1f GB/s host -> HBM (copy + validation on the device)' % (best * 1e3, nbytes / best / 1e9))
 print('rows %d  entries %d  host arrays %.2f GB (int64 indptr, int32 indices, uint16 scores; pageable numpy memory)'
       % (rows, len(indices), nbytes / 1e9))
-print('tsem_load_scores: %.1f ms = %.1f GB/s host -> HBM' % (best * 1e3, nbytes / best / 1e9))
 stats, pisum0, cnt, hsh = eng.rowstats()
 eng.set_model(stats, pisum0, cnt, hsh, 0.0, 200000.0)
 eng.em_steps(3, False); eng.synchronize()
