@@ -90,7 +90,9 @@ int  tsem_synchronize(tsem_ctx* h);
  * Q = expm1((r * (1/max_score)) * 100.) for r = 0..lut_len-1, computed by the
  * host with the reference's numpy expression so Q is bit-identical; max_score
  * is the GLOBAL maximum (all ranks).  The arrays are borrowed for the call, copied to HBM and validated there
- * (non-decreasing row pointers, column ids in [0, n_cols), scores < lut_len): TSEM_ERR_ARG and no matrix otherwise. */
+ * (non-decreasing row pointers, column ids in [0, n_cols), scores < lut_len): TSEM_ERR_ARG and no matrix otherwise.
+ * `lut` may be NULL: the table then follows with tsem_set_lut once the (global) maximum is known — tsem_max_score
+ * takes it on the device, so the host never has to scan the entries. */
 int  tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols,
                       const int64_t* indptr, const int32_t* indices,
                       const uint16_t* raw, const double* lut, int32_t lut_len);

@@ -190,6 +190,10 @@ class Engine(object):
         indptr = np.ascontiguousarray(indptr, dtype=np.int64)
         indices = np.ascontiguousarray(indices, dtype=np.int32)
         raw = np.ascontiguousarray(raw, dtype=np.uint16)
+        if lut is None:                                   # the table follows: max_score() -> set_lut()
+            self._ck(self._L.tsem_load_scores(self._h, len(indptr) - 1, int(n_cols), ptr(indptr), ptr(indices),
+                                              ptr(raw), None, 0))
+            return
         lut = np.ascontiguousarray(lut, dtype=np.float64)
         self._ck(self._L.tsem_load_scores(self._h, len(indptr) - 1, int(n_cols), ptr(indptr), ptr(indices),
                                           ptr(raw), ptr(lut), len(lut)))

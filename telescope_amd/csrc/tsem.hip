@@ -1487,10 +1487,19 @@ __global__ __launch_bounds__(256) void k_check_csr(int64_t N, int32_t K, int32_t
     const int64_t a = indptr[i], b = indptr[i + 1];
     if (b < a || a < 0 || b > nnz) f |= 1u;
   }
+  // canonical form (column ids strictly increasing inside a row): every position where the ids do not increase must
+  // be the first entry of a row -> count such positions over the entries and over the row starts, compare
+  unsigned long long desc = 0;
   for (int64_t k = t0; k < nnz; k += stride) {
     if ((uint32_t)indices[k] >= (uint32_t)K) f |= 2u;
     if ((int32_t)raw[k] >= lut_len) f |= 4u;
+    if (k > 0 && indices[k] <= indices[k - 1]) ++desc;
   }
+  for (int64_t i = t0; i < N; i += stride) {
+    const int64_t a = indptr[i], b = indptr[i + 1];
+    if (a > 0 && a < b && a < nnz && indices[a] <= indices[a - 1]) --desc;     // (wraps; the sum over all threads is what counts)
+  }
+  if (desc) atomicAdd(reinterpret_cast<unsigned long long*>(bad + 2), desc);
   if (f) atomicOr(bad, f);
 }
 
@@ -1504,7 +1513,12 @@ int tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols, const int64_t*
   if (indptr[0] != 0 || nnz < 0) TSEM_FAIL(TSEM_ERR_ARG, "indptr must start at 0");
   if (nnz && (!indices || !raw)) TSEM_FAIL(TSEM_ERR_ARG, "null entry arrays");
   free_matrix(h);
-  if (int rc = set_lut(h, lut, lut_len)) return rc;
+  if (lut) {
+    if (int rc = set_lut(h, lut, lut_len)) return rc;
+  } else {                                                   // the table follows (tsem_max_score -> tsem_set_lut)
+    dfree(h->d_lut); h->lut_host.clear(); h->lut_len = 0;
+    lut_len = 65536;
+  }
   h->N = n_rows; h->K = n_cols; h->nnz = nnz;
   TSEM_ALLOC(h->d_indptr, n_rows + 1);
   TSEM_ALLOC(h->d_indices, nnz);
@@ -1517,22 +1531,24 @@ int tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols, const int64_t*
     TSEM_HIP(hipMemcpy(h->d_raw, raw, sizeof(uint16_t) * nnz, hipMemcpyHostToDevice));
   }
   // The host arrays are checked on the DEVICE, after the copy (the host loop of round 1 over the entries took twice as
-  // long as the copy itself: 97 of 142 ms at 4e8 entries): row pointers non-decreasing, column ids in [0, K), scores
-  // inside the table.
-  uint32_t* d_bad = nullptr;
-  TSEM_ALLOC(d_bad, 1);
-  TSEM_HIP(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), h->stream));
+  // long as the copy itself: 97 of 142 ms at 4e8 entries): row pointers non-decreasing, column ids in [0, K) and strictly
+  // increasing inside a row (canonical CSR: z, masks and the tie order of `choose` are aligned to it), scores inside the table.
+  uint32_t* d_bad = nullptr;                                  // [0] flags, [2..3] 64-bit count (see k_check_csr)
+  TSEM_ALLOC(d_bad, 4);
+  TSEM_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(uint32_t), h->stream));
   k_check_csr<<<2048, 256, 0, h->stream>>>(n_rows, n_cols, lut_len, h->d_indptr, h->d_indices, h->d_raw, d_bad);
-  uint32_t bad = 0;
-  TSEM_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  uint32_t badw[4] = {0, 0, 0, 0};
+  TSEM_HIP(hipMemcpyAsync(badw, d_bad, sizeof(badw), hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
+  uint32_t bad = badw[0] | ((badw[2] | badw[3]) && !(badw[0] & 1u) ? 8u : 0u);
   (void)hipFree(d_bad);
   if (bad) {
     free_matrix(h);
     h->N = 0; h->nnz = 0;
     if (bad & 1u) TSEM_FAIL(TSEM_ERR_ARG, "indptr must be non-decreasing");
     if (bad & 2u) TSEM_FAIL(TSEM_ERR_ARG, "column index out of range");
-    TSEM_FAIL(TSEM_ERR_ARG, "raw score exceeds lookup table");
+    if (bad & 4u) TSEM_FAIL(TSEM_ERR_ARG, "raw score exceeds lookup table");
+    TSEM_FAIL(TSEM_ERR_ARG, "not a canonical CSR: column ids must be strictly increasing inside every row");
   }
   return TSEM_OK;
 }

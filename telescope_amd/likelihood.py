@@ -126,37 +126,55 @@ class TelescopeLikelihood(object):
         (GPU index), `comm` (row-sharded runs, telescope_amd.distributed), `engine_options` — a dict for
         `tsem_set_option`, e.g. {'value_format': 1} for fp64 entries (include/telescope_em.h)."""
         self.comm = comm if comm is not None else _NullComm()
-        raw = sp.csr_matrix(score_matrix)
-        if not raw.has_canonical_format:
+        # (a csr_matrix is taken as it is: re-wrapping one scans its index arrays, 0.8 s at 2e9 entries)
+        raw = score_matrix if isinstance(score_matrix, sp.csr_matrix) else sp.csr_matrix(score_matrix)
+        if engine is not None and not raw.has_canonical_format:      # (a fresh engine checks that on the device, below)
             raw = raw.copy()
             raw.sum_duplicates()
-        if raw.nnz and (raw.data.min() < 0 or raw.data.max() > 65535
-                        or not np.all(raw.data == np.floor(raw.data))):
-            raise ValueError('score matrix must hold integer alignment scores in [0, 65535]')
+        data = raw.data
+        if data.dtype != np.uint16 and raw.nnz:                      # (uint16 — what Telescope.raw_scores holds, model.py:300 — needs no check)
+            if data.min() < 0 or data.max() > 65535 or \
+                    (data.dtype.kind not in 'ui' and not np.all(data == np.floor(data))):
+                raise ValueError('score matrix must hold integer alignment scores in [0, 65535]')
         self.raw_scores = score_matrix
         self._raw = raw
         self.N, self.K = raw.shape                                   # model.py:643
-        local_max = int(raw.data.max()) if raw.nnz else 0
-        self.max_score = self.comm.max_scalar(local_max)             # model.py:640 (global)
         self.scale_factor = 100.                                     # model.py:652
         engine_options = dict(engine_options or {})
         self._mantissa_bits = int(engine_options.pop('lut_mantissa_bits', 53))   # host-side knob, see score_lut
+        if device is None:
+            device = getattr(self.comm, 'device', 0)
+        self._eng = engine if engine is not None else Engine(device)
+        for key, value in engine_options.items():
+            self._eng.set_option(key, int(value))
+        if engine is None:
+            # the matrix goes to the device first and the maximum is taken THERE (k_max_u16, 2 ms at 2e9 entries; numpy
+            # needs 0.3 s, scipy's .max() 4 s); the score table follows once the global maximum is known
+            try:
+                self._eng.load_scores(raw.indptr, raw.indices, data.astype(np.uint16, copy=False), self.K, None)
+            except EngineError as e:
+                if 'canonical' not in str(e):
+                    raise
+                raw = raw.copy()                                     # unsorted or duplicate column ids (the device found
+                raw.sum_duplicates()                                 # them): canonicalise like scipy would, load again
+                if raw.nnz and raw.data.dtype != np.uint16 and raw.data.max() > 65535:
+                    raise ValueError('score matrix must hold integer alignment scores in [0, 65535]')
+                self._raw = raw
+                self._eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16, copy=False), self.K, None)
+            local_max = self._eng.max_score()
+        else:
+            local_max = int(data.max()) if raw.nnz else 0
+        self.max_score = self.comm.max_scalar(local_max)             # model.py:640 (global)
         self._lut = score_lut(self.max_score, self.scale_factor, self._mantissa_bits) if self.max_score > 0 \
             else np.zeros(1)
+        if engine is None:
+            self._eng.set_lut(self._lut)
 
         self.epsilon = opts.em_epsilon                               # model.py:661-662
         self.max_iter = opts.max_iter
         self.pi_prior = opts.pi_prior                                # model.py:686-687
         self.theta_prior = opts.theta_prior
 
-        if device is None:
-            device = getattr(self.comm, 'device', 0)
-        self._eng = engine if engine is not None else Engine(device)
-        for key, value in (engine_options or {}).items():
-            self._eng.set_option(key, int(value))
-        if engine is None:
-            self._eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16),
-                                  self.K, self._lut)
         self._setup_model()
 
     @classmethod

@@ -536,7 +536,29 @@ def test_load_scores_validates_on_the_device(gpu_device):
             (np.array([0, 3, 2], np.int64), idx, raw, 'non-decreasing'),
             (np.array([0, 2, 3], np.int64), np.array([0, 3, 1], np.int32), raw, 'column index out of range'),
             (np.array([0, 2, 3], np.int64), np.array([0, -1, 1], np.int32), raw, 'column index out of range'),
-            (np.array([0, 2, 3], np.int64), idx, np.array([150, 301, 300], np.uint16), 'exceeds lookup table')):
+            (np.array([0, 2, 3], np.int64), idx, np.array([150, 301, 300], np.uint16), 'exceeds lookup table'),
+            (np.array([0, 2, 3], np.int64), np.array([2, 0, 1], np.int32), raw, 'canonical'),
+            (np.array([0, 2, 3], np.int64), np.array([2, 2, 1], np.int32), raw, 'canonical')):
         with pytest.raises(EngineError, match=msg):
             eng.load_scores(bad_ptr, bad_idx, bad_raw, 3, lut)
     eng.load_scores(indptr, idx, raw, 3, lut)               # the handle is usable afterwards
+
+
+def test_constructor_canonicalises_what_the_device_rejects(gpu_device):
+    """A matrix with unsorted column ids (or duplicates) is found by the device-side check of tsem_load_scores; the
+    constructor then canonicalises it like `csr_matrix.sum_duplicates` and the run equals the canonical matrix's."""
+    c = load_case('bundled')
+    m = case_matrix(c)
+    rng = np.random.default_rng(3)
+    data, idx = m.data.copy(), m.indices.copy()
+    for i in range(m.shape[0]):                                # shuffle every row's entries
+        a, b = m.indptr[i], m.indptr[i + 1]
+        p = rng.permutation(b - a)
+        data[a:b], idx[a:b] = data[a:b][p], idx[a:b][p]
+    shuffled = sp.csr_matrix((data, idx, m.indptr.copy()), shape=m.shape)
+    assert not shuffled.has_sorted_indices
+    from telescope_amd.likelihood import TelescopeLikelihood
+    t1, t2 = TelescopeLikelihood(m, Opts(c)), TelescopeLikelihood(shuffled, Opts(c))
+    t1.em(); t2.em()
+    assert np.isclose(t1.lnl, t2.lnl, rtol=1e-13, atol=0) and np.allclose(t1.pi, t2.pi, rtol=1e-11, atol=0)   # (LDS atomics: summation order)
+    assert np.array_equal(t1.reassign('exclude').sum(0).A1, t2.reassign('exclude').sum(0).A1)
