@@ -329,6 +329,12 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     // runs behind) delays the next issue behind the burst, whose values then come late, and so on for the rest of
     // the pass.  Same-step is robust, needs half the registers, and the two steps between publish and load make
     // a miss rarer (profiles/r02_ab_exchange.txt).
+    // Tried once more at the end of round 2 with UNTRACKED loads (inline-asm buffer loads the compiler keeps no
+    // score-board entry for, one explicit `s_waitcnt vmcnt(n)`, two generations, loads a step ahead of their combine):
+    // the exchange wave is then done long before the data waves, and the pass is no faster (codes 3.55 = 3.55 ms, fp64
+    // entries 4.21 against 4.08 ms on the same box; three times the tag misses with one step between publish and
+    // load) — the step is not waiting for the exchange.  (Lesson kept: asm VMEM needs `s_nop 4` in front — the hazard
+    // recognizer does not see it, and a descriptor SGPR restored by v_readlane was read too early.)
     // publish y(i-1): tagged granules, 16-byte stores (a tear between halves is harmless).  PLAIN
     // stores: the line stays in the XCD's L2, where the partners' sc1 loads find it (a write-through
     // sc1 store drops it from L2: measured 14 M tag misses per pass vs 0.14 M)
