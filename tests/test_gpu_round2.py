@@ -387,12 +387,15 @@ def test_integer_outputs_identical_across_runs(gpu_device):
         tl = _tl_for(raw, Opts(c))
         tl.em()
         np.random.seed(1)
-        runs.append((tl.n_iter, [tl.reassign_colsums(m) for m in ('exclude', 'choose', 'unique', 'all')], tl.pi.copy()))
+        runs.append((tl.n_iter, [tl.reassign_colsums(m) for m in ('exclude', 'choose', 'unique', 'all')], tl.pi.copy(),
+                     [tl.reassign_colsums(m) for m in ('average', 'conf')]))
     for r in runs[1:]:
         assert r[0] == runs[0][0]
         for a, b in zip(r[1], runs[0][1]):
             assert np.array_equal(a, b)
         assert np.allclose(r[2], runs[0][2], rtol=1e-12, atol=0)
+        for a, b in zip(r[3], runs[0][3]):                       # float-valued modes: unordered fp64 atomics, documented
+            assert np.allclose(a, b, rtol=1e-12, atol=1e-9)      # tolerance
     big = []
     for _ in range(2):
         tl = _synthetic_tl(5_000_000, 30000, 40, 'zipf', uniq=0.05, opts=Opts(max_iter=10, em_epsilon=0.0))
