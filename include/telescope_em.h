@@ -227,6 +227,17 @@ int  tsem_best_ties(tsem_ctx* h, int which, int64_t cap, int32_t* rows, int32_t*
  * NULL to skip).  `picks[i]` (choose only) = ordinal of the chosen best hit. */
 int  tsem_reassign(tsem_ctx* h, int method, double thresh, int which,
                    const int32_t* picks, double* colsums, double* mask);
+/* The column sums `Telescope.output_report` takes from ONE z (model.py:432-457) in ONE pass over the rows:
+ * out[0..K) = reassign('conf', thresh).sum(0), out[K..2K) = 'exclude', out[2K..3K) = 'average' (local rows).  The
+ * rows with several best hits — the only rows `choose` treats differently from `exclude` (sparse_plus.py:140-154) —
+ * are compacted on the device in row order: *n_ties of them; tsem_report_ties copies their indices and numbers of
+ * best hits out (cap >= n_ties), and tsem_reassign_rows(TSEM_RA_CHOOSE, ..., rows = NULL, picks, n_ties, out) adds up
+ * the picked entries of exactly those rows, so that  choose = exclude + that.  tsem_reassign_rows with a caller's
+ * row list gives the contribution of those rows to any method (picks[i] belongs to rows[i]). */
+int  tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out /* 3*K */, int64_t* n_ties);
+int  tsem_report_ties(tsem_ctx* h, int64_t cap, int32_t* rows, int32_t* counts);
+int  tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const int32_t* rows,
+                        const int32_t* picks, int64_t n, double* colsums);
 /* the same assignment summed per GROUP of rows: scTelescope.output_report's per-barcode count matrix
  * `_assignments[_rows, :].sum(0)` for every barcode (model.py:611-625).  group_of_row[i] in
  * [0, n_groups) or -1 (row in no group); out is row-major [n_groups][K], caller-allocated. */

@@ -121,6 +121,9 @@ def lib():
     L.tsem_calc_lnl.argtypes = [vp, vp, vp, vp, C.POINTER(dbl)]
     L.tsem_best_counts.argtypes = [vp, C.c_int, vp]
     L.tsem_best_ties.argtypes = [vp, C.c_int, i64, vp, vp, C.POINTER(i64)]
+    L.tsem_report_colsums.argtypes = [vp, C.c_int, C.c_double, vp, C.POINTER(i64)]
+    L.tsem_report_ties.argtypes = [vp, i64, vp, vp]
+    L.tsem_reassign_rows.argtypes = [vp, C.c_int, C.c_double, C.c_int, vp, vp, i64, vp]
     L.tsem_reassign.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, vp]
     L.tsem_reassign_groups.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, C.c_int32, vp]
     L.tsem_csr_norm_rows.argtypes = [C.c_int, i64, vp, vp, vp]
@@ -378,6 +381,28 @@ class Engine(object):
                 cap = int(n.value)
                 continue
             self._ck(rc)
+
+    def report_colsums(self, which, thresh):
+        """One pass: {'conf', 'exclude', 'average'} column sums of z(`which`) and the tied rows (rows, counts) in row order."""
+        _, k, _ = self.dims()
+        out = np.empty(3 * k)
+        n = C.c_int64()
+        self._ck(self._L.tsem_report_colsums(self._h, which, float(thresh), ptr(out), C.byref(n)))
+        rows, counts = np.empty(n.value, np.int32), np.empty(n.value, np.int32)
+        self._ck(self._L.tsem_report_ties(self._h, n.value, ptr(rows), ptr(counts)))
+        return {'conf': out[:k], 'exclude': out[k:2 * k], 'average': out[2 * k:]}, rows, counts
+
+    def reassign_rows(self, method, thresh, which, rows, picks, n=None):
+        """Column sums of reassign(method) restricted to a list of rows (rows=None: the tie rows of the last report)."""
+        _, k, _ = self.dims()
+        cs = np.empty(k)
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, dtype=np.int32); n = len(rows)
+        pk = np.ascontiguousarray(picks, dtype=np.int32) if picks is not None else None
+        self._ck(self._L.tsem_reassign_rows(self._h, RA_CODE[method], float(thresh), which,
+                                            ptr(rows) if rows is not None else None,
+                                            ptr(pk) if pk is not None else None, int(n), ptr(cs)))
+        return cs
 
     def reassign(self, method, thresh, which, picks=None, want_mask=False):
         n, k, nnz = self.dims()

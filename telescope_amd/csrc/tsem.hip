@@ -924,7 +924,7 @@ static_assert(FZ_SYNC_WORDS == 16, "k_update clears 16 sync words");
 // ============================================================================
 // CSR row passes: z export, best-hit counts, reassign (model.py:808-865)
 // ============================================================================
-enum { RP_EXPORT_Z = 0, RP_BEST = 1, RP_REASSIGN = 2 };
+enum { RP_EXPORT_Z = 0, RP_BEST = 1, RP_REASSIGN = 2, RP_REPORT = 3 };
 constexpr int RP_SUB = 16;
 
 struct RowPassArgs {
@@ -946,6 +946,8 @@ struct RowPassArgs {
   int32_t* nbest;
   double* colsums;
   const int32_t* group;  // REASSIGN: optional row -> group map; colsums is then [n_groups][K]
+  const int32_t* rowlist; int64_t nlist;   // REASSIGN: optional list of rows to visit (picks[] is then indexed by list position)
+  // REPORT: conf, exclude and average in ONE pass -> colsums[0..K), [K..2K), [2K..3K); best-hit counts -> nbest
   // REASSIGN without groups: the Hs most popular slots of every column part are summed in LDS per
   // workgroup and flushed once (global fp64 atomics: 22 G/s, 2 G/s on a popular column)
   const uint32_t* colmap; const int32_t* col_of_pc; int P, Kp, Hs;
@@ -961,15 +963,23 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
   double* const hot = rp_lds + A.lut_len;
   const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
   const bool initial = (A.pi == nullptr);
-  const int nhot = MODE == RP_REASSIGN ? A.P * A.Hs : 0;
+  const int nhot1 = (MODE == RP_REASSIGN || MODE == RP_REPORT) ? A.P * A.Hs : 0;
+  const int nhot = MODE == RP_REPORT ? 3 * nhot1 : nhot1;
   // The pass is bound by vector-memory INSTRUCTIONS (every gather touches 64 cache lines): the score table
   // comes from LDS and pi*theta from one precomputed table, 3 instead of 5 vector-memory instructions per round
   for (int t = threadIdx.x; t < A.lut_len; t += blockDim.x) lutS[t] = A.lut[t];
   for (int t = threadIdx.x; t < nhot; t += blockDim.x) hot[t] = 0.0;
   __syncthreads();
-  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < A.N; row += (int64_t)gridDim.x * subs) {
+  const int64_t n_visit = (MODE == RP_REASSIGN && A.rowlist) ? A.nlist : A.N;
+  for (int64_t idx = (int64_t)blockIdx.x * subs + sub; idx < n_visit; idx += (int64_t)gridDim.x * subs) {
+    const int64_t row = (MODE == RP_REASSIGN && A.rowlist) ? (int64_t)A.rowlist[idx] : idx;
     const int64_t s = A.indptr[row], e = A.indptr[row + 1];
     const bool amb = (e - s) > 1;
+    // one value of report column m (0 for a plain reassign) for column `col`: popular columns in LDS, the rest global
+    auto emit = [&](int m, int col, uint32_t cm, double val, int64_t grp_off) {
+      if (nhot1 && (int)(cm & 0x1FFFu) < A.Hs) lds_add(&hot[m * nhot1 + (cm >> 16) * A.Hs + (cm & 0x1FFFu)], val);
+      else unsafeAtomicAdd(&A.colsums[(int64_t)m * A.K + grp_off + col], val);
+    };
     auto numer = [&](int64_t k) -> double {
       if (A.zin) return A.zin[k];
       double q = A.lut_len ? lutS[A.raw[k]] : A.lut[A.raw[k]];
@@ -1012,12 +1022,29 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
         continue;
       }
       double vsum = 0.0;
-      if (method == TSEM_RA_CONF) {
+      if (method == TSEM_RA_CONF || MODE == RP_REPORT) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (inp[i] && n[i] * r >= A.thresh) vsum += n[i] * r;
         vsum = sg_sum<RP_SUB>(vsum);
       }
-      const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[row] : 0;
+      if (MODE == RP_REPORT) {                              // conf | exclude | average of model.py:839-856 from one set of numerators
+        if (lane == 0 && A.nbest) A.nbest[row] = cnt ? nb : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double z = n[i] * r;
+          const bool best = inp[i] && (z == zmax);
+          const double vc = (inp[i] && z >= A.thresh) ? z * recip0(vsum) : 0.0;
+          if (vld[i] && (best || vc != 0.0)) {
+            const int col = A.indices[s + lane + i * RP_SUB];
+            const uint32_t cm = nhot1 ? A.colmap[col] : 0xFFFFFFFFu;
+            if (vc != 0.0) emit(0, col, cm, vc, 0);
+            if (best && nb == 1) emit(1, col, cm, 1.0, 0);
+            if (best) emit(2, col, cm, 1.0 * recip0((double)nb), 0);
+          }
+        }
+        continue;
+      }
+      const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[A.rowlist ? idx : row] : 0;
       const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
       int base = 0;
 #pragma unroll
@@ -1042,10 +1069,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
           if (A.zout) A.zout[k] = val;
           if (val != 0.0 && grp_off >= 0) {
             const int col = A.indices[k];
-            uint32_t cm = 0xFFFFFFFFu;
-            if (nhot) cm = A.colmap[col];
-            if (nhot && (int)(cm & 0x1FFFu) < A.Hs) lds_add(&hot[(cm >> 16) * A.Hs + (cm & 0x1FFFu)], val);
-            else unsafeAtomicAdd(&A.colsums[grp_off + col], val);
+            emit(0, col, nhot1 ? A.colmap[col] : 0xFFFFFFFFu, val, grp_off);
           }
         }
       }
@@ -1088,7 +1112,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
     }
     // ---- reassign ----
     double vsum = 0.0;
-    if (method == TSEM_RA_CONF) {
+    if (method == TSEM_RA_CONF || MODE == RP_REPORT) {
       for (int64_t k = s + lane; k < e; k += RP_SUB) {
         double n = numer(k);
         double z = n * r;
@@ -1096,7 +1120,25 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       }
       vsum = sg_sum<RP_SUB>(vsum);
     }
-    const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[row] : 0;
+    if (MODE == RP_REPORT) {
+      if (lane == 0 && A.nbest) A.nbest[row] = cnt ? nb : 0;
+      for (int64_t k = s + lane; k < e; k += RP_SUB) {
+        const double n = numer(k);
+        const bool inpat = A.zin ? !isnan(n) : (initial || n != 0.0);
+        const double z = n * r;
+        const bool best = inpat && (z == zmax);
+        const double vc = (inpat && z >= A.thresh) ? z * recip0(vsum) : 0.0;
+        if (best || vc != 0.0) {
+          const int col = A.indices[k];
+          const uint32_t cm = nhot1 ? A.colmap[col] : 0xFFFFFFFFu;
+          if (vc != 0.0) emit(0, col, cm, vc, 0);
+          if (best && nb == 1) emit(1, col, cm, 1.0, 0);
+          if (best) emit(2, col, cm, 1.0 * recip0((double)nb), 0);
+        }
+      }
+      continue;
+    }
+    const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[A.rowlist ? idx : row] : 0;
     const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
     int base = 0;
     for (int64_t k0 = s; k0 < e; k0 += RP_SUB) {
@@ -1123,10 +1165,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
         if (A.zout) A.zout[k] = val;
         if (val != 0.0 && grp_off >= 0) {
           const int col = A.indices[k];
-          uint32_t cm = 0xFFFFFFFFu;
-          if (nhot) cm = A.colmap[col];
-          if (nhot && (int)(cm & 0x1FFFu) < A.Hs) lds_add(&hot[(cm >> 16) * A.Hs + (cm & 0x1FFFu)], val);
-          else unsafeAtomicAdd(&A.colsums[grp_off + col], val);
+          emit(0, col, nhot1 ? A.colmap[col] : 0xFFFFFFFFu, val, grp_off);
         }
       }
     }
@@ -1135,7 +1174,8 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
     __syncthreads();
     for (int t = threadIdx.x; t < nhot; t += blockDim.x) {
       const double v = hot[t];
-      if (v != 0.0) unsafeAtomicAdd(&A.colsums[A.col_of_pc[(t / A.Hs) * A.Kp + t % A.Hs]], v);
+      const int m = t / nhot1, tt = t % nhot1;
+      if (v != 0.0) unsafeAtomicAdd(&A.colsums[(int64_t)m * A.K + A.col_of_pc[(tt / A.Hs) * A.Kp + tt % A.Hs]], v);
     }
   }
 }
@@ -1378,6 +1418,7 @@ static void free_matrix(tsem_ctx* h) {
   dfree(h->d_ctab); dfree(h->d_ctab_prev); dfree(h->d_red_own); dfree(h->d_tmp_pi); dfree(h->d_tmp_theta);
   dfree(h->d_c32); dfree(h->d_cs32); dfree(h->d_lut32); dfree(h->d_cnat);
   dfree(h->d_ctl); dfree(h->d_ctld); dfree(h->d_lnls); dfree(h->d_pi_first); dfree(h->d_theta_first); dfree(h->d_user_z);
+  dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;
   h->first_pending = false;
   h->d_red = nullptr;
   h->have_rowstats = h->have_model = false;
@@ -2634,7 +2675,7 @@ static int make_cnat(tsem_ctx* h, RowPassArgs& A) {
 
 static int rowpass_args(tsem_ctx* h, int which, RowPassArgs& A) {
   A.N = h->N; A.K = h->K; A.indptr = h->d_indptr; A.indices = h->d_indices; A.raw = h->d_raw; A.lut = h->d_lut;
-  A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr; A.group = nullptr; A.colmap = nullptr; A.col_of_pc = nullptr; A.P = 0; A.Kp = 0; A.Hs = 0;
+  A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr; A.group = nullptr; A.rowlist = nullptr; A.nlist = 0; A.colmap = nullptr; A.col_of_pc = nullptr; A.P = 0; A.Kp = 0; A.Hs = 0;
   A.zin = nullptr; A.cnat = nullptr; A.lut_len = h->lut_len <= 2048 ? h->lut_len : 0;   // (larger tables stay in global memory)
   if (which == TSEM_Z_USER) {
     if (!h->d_user_z) TSEM_FAIL(TSEM_ERR_ARG, "TSEM_Z_USER without tsem_set_user_z");
@@ -2829,6 +2870,115 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
   TSEM_HIP(hipStreamSynchronize(h->stream));
   (void)hipFree(d_cs);
   if (d_mask) (void)hipFree(d_mask);
+  if (d_picks) (void)hipFree(d_picks);
+  return TSEM_OK;
+}
+
+// One pass for the column sums output_report takes from one z (model.py:432-457): conf | exclude | average, and the rows
+// with several best hits (the only rows `choose` treats differently from `exclude`) compacted in row order.
+int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, int64_t* n_ties) {
+  if (!h || !h->d_indptr || !out3K) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;
+  if (n_ties) *n_ties = 0;
+  const int K = h->K;
+  double* d_cs = nullptr;
+  int32_t *d_nb = nullptr, *d_rows = nullptr;
+  unsigned long long* d_n = nullptr;
+  TSEM_ALLOC(d_cs, 3 * (int64_t)K);
+  TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * 3 * K, h->stream));
+  if (h->N) {
+    TSEM_ALLOC(d_nb, h->N); TSEM_ALLOC(d_rows, h->N); TSEM_ALLOC(d_n, 1);
+    A.thresh = thresh; A.colsums = d_cs; A.nbest = d_nb;
+    void (*kern)(RowPassArgs) = k_rowpass<RP_REPORT>;
+    if (h->d_colmap && h->d_col_of_pc && h->P > 0) {
+      const int wgs = h->opt_rowpass_wgs < 2 ? 1 : 2;
+      A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;
+      A.Hs = std::max(0, std::min(h->Kp, (int)((TS_LDS_MAX / wgs - 8192 / wgs - 1024 - A.lut_len * 8) / 8 / h->P / 3)));
+      TSEM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      kern<<<h->n_cu * wgs, 1024, (size_t)(3 * A.P * A.Hs + A.lut_len) * 8, h->stream>>>(A);
+    } else {
+      kern<<<rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+    }
+    TSEM_HIP(hipGetLastError());
+    size_t tb = 0;
+    TiedRow pred{d_nb};
+    rocprim::counting_iterator<int32_t> first(0);
+    TSEM_HIP(rocprim::select(nullptr, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
+    void* tmp = nullptr;
+    TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+    TSEM_HIP(rocprim::select(tmp, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
+    unsigned long long n = 0;
+    TSEM_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(out3K, d_cs, sizeof(double) * 3 * K, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(tmp);
+    if (n) {
+      TSEM_ALLOC(h->d_tie_rows, n); TSEM_ALLOC(h->d_tie_cnt, n);
+      TSEM_HIP(hipMemcpyAsync(h->d_tie_rows, d_rows, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, h->stream));
+      k_gather_i32<<<cdiv64((int64_t)n, 256), 256, 0, h->stream>>>((int64_t)n, d_rows, d_nb, h->d_tie_cnt);
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+    }
+    h->n_ties = (int64_t)n;
+    if (n_ties) *n_ties = (int64_t)n;
+    (void)hipFree(d_nb); (void)hipFree(d_rows); (void)hipFree(d_n);
+  } else {
+    for (int64_t j = 0; j < 3 * (int64_t)K; ++j) out3K[j] = 0.0;
+  }
+  (void)hipFree(d_cs);
+  return TSEM_OK;
+}
+
+int tsem_report_ties(tsem_ctx* h, int64_t cap, int32_t* rows, int32_t* counts) {
+  if (!h || cap < 0) return TSEM_ERR_ARG;
+  if (h->n_ties > cap) TSEM_FAIL(TSEM_ERR_ARG, "tsem_report_ties: the arrays are shorter than the tie count of the last tsem_report_colsums");
+  if (h->n_ties == 0) return TSEM_OK;
+  if (!rows || !counts) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipMemcpyAsync(rows, h->d_tie_rows, sizeof(int32_t) * h->n_ties, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipMemcpyAsync(counts, h->d_tie_cnt, sizeof(int32_t) * h->n_ties, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return TSEM_OK;
+}
+
+// The contribution of a LIST of rows to reassign(method).sum(0): `choose` = `exclude` + the picked entries of the tied
+// rows (rows == NULL: the tie rows the last tsem_report_colsums left on the device; picks[i] belongs to list entry i).
+int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const int32_t* rows, const int32_t* picks,
+                       int64_t n, double* colsums) {
+  if (!h || !h->d_indptr || !colsums || n < 0) return TSEM_ERR_ARG;
+  if (method < TSEM_RA_EXCLUDE || method > TSEM_RA_ALL) TSEM_FAIL(TSEM_ERR_ARG, "bad reassign method");
+  if (!rows && n != h->n_ties) TSEM_FAIL(TSEM_ERR_ARG, "tsem_reassign_rows: rows == NULL needs n == the tie count of the last report");
+  if (int rc = ensure_device(h)) return rc;
+  for (int j = 0; j < h->K; ++j) colsums[j] = 0.0;
+  if (n == 0) return TSEM_OK;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  if (rows)
+    for (int64_t i = 0; i < n; ++i)
+      if (rows[i] < 0 || rows[i] >= h->N) TSEM_FAIL(TSEM_ERR_ARG, "tsem_reassign_rows: row out of range");
+  double* d_cs = nullptr;
+  int32_t *d_rows = nullptr, *d_picks = nullptr;
+  TSEM_ALLOC(d_cs, h->K);
+  TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
+  if (rows) {
+    TSEM_ALLOC(d_rows, n);
+    TSEM_HIP(hipMemcpyAsync(d_rows, rows, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  }
+  if (method == TSEM_RA_CHOOSE && picks) {
+    TSEM_ALLOC(d_picks, n);
+    TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  }
+  A.method = method; A.thresh = thresh; A.colsums = d_cs; A.picks = d_picks;
+  A.rowlist = rows ? d_rows : h->d_tie_rows; A.nlist = n;
+  const int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + 15) / 16));
+  k_rowpass<RP_REASSIGN><<<grid, 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_cs);
+  if (d_rows) (void)hipFree(d_rows);
   if (d_picks) (void)hipFree(d_picks);
   return TSEM_OK;
 }

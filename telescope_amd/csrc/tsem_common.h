@@ -138,6 +138,9 @@ struct tsem_ctx {
   double *d_pi = nullptr, *d_theta = nullptr, *d_pi_prev = nullptr, *d_theta_prev = nullptr;
   double *d_ctab = nullptr, *d_ctab_prev = nullptr;  // [Kpad] permuted pi*theta
   double* d_user_z = nullptr;       // [nnz] caller-assigned z (TSEM_Z_USER), NaN = not in z's pattern
+  int32_t* d_tie_rows = nullptr;    // rows with several best hits, in row order, and their counts: left by the last
+  int32_t* d_tie_cnt = nullptr;     // tsem_report_colsums for tsem_report_ties / tsem_reassign_rows
+  int64_t n_ties = 0;
   double* d_red = nullptr;          // reduce buffer (K+2), internal or bound
   double* d_red_own = nullptr;
   int64_t red_count = 0;

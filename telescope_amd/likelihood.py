@@ -97,12 +97,7 @@ class Assignment(object):
     def sum(self, axis=None, **kw):
         if axis in (0, -2) and not kw and self._mat is None:
             if self._colsum is None:
-                method, thresh, which, picks = self._args
-                cs, _ = self._tl._eng.reassign(method, thresh, which, picks)
-                cs = self._tl.comm.sum_array(cs)
-                if _MASK_DTYPE[method] != np.float64:
-                    cs = np.rint(cs).astype(np.int64)
-                self._colsum = cs
+                self._colsum = self._tl._colsums(*self._args)      # (picks: the tied rows only, sparse)
             return np.asarray(self._colsum).reshape(1, -1).view(np.matrix)   # scipy returns a 1 x K np.matrix: `.A1` works
         return self.tocsr().sum(axis, **kw)
 
@@ -215,6 +210,7 @@ class TelescopeLikelihood(object):
         self.lnl = float('inf')                                      # model.py:683
         self._z = None
         self._z_which = None
+        self._report_cache = {}
         self.n_iter, self.converged = 0, False
 
     # ---- lazily materialised compat attributes --------------------------------
@@ -242,6 +238,7 @@ class TelescopeLikelihood(object):
         """A caller-assigned z (the reference's `reassign` reads whatever `self.z` holds, model.py:837)."""
         self._z, self._z_which = value, None
         self._user_z_loaded = False
+        self._report_cache = {}
 
     def _need_raw(self):
         if self._raw is None:
@@ -362,6 +359,7 @@ class TelescopeLikelihood(object):
             self.pi_init, self.theta_init = eng.get_params(Z_FIRST)
         self.pi, self.theta = eng.get_params(Z_CUR)
         self._z, self._z_which = None, Z_PREV   # z of the last E-step, exported on demand
+        self._report_cache = {}
         _con = 'converged' if converged else 'terminated'
         if not use_likelihood:
             self.lnl = eng.final_lnl() if chunked else self._device_lnl()
@@ -389,17 +387,28 @@ class TelescopeLikelihood(object):
             return Z_USER
         return self._z_which
 
-    def _picks(self, which):
-        """Random picks for `choose`, drawn exactly like sparse_plus.py:140-154:
-        one draw per row with >1 best hits, in (global) row order, on numpy's
-        legacy global RandomState (seeded by the caller, telescope_assign.py:429-431)."""
-        eng = self._eng
-        if hasattr(eng, 'best_ties'):                         # compacted on the device: only the tied rows travel
-            rows, counts = eng.best_ties(which)
-        else:                                                 # (tests-only oracle engine)
-            nbest = eng.best_counts(which)
-            rows = np.flatnonzero(nbest > 1).astype(np.int32)
-            counts = nbest[rows]
+    def _report(self, which, thresh):
+        """The column sums `output_report` takes from one z (model.py:432-457) — conf, exclude, average — and the rows
+        with several best hits, from ONE device pass, kept until z changes (`em()`, `tl.z = ...`): the reference's
+        report asks for three modes of the initial z and two of the final one, one after the other."""
+        key = (which, float(thresh))
+        cache = self.__dict__.setdefault('_report_cache', {})
+        if key not in cache:
+            other = [k for k in cache if k[0] == which]
+            sums, rows, counts = self._eng.report_colsums(which, thresh)
+            flat = self.comm.sum_array(np.concatenate([sums['conf'], sums['exclude'], sums['average']]))
+            K = self.K
+            rep = {'conf': flat[:K], 'exclude': np.rint(flat[K:2 * K]).astype(np.int64), 'average': flat[2 * K:],
+                   'rows': rows, 'counts': counts}
+            for k in other:                                        # same z, other threshold: only `conf` differs
+                del cache[k]
+            cache[key] = rep
+        return cache[key]
+
+    def _draw_picks(self, counts):
+        """Random picks for `choose`, drawn exactly like sparse_plus.py:140-154: one draw per row with >1 best
+        hits, in (global) row order, on numpy's legacy global RandomState (seeded by the caller,
+        telescope_assign.py:429-431).  `counts`: this rank's tied rows' numbers of best hits, in row order."""
         parts = self.comm.gather_rows(counts)                 # rank order == global row order
         if self.comm.rank == 0:
             allc = parts[0] if len(parts) == 1 else np.concatenate(parts)
@@ -407,10 +416,25 @@ class TelescopeLikelihood(object):
             cuts = np.cumsum([len(p) for p in parts])[:-1]
             parts = np.split(np.asarray(draws, dtype=np.int32), cuts)
         mine = self.comm.scatter_rows(parts)
-        if mine is None or len(rows) == 0:                    # no row has a tie: nothing to apply
+        return np.zeros(0, np.int32) if mine is None else np.asarray(mine, dtype=np.int32)
+
+    def _picks(self, which):
+        """(rows, picks) of the tied rows for `choose` (sparse); consumes the caller's RNG stream NOW."""
+        eng = self._eng
+        if hasattr(eng, 'report_colsums'):                    # compacted on the device: only the tied rows travel
+            rep = self._report(which, self._cached_thresh(which, 0.9))
+            rows, counts = rep['rows'], rep['counts']
+        else:                                                 # (tests-only oracle engine)
+            nbest = eng.best_counts(which)
+            rows = np.flatnonzero(nbest > 1).astype(np.int32)
+            counts = nbest[rows]
+        return rows, self._draw_picks(counts)
+
+    def _dense_picks(self, sparse):
+        if sparse is None or len(sparse[0]) == 0:
             return None
         picks = np.zeros(self.N, dtype=np.int32)
-        picks[rows] = mine
+        picks[sparse[0]] = sparse[1]
         return picks
 
     def reassign_colsums(self, method, thresh=0.9, initial=False):
@@ -418,12 +442,30 @@ class TelescopeLikelihood(object):
         if method not in REASSIGN_METHODS:
             raise ValueError('Argument "method" should be one of (exclude, choose, average, conf, unique, all)')
         which = self._which(initial)
-        picks = self._picks(which) if method == 'choose' else None
-        cs, _ = self._eng.reassign(method, thresh, which, picks)
+        return self._colsums(method, thresh, which, self._picks(which) if method == 'choose' else None)
+
+    def _colsums(self, method, thresh, which, sparse_picks):
+        eng = self._eng
+        if hasattr(eng, 'report_colsums') and method in ('conf', 'exclude', 'average', 'choose') \
+                and which != Z_USER:
+            if method == 'choose':                               # = exclude + the picked entries of the tied rows
+                rep = self._report(which, self._cached_thresh(which, 0.9))
+                rows, picks = sparse_picks
+                cs = self.comm.sum_array(eng.reassign_rows('choose', thresh, which, rows, picks))
+                return rep['exclude'] + np.rint(cs).astype(np.int64)
+            rep = self._report(which, thresh if method == 'conf' else self._cached_thresh(which, thresh))
+            return rep[method].copy()
+        cs, _ = eng.reassign(method, thresh, which, self._dense_picks(sparse_picks) if method == 'choose' else None)
         cs = self.comm.sum_array(cs)
         if _MASK_DTYPE[method] != np.float64:
             cs = np.rint(cs).astype(np.int64)
         return cs
+
+    def _cached_thresh(self, which, thresh):
+        for k in self.__dict__.get('_report_cache', {}):
+            if k[0] == which:
+                return k[1]                                       # exclude / average do not depend on it: reuse the pass
+        return thresh
 
     def reassign_group_sums(self, method, group_rows, thresh=0.9, initial=False):
         """Per-group column sums of the assignment matrix: row g of the result is
@@ -456,7 +498,7 @@ class TelescopeLikelihood(object):
                 take = free & first
                 grp[g[take]] = gi
                 rest.append((gi, g[~take]))
-            out += self._eng.reassign_groups(method, thresh, which, grp, len(groups), picks)
+            out += self._eng.reassign_groups(method, thresh, which, grp, len(groups), self._dense_picks(picks))
             pending = rest
         out = self.comm.sum_array(out.ravel()).reshape(out.shape)
         if _MASK_DTYPE[method] != np.float64:
@@ -476,7 +518,7 @@ class TelescopeLikelihood(object):
         return Assignment(self, method, thresh, which, picks)
 
     def _assignment_matrix(self, method, thresh, which, picks):
-        _, mask = self._eng.reassign(method, thresh, which, picks, want_mask=True)
+        _, mask = self._eng.reassign(method, thresh, which, self._dense_picks(picks), want_mask=True)
         r = self._need_raw()
         keep = mask != 0
         rows = np.repeat(np.arange(self.N), np.diff(r.indptr))[keep]

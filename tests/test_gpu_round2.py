@@ -565,3 +565,62 @@ def test_constructor_canonicalises_what_the_device_rejects(gpu_device):
     t1.em(); t2.em()
     assert np.isclose(t1.lnl, t2.lnl, rtol=1e-13, atol=0) and np.allclose(t1.pi, t2.pi, rtol=1e-11, atol=0)   # (LDS atomics: summation order)
     assert np.array_equal(t1.reassign('exclude').sum(0).A1, t2.reassign('exclude').sum(0).A1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# one pass for the report's column sums (tsem_report_colsums / tsem_reassign_rows)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['bundled', 'tiny_ties', 'mid_zipf_20k'])
+def test_report_pass_equals_the_single_mode_passes(gpu_device, name):
+    """conf | exclude | average from ONE pass, and choose = exclude + the picked entries of the tied rows, equal what
+    the one-mode-per-pass kernels give (which the golden tests pin against the reference), for the final and the
+    initial z; the tie list equals best_ties."""
+    from telescope_amd._lib import Z_INITIAL, Z_PREV
+    c = load_case(name)
+    tl = _tl_for(case_matrix(c), Opts(c))
+    tl.em()
+    eng = tl._eng
+    for which in (Z_PREV, Z_INITIAL):
+        for thresh in (0.9, 0.3):
+            sums, rows, counts = eng.report_colsums(which, thresh)
+            for m in ('conf', 'exclude', 'average'):
+                want, _ = eng.reassign(m, thresh, which)
+                if m == 'exclude':
+                    assert np.array_equal(sums[m], want)
+                else:
+                    assert np.allclose(sums[m], want, rtol=1e-12, atol=1e-12)
+            r2, c2 = eng.best_ties(which)
+            assert np.array_equal(rows, r2) and np.array_equal(counts, c2)
+            rng = np.random.default_rng(7)
+            picks = (rng.integers(0, 1 << 30, len(rows)) % np.maximum(counts, 1)).astype(np.int32)
+            dense = np.zeros(tl.N, np.int32); dense[rows] = picks
+            want, _ = eng.reassign('choose', thresh, which, dense)
+            got = sums['exclude'] + eng.reassign_rows('choose', thresh, which, rows, picks)
+            assert np.array_equal(got, want)
+            got2 = sums['exclude'] + eng.reassign_rows('choose', thresh, which, None, picks, n=len(rows))   # rows left on the device
+            assert np.array_equal(got2, want)
+
+
+def test_report_order_consumes_the_rng_like_the_reference(gpu_device):
+    """output_report's sequence (model.py:432-457) through the cached report passes gives the same columns as
+    uncached single-mode calls with the same RNG seed; em() and `tl.z = ...` drop the cache."""
+    c = load_case('mid_zipf_20k')
+    raw = case_matrix(c)
+    seq = (('conf', False), ('all', True), ('unique', False), ('exclude', True), ('choose', True), ('average', True), ('exclude', False),
+           ('choose', False), ('average', False))
+    tl = _tl_for(raw, Opts(c)); tl.em()
+    np.random.seed(11)
+    got = [tl.reassign(m, 0.9, init).sum(0).A1 for m, init in seq]
+    assert len(tl._report_cache) == 2                                    # one pass per z
+    tl2 = _tl_for(raw, Opts(c)); tl2.em()
+    np.random.seed(11)
+    for (m, init), g in zip(seq, got):
+        which = tl2._which(init)
+        sp_picks = tl2._picks(which) if m == 'choose' else None
+        want, _ = tl2._eng.reassign(m, 0.9, which, tl2._dense_picks(sp_picks))
+        if m in ('conf', 'average'):
+            assert np.allclose(g, want, rtol=1e-12, atol=1e-12)
+        else:
+            assert np.array_equal(g, np.rint(want).astype(np.int64))
+    tl.em()
+    assert tl._report_cache == {}
