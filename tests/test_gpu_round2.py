@@ -624,3 +624,48 @@ def test_report_order_consumes_the_rng_like_the_reference(gpu_device):
             assert np.array_equal(g, np.rint(want).astype(np.int64))
     tl.em()
     assert tl._report_cache == {}
+
+
+def _check_report(tl, whiches, threshes=(0.9,)):
+    eng = tl._eng
+    for which in whiches:
+        for thresh in threshes:
+            sums, rows, counts = eng.report_colsums(which, thresh)
+            for m in ('conf', 'exclude', 'average'):
+                want, _ = eng.reassign(m, thresh, which)
+                assert np.allclose(sums[m], want, rtol=1e-12, atol=1e-12), (which, thresh, m)
+            r2, c2 = eng.best_ties(which)
+            assert np.array_equal(rows, r2) and np.array_equal(counts, c2)
+            picks = (np.arange(len(rows)) % np.maximum(counts, 1)).astype(np.int32)
+            dense = np.zeros(tl.N, np.int32); dense[rows] = picks
+            want, _ = eng.reassign('choose', thresh, which, dense)
+            assert np.array_equal(sums['exclude'] + eng.reassign_rows('choose', thresh, which, rows, picks), want)
+
+
+def test_report_pass_on_the_layouts_the_row_pass_branches_on(gpu_device):
+    """RP_REPORT on: rows of hundreds of entries (the sweep path of the row pass), more than eight column parts (the
+    two-pass layout), and a caller-assigned z (TSEM_Z_USER)."""
+    from telescope_amd._lib import Z_INITIAL, Z_PREV, Z_USER
+    from telescope_amd.likelihood import TelescopeLikelihood
+    rng = np.random.RandomState(15)
+    n, k = 5000, 7000
+    lens = np.where(rng.rand(n) < 0.05, rng.randint(100, 600, n), rng.randint(1, 12, n))
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.randint(139, 160, indptr[-1]).astype(np.uint16)            # few score levels: many ties
+    raw = sp.csr_matrix((data, indices, indptr), shape=(n, k))
+    tl = TelescopeLikelihood(raw, Opts(max_iter=6, em_epsilon=0.0)); tl.em()
+    _check_report(tl, (Z_PREV, Z_INITIAL), (0.9, 0.2))
+    z = tl.z.copy(); z.data[::7] = 0.0; z.eliminate_zeros()               # a caller's z with a different pattern, used as is
+    tl.z = z
+    assert tl._which(False) == Z_USER
+    _check_report(tl, (Z_USER,))
+    np.random.seed(3)
+    a = tl.reassign('choose').sum(0).A1
+    np.random.seed(3)
+    want, _ = tl._eng.reassign('choose', 0.9, Z_USER, tl._dense_picks(tl._picks(Z_USER)))
+    assert np.array_equal(a, np.rint(want).astype(np.int64))
+    big = _synthetic_tl(300_000, 70_000, 30, 'zipf', uniq=0.05)            # P = 10 column parts: two-pass layout
+    big.em()
+    assert big._eng.layout_info()['P'] > 8
+    _check_report(big, (Z_PREV, Z_INITIAL))
