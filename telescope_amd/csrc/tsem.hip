@@ -1423,6 +1423,7 @@ static void free_matrix(tsem_ctx* h) {
   h->d_red = nullptr;
   h->have_rowstats = h->have_model = false;
   h->N = h->nnz = 0; h->K = 0;
+  h->max_code = -1;
 }
 
 extern "C" {
@@ -1648,12 +1649,15 @@ __global__ void k_max_u16(const uint16_t* __restrict__ v, int64_t n, uint32_t* _
 int tsem_max_score(tsem_ctx* h, int32_t* max_score) {
   if (!h || !h->d_indptr || !max_score) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
-  TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
-  if (h->nnz) k_max_u16<<<1024, 256, 0, h->stream>>>(h->d_raw, h->nnz, h->d_maxcode);
-  uint32_t m = 0;
-  TSEM_HIP(hipMemcpyAsync(&m, h->d_maxcode, 4, hipMemcpyDeviceToHost, h->stream));
-  TSEM_HIP(hipStreamSynchronize(h->stream));
-  *max_score = (int32_t)m;
+  if (h->max_code < 0) {                                     // (the matrix does not change between load / generate calls)
+    TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
+    if (h->nnz) k_max_u16<<<1024, 256, 0, h->stream>>>(h->d_raw, h->nnz, h->d_maxcode);
+    uint32_t m = 0;
+    TSEM_HIP(hipMemcpyAsync(&m, h->d_maxcode, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    h->max_code = (int32_t)m;
+  }
+  *max_score = h->max_code;
   return TSEM_OK;
 }
 

@@ -75,6 +75,7 @@ struct tsem_ctx {
   int32_t* d_uni_col = nullptr;     // [N_uni]
   uint16_t* d_uni_code = nullptr;   // [N_uni]
   uint32_t* d_maxcode = nullptr;    // [1]
+  int32_t max_code = -1;            // largest raw score of the resident matrix (-1: not taken yet); tsem_max_score
   bool have_rowstats = false;
 
   // ---- model scalars (GLOBAL after set_model) ----
