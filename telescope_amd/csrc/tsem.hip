@@ -480,17 +480,38 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
     total[threadIdx.x] = run; lastrow[threadIdx.x] = last;
   }
   __syncthreads();
+  // A row's entries keep their CSR order inside each part: the position of an entry = the row's cursor for its part
+  // (read-only after the scan) + the number of earlier entries of the row in that part, counted with wave ballots over
+  // the 16 lanes that walk the row — no LDS atomic per entry (2e9 of them with a return value were half of this
+  // kernel's time), and the layout is the same from run to run.
+  const int sgbase = (threadIdx.x & 63) / RS_SUB * RS_SUB;
+  const uint32_t below = (1u << lane) - 1u;
   for (int lr = sub; lr < R; lr += subs) {
     const int64_t i = amb_row[b * R + lr];
     if (i < 0) continue;
-    for (int64_t k = indptr[i] + lane; k < indptr[i + 1]; k += RS_SUB) {
-      const uint32_t cm = colmap[indices[k]];
-      const uint32_t p = cm >> 16;
-      const uint32_t t = atomicAdd(&cnt[lr * P + p], 1u);
-      const int64_t pos = sb_off[b * P + p] + t;
-      if (pcode) pcode[pos] = raw[k];
-      else pval[pos] = lut[raw[k]];
-      prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
+    uint32_t run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t s = indptr[i], e = indptr[i + 1];
+    for (int64_t k0 = s; k0 < e; k0 += RS_SUB) {          // (all 16 lanes stay in the loop: the ballots need them)
+      const int64_t k = k0 + lane;
+      const bool valid = k < e;
+      const uint32_t cm = valid ? colmap[indices[k]] : 0u;
+      const uint32_t p = valid ? cm >> 16 : 0xFFFFu;
+      uint32_t t = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (q < P) {
+          const uint32_t m = (uint32_t)(__ballot(p == (uint32_t)q) >> sgbase) & 0xFFFFu;
+          if (p == (uint32_t)q) t = run[q] + __popc(m & below);
+          run[q] += __popc(m);
+        }
+      }
+      if (valid) {
+        t += cnt[lr * P + p];
+        const int64_t pos = sb_off[b * P + p] + t;
+        if (pcode) pcode[pos] = raw[k];
+        else pval[pos] = lut[raw[k]];
+        prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
+      }
     }
   }
   for (int p = 0; p < P; ++p) {                            // padding: value 0 (buffers are zero-filled), row = last row
