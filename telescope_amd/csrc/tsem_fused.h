@@ -588,7 +588,9 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       const uint32_t a0 = idle2 ? 0u : rs.rc.x, a1 = rs.rc.y, a2 = rs.rc.z, a3 = rs.rc.w;
       const double* sb = s + (k2 & 1) * R;
       // (Row order: gathering only the outer two row factors of a lane when no lane of the wave spans three rows
-      // — two LDS reads less per lane — was tried: the wave-uniform branch costs more than the reads, 4.20 -> 4.30 ms.)
+      // — two LDS reads less per lane — was tried twice: with the select at the top (a second LDS round trip) 4.20 ->
+      // 4.30 ms, with the select deferred to phase 2 3.57 -> 3.73 ms (codes) / 4.09 -> 4.19 ms: the ballot, the
+      // compares and the selects cost more issue slots than the two broadcast reads they save.)
       const double s0 = sb[a0 >> 16], s1 = sb[a1 >> 16], s2 = sb[a2 >> 16], s3 = sb[a3 >> 16];
       double2 q0 = rp.v0, q1 = rp.v1;
       if (FMT == 1) {                                     // Q from the score table: the same fp64 the fp64 layout stores
