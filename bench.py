@@ -255,7 +255,8 @@ def main():
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC, profiles/pmc_traffic.json)',
             'kernel': 'EM pass k_em_fused (rank 0 shard)', 'kernel_ms': k_ms, 'kernel_launches_timed': ks['em_launches'],
             'limiter': ('LDS atomics/gathers (2-byte score codes halve the HBM bytes)'
-                        if info.get('value_bytes') == 2 else 'HBM stream + exchange traffic'),
+                        if info.get('value_bytes') == 2 else
+                        'HBM stream (83-87 % of what a pure streaming read reaches on this part); the LDS work of a step is next (DESIGN.md 9.2)'),
             'algo_bytes_per_launch': ks['algo_bytes_per_pass'],
         },
     }
