@@ -203,6 +203,14 @@ def main():
         # exactly what TelescopeLikelihood.em() runs per chunk of iterations (likelihood.py): pass, in-library
         # RCCL all-reduce (N > 1 / --force-comm), update and the device-side convergence test (never true at
         # em_epsilon = 0), one host synchronisation per call
+        if comm is not None and not comm.in_library:
+            # fall-back transport (the library communicator could not be created, distributed.py): what em() then runs —
+            # one torch.distributed all-reduce of the engine's reduce buffer and one host round trip per iteration
+            for _ in range(n):
+                eng.em_pass()
+                comm.allreduce_device(eng, 0, args.cols + 1)
+                eng.em_update()
+            return
         eng.em_chunk(n, 0.0, False)
 
     def fence():
@@ -246,7 +254,9 @@ def main():
                         'pi_prior=0 theta_prior=200000, em_epsilon=0 (fixed iterations)'
                         % (total_rows // 1_000_000, args.cols // 1000, args.nnz_row, args.dist),
             'rows': total_rows, 'cols': args.cols, 'nnz': nnz_total, 'dist': args.dist, 'seed': args.seed,
-            'parallelism': ('row-sharded x%d, 1 in-library RCCL all-reduce(K+2 f64)/iter' % world) if comm is not None else 'single GPU',
+            'parallelism': (('row-sharded x%d, 1 in-library RCCL all-reduce(K+2 f64)/iter' % world) if comm.in_library else
+                            ('row-sharded x%d, FALL-BACK transport: torch.distributed all-reduce(K+1 f64) + host round trip per iter' % world))
+            if comm is not None else 'single GPU',
             'em_kernel': args.em_kernel, 'layout': info,
             'value_format': 'code16+lut (6 B/nnz stored)' if info.get('value_bytes') == 2 else 'f64 (12 B/nnz stored)', 'setup_s': round(t_setup, 3),
         },

@@ -64,9 +64,36 @@ class Comm(object):
             self.tdev = torch.device('cuda', self.device)
             torch.cuda.set_device(self.device)
             from ._lib import LibComm
-            ids = [LibComm.unique_id() if self.rank == 0 else None]
+            # The library's own communicator.  If it cannot be created on this system (every rank decides together:
+            # the flags are all-reduced over torch's group), the collectives fall back to torch.distributed on the
+            # engine's reduce buffer: one all-reduce per iteration from the host — slower (a host round trip per
+            # iteration) but the same numbers.  TSEM_TORCH_COLLECTIVES=1 forces that path (tests).
+            failed = os.environ.get('TSEM_TORCH_COLLECTIVES', '0') == '1'
+            ids = [None]
+            if not failed and self.rank == 0:
+                try:
+                    ids = [LibComm.unique_id()]
+                except Exception as exc:                      # noqa: BLE001
+                    failed, self.lib_error = True, str(exc)
             dist.broadcast_object_list(ids, src=0, group=group, device=self.tdev)
-            self.lib = LibComm(self.device, ids[0], self.rank, self.world)
+            if ids[0] is not None and not failed:
+                try:
+                    self.lib = LibComm(self.device, ids[0], self.rank, self.world)
+                except Exception as exc:                      # noqa: BLE001
+                    failed, self.lib_error = True, str(exc)
+            else:
+                failed = True
+            flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=self.tdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            if int(flag.item()):
+                if self.lib is not None:
+                    self.lib.close()
+                self.lib = None
+                if self.rank == 0:
+                    import warnings
+                    warnings.warn('telescope_amd: the library RCCL communicator is not in use (%s); collectives go '
+                                  'through torch.distributed, one host round trip per EM iteration'
+                                  % getattr(self, 'lib_error', 'TSEM_TORCH_COLLECTIVES=1'))
         else:
             self.device = 0 if device is None else device
             self.tdev = torch.device('cpu')
@@ -138,7 +165,7 @@ class Comm(object):
             self.in_library = True
             return
         from ._lib import Engine
-        if isinstance(engine, Engine):
+        if isinstance(engine, Engine) and self.backend != 'nccl':
             raise RuntimeError('a HIP engine needs the nccl (RCCL) backend: its reduce buffer lives in HBM and the %s '
                                'backend reduces host tensors' % self.backend)
         t = self._torch

@@ -669,3 +669,39 @@ def test_report_pass_on_the_layouts_the_row_pass_branches_on(gpu_device):
     big.em()
     assert big._eng.layout_info()['P'] > 8
     _check_report(big, (Z_PREV, Z_INITIAL))
+
+
+def test_torch_transport_fallback(gpu_device):
+    """If the library's RCCL communicator cannot be created, Comm falls back to torch.distributed collectives on the
+    engine's reduce buffer (one host round trip per iteration).  Forced here with TSEM_TORCH_COLLECTIVES=1 in a
+    1-rank group of its own process: same iteration count, parameters and integer report columns as the goldens."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, sys, warnings
+        sys.path[:0] = [%r, %r]
+        import numpy as np, scipy.sparse as sp
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29617', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                          TSEM_TORCH_COLLECTIVES='1')
+        from conftest import Opts, case_matrix, load_case
+        from telescope_amd.distributed import init_from_env
+        from telescope_amd.likelihood import TelescopeLikelihood
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            comm = init_from_env(force=True)
+        assert comm.lib is None and any('torch.distributed' in str(x.message) for x in w)
+        for name in ('bundled', 'mid_zipf_20k'):
+            c = load_case(name)
+            tl = TelescopeLikelihood(case_matrix(c), Opts(c), comm=comm)
+            assert not comm.in_library
+            tl.em(use_likelihood=bool(c['use_likelihood']))
+            assert tl.n_iter == int(c['n_iter'])
+            assert abs(tl.lnl - float(c['lnl'])) <= 1e-9 * abs(float(c['lnl']))
+            assert np.allclose(tl.pi, c['pi'], rtol=1e-9, atol=0) and np.allclose(tl.pi_init, c['pi_init'], rtol=1e-9, atol=0)
+            np.random.seed(int(c['seed']))
+            assert np.array_equal(tl.reassign_colsums('choose'), c['ra_choose_0_colsum'])
+            assert np.array_equal(tl.reassign_colsums('exclude'), c['ra_exclude_0_colsum'])
+        print('FALLBACK-OK')
+    """) % (root, os.path.join(root, 'tests'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert 'FALLBACK-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
