@@ -245,31 +245,34 @@ __global__ void k_compact_rows(int64_t N, const uint8_t* __restrict__ cls, const
 // Counts order columns by popularity; (count, hash) identifies exact twin
 // columns (same rows, same scores) whose parameters the reference keeps
 // bit-identical (it accumulates every column in row order).
-constexpr int SIG_WIN = 12288;      // 12 B of LDS per column: 147 KB
+constexpr int SIG_WIN = 18432;      // 8 B of LDS per column: 147 KB
+// One 64-bit LDS atomic per entry: the low half counts the column's entries, the high half sums a 32-bit hash of
+// (global row, score) modulo 2^32 (a workgroup sees fewer than 2^32 entries of a column, so the halves never mix).
+// Twins must agree on the count and on the hash sum of every rank — and k_update still only ties two columns whose
+// accumulated sums agree to 1e-12, so a 32-bit signature is a filter, not the proof.  (Round 1: a 32-bit counter and
+// a 64-bit hash, 12 B per column: three passes over the matrix at K = 30k instead of two, and two atomics per entry:
+// 29 -> 14 ms at 2e9 entries.)
 __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, const int64_t* __restrict__ indptr,
     const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw, int col_base, int K,
     unsigned long long* __restrict__ counts, unsigned long long* __restrict__ hashes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* hh = reinterpret_cast<unsigned long long*>(smem);
-  uint32_t* hc = reinterpret_cast<uint32_t*>(hh + SIG_WIN);
-  for (int t = threadIdx.x; t < SIG_WIN; t += blockDim.x) { hh[t] = 0; hc[t] = 0; }
+  for (int t = threadIdx.x; t < SIG_WIN; t += blockDim.x) hh[t] = 0;
   __syncthreads();
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
   for (int64_t i = (int64_t)blockIdx.x * subs + sub; i < N; i += (int64_t)gridDim.x * subs) {
     int64_t s = indptr[i], e = indptr[i + 1];
     for (int64_t k = s + lane; k < e; k += RS_SUB) {
       int c = indices[k] - col_base;
-      if (c >= 0 && c < SIG_WIN) {
-        atomicAdd(&hc[c], 1u);
-        atomicAdd(&hh[c], (unsigned long long)ts_hash3(0x7715ull, (uint64_t)(row_offset + i), (uint64_t)raw[k]));
-      }
+      if (c >= 0 && c < SIG_WIN)
+        atomicAdd(&hh[c], (ts_hash3(0x7715ull, (uint64_t)(row_offset + i), (uint64_t)raw[k]) & 0xFFFFFFFF00000000ull) | 1ull);
     }
   }
   __syncthreads();
   for (int t = threadIdx.x; t < SIG_WIN; t += blockDim.x)
-    if (hc[t] && col_base + t < K) {
-      atomicAdd(&counts[col_base + t], (unsigned long long)hc[t]);
-      atomicAdd(&hashes[col_base + t], hh[t]);
+    if (hh[t] && col_base + t < K) {
+      atomicAdd(&counts[col_base + t], hh[t] & 0xFFFFFFFFull);
+      atomicAdd(&hashes[col_base + t], hh[t] >> 32);
     }
 }
 
@@ -1811,7 +1814,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     TSEM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * K, h->stream));
     TSEM_HIP(hipMemsetAsync(d_hash, 0, sizeof(unsigned long long) * K, h->stream));
     if (N) {
-      const int lds = SIG_WIN * 12;
+      const int lds = SIG_WIN * 8;
       TSEM_HIP(hipFuncSetAttribute((const void*)k_colsig, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       int g2 = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, (N + 63) / 64));
       for (int base = 0; base < K; base += SIG_WIN)
