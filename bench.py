@@ -150,19 +150,69 @@ def cpu_baseline(args, dist_code, cdf):
                                    lnl_rel_delta=abs(tlc.lnl - omc.lnl) / abs(omc.lnl)))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
+    environment torch.distributed.run would give them), relay rank 0's JSON line as OUR last stdout line, and return
+    the worst exit code.  Rank r's stderr is passed through; its stdout too, except for rank 0's, which is kept so
+    that the result line can be printed last."""
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs, out0 = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), TSEM_BENCH_SELF_LAUNCHED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None, text=(r == 0)))
+    th = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    th.start()
+    rcs = [None] * n
+    deadline = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs) and deadline is None:
+            deadline = time.time() + 30.0                       # a rank failed: the others may sit in a collective
+        if deadline is not None and time.time() > deadline:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.kill()                                    # exactly the processes started above
+        time.sleep(0.05)
+    th.join(10)
+    lines = [ln.rstrip('\n') for ln in out0 if ln.strip()]
+    result = None
+    for ln in reversed(lines):
+        if ln.startswith('{') and '"metric"' in ln:
+            result = ln
+            break
+    for ln in lines:
+        if ln is not result:
+            print(ln)
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if result is None and worst == 0:
+        worst = 1
+    if result is not None:
+        print(result, flush=True)
+    return worst
+
+
 def main():
     args = parse()
+    if 'RANK' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run '
-                     '--nproc-per-node %d' % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     from telescope_amd import synthetic
     from telescope_amd._lib import Engine, EMK_AUTO, EMK_FUSED, EMK_TWOPASS
     from telescope_amd.distributed import init_from_env, shard_bounds
     from telescope_amd.likelihood import TelescopeLikelihood
 
+    # the engine first: without a usable GPU every rank fails HERE, loudly ("no CPU fallback"), not in the launcher
+    eng = Engine(int(os.environ.get('LOCAL_RANK', '0')))
     comm = init_from_env('nccl', force=args.force_comm) if (world > 1 or args.force_comm) else None
     rank = comm.rank if comm else 0
     local = comm.device if comm else 0
@@ -171,7 +221,6 @@ def main():
     dist_code = synthetic.DIST_CODE[args.dist]
     cdf = synthetic.poisson_cdf_u32(args.nnz_row)
 
-    eng = Engine(local)
     eng.set_option('row_offset', r0)
     eng.set_option('em_kernel', {'auto': EMK_AUTO, 'twopass': EMK_TWOPASS, 'fused': EMK_FUSED}[args.em_kernel])
     eng.set_option('value_format', {'auto': 0, 'f64': 1, 'code16': 2}[args.value_format])
@@ -257,6 +306,9 @@ def main():
             'parallelism': (('row-sharded x%d, 1 in-library RCCL all-reduce(K+2 f64)/iter' % world) if comm.in_library else
                             ('row-sharded x%d, FALL-BACK transport: torch.distributed all-reduce(K+1 f64) + host round trip per iter' % world))
             if comm is not None else 'single GPU',
+            'transport': comm.describe() if comm is not None else None,
+            'launcher': 'self (bench.py started the ranks)' if os.environ.get('TSEM_BENCH_SELF_LAUNCHED') else
+                        ('torchrun / external' if world > 1 else 'single process'),
             'em_kernel': args.em_kernel, 'layout': info,
             'value_format': 'code16+lut (6 B/nnz stored)' if info.get('value_bytes') == 2 else 'f64 (12 B/nnz stored)', 'setup_s': round(t_setup, 3),
         },

@@ -177,6 +177,10 @@ int  tsem_recover_timeout(tsem_ctx* h, int32_t* switched);
 /* calculate_lnl(z(prev params), current params) (model.py:800-801), summed over the ranks of an attached
  * communicator; synchronous.  Redone on the two-pass kernels after a time-out of the fused pass. */
 int  tsem_final_lnl(tsem_ctx* h, double* lnl);
+/* The log-likelihood the FIRST iteration of the next run (tsem_em_chunk with first != 0) is compared with under
+ * use_likelihood: the reference compares with self.lnl as the previous em() left it (model.py:786; inf on a fresh
+ * model, model.py:683).  tsem_set_model resets it to inf, tsem_em_run leaves its final value. */
+int  tsem_set_prev_lnl(tsem_ctx* h, double lnl);
 /* Full EM loop (model.py:762-806) on top of tsem_em_chunk. */
 int  tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likelihood,
                  int32_t* n_iter, int32_t* converged, double* lnl,
@@ -200,6 +204,18 @@ const char* tsem_comm_last_error(void);
 int  tsem_comm_attach(tsem_ctx* h, tsem_comm* c);             /* c == NULL detaches */
 int  tsem_comm_allreduce(tsem_ctx* h, int64_t offset, int64_t count);   /* reduce buffer [offset, offset+count), async */
 int  tsem_comm_allreduce_host(tsem_comm* c, void* data, int64_t count, int dtype /*0 f64 sum, 1 u64 sum, 2 f64 max, 3 i64 max*/);
+/* RCCL is resolved at run time, not linked: the librccl already mapped into the process (a torch process carries
+ * one) or else librccl.so.1 from the loader path — ONE copy, chosen deliberately; without RCCL the library still
+ * loads and runs single-GPU.  Writes "rccl <version> (<path>)" (or why it is unavailable) into buf. */
+int  tsem_comm_library_info(char* buf, int32_t cap);
+/* In-process transport: `world` handles on ONE device, one host thread each (tests of the row-sharded protocol on
+ * a one-GPU box; hosts that share a GPU between engines).  Same tsem_em_chunk, same reduce buffer, error slot and
+ * device-side stop flag; the all-reduce is a copy into per-rank slots, a host rendezvous of the ranks' threads at
+ * ENQUEUE time, stream waits on the peers' events and a sum in rank order (bit-identical on every rank). */
+typedef struct tsem_local_group tsem_local_group;
+int  tsem_comm_local_group(tsem_local_group** out, int device, int world /* <= 8 */);
+void tsem_comm_local_group_destroy(tsem_local_group* g);      /* after every communicator of the group */
+int  tsem_comm_create_local(tsem_comm** out, tsem_local_group* g, int rank);
 
 /* ---- results -------------------------------------------------------------- */
 /* z aligned to the CSR pattern of the loaded scores (-1 where the reference

@@ -37,7 +37,7 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
            '-munsafe-fp-atomics', '-I' + os.path.join(ROOT, 'include'),
-           '-I' + os.path.join(HERE, 'csrc'), '-o', LIB_PATH, SRC, '-lrccl']
+           '-I' + os.path.join(HERE, 'csrc'), '-o', LIB_PATH, SRC, '-ldl', '-lpthread']   # (RCCL is resolved at run time)
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
@@ -112,6 +112,12 @@ def lib():
     L.tsem_comm_attach.argtypes = [vp, vp]
     L.tsem_comm_allreduce.argtypes = [vp, i64, i64]
     L.tsem_comm_allreduce_host.argtypes = [vp, vp, i64, C.c_int]
+    L.tsem_comm_library_info.argtypes = [C.c_char_p, i32]
+    L.tsem_comm_local_group.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    L.tsem_comm_local_group_destroy.argtypes = [vp]
+    L.tsem_comm_local_group_destroy.restype = None
+    L.tsem_comm_create_local.argtypes = [C.POINTER(vp), vp, C.c_int]
+    L.tsem_set_prev_lnl.argtypes = [vp, dbl]
     L.tsem_em_run.argtypes = [vp, dbl, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(dbl),
                               vp, vp, vp, vp]
     L.tsem_export_z.argtypes = [vp, C.c_int, vp]
@@ -137,7 +143,7 @@ def lib():
     for name in exported_symbols():
         fn = getattr(L, name)
         if name not in ('tsem_destroy', 'tsem_last_error', 'tsem_comm_destroy', 'tsem_comm_last_error',
-                        'tsem_debug_subblock'):
+                        'tsem_debug_subblock', 'tsem_comm_local_group_destroy'):
             fn.restype = C.c_int
     L.tsem_debug_subblock.restype = C.c_int64
     _lib = L
@@ -184,6 +190,7 @@ class Engine(object):
 
     def set_option(self, key, value):
         self._ck(self._L.tsem_set_option(self._h, key.encode(), int(value)))
+        self.__dict__.setdefault('options', {})[key] = int(value)      # (what was set: em() restores "kernel_timing")
 
     def synchronize(self):
         self._ck(self._L.tsem_synchronize(self._h))
@@ -295,6 +302,10 @@ class Engine(object):
                                        C.byref(done), C.byref(stopped), ptr(diffs), ptr(lnls)))
         n = done.value
         return diffs[:n], (lnls[:n] if use_likelihood else None), bool(stopped.value)
+
+    def set_prev_lnl(self, lnl):
+        """The lnl the next run's first iteration is compared with under use_likelihood (model.py:786)."""
+        self._ck(self._L.tsem_set_prev_lnl(self._h, float(lnl)))
 
     def final_lnl(self):
         out = C.c_double()
@@ -452,9 +463,37 @@ class Engine(object):
                          'lds_bytes', 'row_order', 'geometry', 'fallbacks'), info.tolist()))
 
 
+def comm_library_info():
+    """Which RCCL the library resolved at run time: 'rccl <version> (<path>)', or why none is available."""
+    buf = C.create_string_buffer(1024)
+    lib().tsem_comm_library_info(buf, 1024)
+    return buf.value.decode()
+
+
+class LocalGroup(object):
+    """In-process transport (include/telescope_em.h): `world` engines on ONE device, one host thread each."""
+
+    def __init__(self, device, world):
+        L = lib()
+        g = C.c_void_p()
+        rc = L.tsem_comm_local_group(C.byref(g), int(device), int(world))
+        if rc != OK:
+            raise EngineError('tsem_comm_local_group failed (%d): %s' % (rc, L.tsem_comm_last_error().decode()))
+        self._L, self.handle, self.device, self.world = L, g, device, world
+
+    def comm(self, rank):
+        return LibComm(self.device, None, rank, self.world, group=self)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._L.tsem_comm_local_group_destroy(self.handle)
+            self.handle = None
+
+
 class LibComm(object):
-    """The library's own RCCL communicator (one per process / GPU): `unique_id()` on rank 0, ship the 128
-    bytes to the other ranks, then `LibComm(device, id, rank, world)` everywhere (collective)."""
+    """The library's own communicator.  RCCL (one per process / GPU): `unique_id()` on rank 0, ship the 128
+    bytes to the other ranks, then `LibComm(device, id, rank, world)` everywhere (collective).  In-process
+    transport: `LocalGroup(device, world).comm(rank)`."""
     ID_BYTES = 128
     _DT = {('f64', 'sum'): 0, ('u64', 'sum'): 1, ('f64', 'max'): 2, ('i64', 'max'): 3}
 
@@ -466,11 +505,15 @@ class LibComm(object):
             raise EngineError('tsem_comm_unique_id failed (%d): %s' % (rc, lib().tsem_comm_last_error().decode()))
         return buf.tobytes()
 
-    def __init__(self, device, unique_id, rank, world):
+    def __init__(self, device, unique_id, rank, world, group=None):
         L = lib()
         h = C.c_void_p()
-        idb = np.frombuffer(unique_id, np.uint8).copy()
-        rc = L.tsem_comm_create(C.byref(h), int(device), ptr(idb), int(rank), int(world))
+        if group is not None:
+            rc = L.tsem_comm_create_local(C.byref(h), group.handle, int(rank))
+            self._group = group                               # keeps the group alive
+        else:
+            idb = np.frombuffer(unique_id, np.uint8).copy()
+            rc = L.tsem_comm_create(C.byref(h), int(device), ptr(idb), int(rank), int(world))
         if rc != OK:
             raise EngineError('tsem_comm_create failed (%d): %s' % (rc, L.tsem_comm_last_error().decode()))
         self._L, self.handle, self.rank, self.world, self.device = L, h, rank, world, device

@@ -19,10 +19,16 @@
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 
+#include <dlfcn.h>
+#include <link.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 
 #include "tsem_common.h"
@@ -2151,6 +2157,7 @@ int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, cons
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipStreamSynchronize(h->stream));
   h->have_model = true;
+  h->lnl_prev_seed = INFINITY;                             // model.py:683
   h->em_cur = h->em_prev = true;                           // pi = theta = 1/K
   return TSEM_OK;
 }
@@ -2454,20 +2461,181 @@ int tsem_read_reduce(tsem_ctx* h, double* out, int64_t offset, int64_t count) {
   return TSEM_OK;
 }
 
-#define TSEM_NCCL(call)                                                          \
-  do {                                                                           \
-    ncclResult_t r_ = (call);                                                    \
-    if (r_ != ncclSuccess) {                                                     \
-      h->err = std::string(#call) + ": " + ncclGetErrorString(r_);               \
-      return TSEM_ERR_HIP;                                                       \
-    }                                                                            \
-  } while (0)
+// ---------------------------------------------------------------------------
+// collectives: RCCL resolved at RUN time, or the in-process transport
+// ---------------------------------------------------------------------------
+// RCCL is not linked.  A torch process already carries a librccl (torch/lib/librccl.so, loaded with torch); linking a
+// second one by DT_NEEDED made the copy that serves this library's calls depend on load order.
+// Now ONE copy is chosen deliberately: the librccl that is already mapped into the process if there is one (so the
+// library and torch.distributed share a single RCCL — one set of IPC handles, one topology detection), otherwise
+// librccl.so.1 from the loader's search path / /opt/rocm/lib.  A box without RCCL can still load and run the library
+// on one GPU; tsem_comm_library_info reports which copy and version is in use (it goes into the bench line).
+struct NcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  bool ok = false;
+  int version = 0;
+  std::string path, others, err;
+};
+static int nccl_phdr_cb(struct dl_phdr_info* info, size_t, void* data) {
+  auto* v = static_cast<std::vector<std::string>*>(data);
+  if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) v->push_back(info->dlpi_name);
+  return 0;
+}
+static NcclApi* nccl_api() {
+  static NcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::vector<std::string> loaded;
+    dl_iterate_phdr(nccl_phdr_cb, &loaded);
+    void* hnd = nullptr;
+    if (!loaded.empty()) {
+      hnd = dlopen(loaded[0].c_str(), RTLD_NOW | RTLD_NOLOAD);
+      if (hnd) api.path = loaded[0];
+      for (size_t i = 1; i < loaded.size(); ++i) api.others += (api.others.empty() ? "" : ", ") + loaded[i];
+    }
+    const char* cands[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int i = 0; i < 3 && !hnd; ++i) {
+      hnd = dlopen(cands[i], RTLD_NOW | RTLD_LOCAL);
+      if (hnd) {
+        api.path = cands[i];
+        Dl_info di;
+        void* sym = dlsym(hnd, "ncclAllReduce");
+        if (sym && dladdr(sym, &di) && di.dli_fname) api.path = di.dli_fname;
+      }
+    }
+    if (!hnd) { api.err = std::string("librccl is not available: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+    auto need = [&](const char* name) -> void* {
+      void* p = dlsym(hnd, name);
+      if (!p && api.err.empty()) api.err = std::string("librccl (") + api.path + ") does not export " + name;
+      return p;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(need("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(need("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(need("ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(need("ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(need("ncclGetErrorString"));
+    api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(need("ncclGetVersion"));
+    if (!api.err.empty()) return;
+    if (api.GetVersion(&api.version) != ncclSuccess) api.version = 0;
+    // the id / enum layout this file was compiled against (rccl.h of the ROCm image) is the 2.x ABI
+    if (api.version && api.version / 10000 != NCCL_MAJOR) {
+      api.err = "librccl (" + api.path + ") has major version " + std::to_string(api.version / 10000) + ", this library was built for " +
+                std::to_string(NCCL_MAJOR);
+      return;
+    }
+    api.ok = true;
+  });
+  return &api;
+}
+
+// ---- in-process transport -------------------------------------------------------------------------------------
+// Several handles on ONE device, each driven by its own host thread of one process, run the protocol of a row-sharded
+// job: same tsem_em_chunk, same reduce-buffer layout, same device-side stop flag and error slot — only the all-reduce
+// itself is different.  Rank r copies its vector into its slot, records an event; after a HOST rendezvous (every rank has
+// recorded) each rank makes its stream wait for the peers' events and sums the slots in rank order, so all ranks get the
+// same bits.  Two slot generations alternate; a slot is rewritten only after the peers' sums of two collectives ago
+// have completed (their `done` events).  For tests of the N > 1 path on a one-GPU box, and for hosts that time-slice
+// one GPU between several engines; a multi-GPU job uses RCCL.
+constexpr int TS_LOCAL_MAXW = 8;
+struct tsem_local_group {
+  int world = 1, device = 0, refs = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  bool broken = false;
+  double timeout_s = 120.0;
+  void* slot[TS_LOCAL_MAXW][2] = {};
+  size_t slot_bytes[TS_LOCAL_MAXW][2] = {};
+  hipEvent_t ready[TS_LOCAL_MAXW][2] = {}, done[TS_LOCAL_MAXW][2] = {};
+  bool done_rec[TS_LOCAL_MAXW][2] = {};
+  bool taken[TS_LOCAL_MAXW] = {};
+};
+// host rendezvous of the group's ranks; false: a peer did not arrive in time (or the group broke earlier)
+static bool local_rendezvous(tsem_local_group* g) {
+  std::unique_lock<std::mutex> lk(g->mu);
+  if (g->broken) return false;
+  const uint64_t my = g->gen;
+  if (++g->arrived == g->world) { g->arrived = 0; ++g->gen; g->cv.notify_all(); return true; }
+  const bool ok = g->cv.wait_for(lk, std::chrono::duration<double>(g->timeout_s), [&] { return g->gen != my || g->broken; });
+  if (!ok || g->broken) { g->broken = true; g->cv.notify_all(); return false; }
+  return true;
+}
+// dtype / op as in tsem_comm_allreduce_host: 0 f64 sum, 1 u64 sum, 2 f64 max, 3 i64 max
+struct LocalSlots { const void* p[TS_LOCAL_MAXW]; };
+__global__ __launch_bounds__(256) void k_local_reduce(void* __restrict__ out, LocalSlots S, int world, int64_t n, int dtype) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (dtype == 0 || dtype == 2) {
+    double v = static_cast<const double*>(S.p[0])[i];
+    for (int q = 1; q < world; ++q) { const double t = static_cast<const double*>(S.p[q])[i]; v = dtype == 0 ? v + t : fmax(v, t); }
+    static_cast<double*>(out)[i] = v;
+  } else if (dtype == 1) {
+    unsigned long long v = static_cast<const unsigned long long*>(S.p[0])[i];
+    for (int q = 1; q < world; ++q) v += static_cast<const unsigned long long*>(S.p[q])[i];
+    static_cast<unsigned long long*>(out)[i] = v;
+  } else {
+    long long v = static_cast<const long long*>(S.p[0])[i];
+    for (int q = 1; q < world; ++q) v = max(v, static_cast<const long long*>(S.p[q])[i]);
+    static_cast<long long*>(out)[i] = v;
+  }
+}
+static int local_allreduce(tsem_comm* c, void* buf, size_t count, int dtype, hipStream_t s, std::string& err) {
+  tsem_local_group* g = c->local;
+  const int r = c->rank, par = (int)(c->epoch & 1);
+  c->epoch += 1;
+  const size_t bytes = count * 8;
+  auto fail = [&](const std::string& m) { err = m; std::lock_guard<std::mutex> lk(g->mu); g->broken = true; g->cv.notify_all(); return TSEM_ERR_HIP; };
+#define LOC_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+  // my slot of this generation is free once the peers' sums of two collectives ago are done
+  for (int q = 0; q < g->world; ++q)
+    if (q != r && g->done_rec[q][par]) LOC_HIP(hipStreamWaitEvent(s, g->done[q][par], 0));
+  if (g->slot_bytes[r][par] < bytes) {
+    for (int q = 0; q < g->world; ++q)
+      if (q != r && g->done_rec[q][par]) LOC_HIP(hipEventSynchronize(g->done[q][par]));
+    if (g->slot[r][par]) LOC_HIP(hipFree(g->slot[r][par]));
+    g->slot[r][par] = nullptr; g->slot_bytes[r][par] = 0;
+    LOC_HIP(hipMalloc(&g->slot[r][par], std::max<size_t>(bytes, 4096)));
+    g->slot_bytes[r][par] = std::max<size_t>(bytes, 4096);
+  }
+  if (bytes) LOC_HIP(hipMemcpyAsync(g->slot[r][par], buf, bytes, hipMemcpyDeviceToDevice, s));
+  LOC_HIP(hipEventRecord(g->ready[r][par], s));
+  if (!local_rendezvous(g)) { err = "in-process communicator: a peer rank did not reach the collective (time-out or an earlier failure)"; return TSEM_ERR_TIMEOUT; }
+  LocalSlots S;
+  for (int q = 0; q < g->world; ++q) {
+    if (q != r) LOC_HIP(hipStreamWaitEvent(s, g->ready[q][par], 0));
+    S.p[q] = g->slot[q][par];
+  }
+  if (count) k_local_reduce<<<(unsigned)((count + 255) / 256), 256, 0, s>>>(buf, S, g->world, (int64_t)count, dtype);
+  LOC_HIP(hipGetLastError());
+  LOC_HIP(hipEventRecord(g->done[r][par], s));
+  g->done_rec[r][par] = true;
+#undef LOC_HIP
+  return TSEM_OK;
+}
+
+static bool comm_on(const tsem_ctx* h) { return h->comm && h->comm->active(); }
+// in-place all-reduce of `count` 8-byte words on device memory, on stream s, over whichever transport the communicator has
+static int comm_allreduce_dev(tsem_comm* c, void* buf, size_t count, int dtype, hipStream_t s, std::string& err) {
+  if (!c || !c->active()) return TSEM_OK;
+  if (c->local) return local_allreduce(c, buf, count, dtype, s, err);
+  NcclApi* N = nccl_api();
+  const ncclDataType_t dt = dtype == 1 ? ncclUint64 : (dtype == 3 ? ncclInt64 : ncclDouble);
+  const ncclRedOp_t op = dtype >= 2 ? ncclMax : ncclSum;
+  const ncclResult_t r = N->AllReduce(buf, buf, count, dt, op, c->nccl, s);
+  if (r != ncclSuccess) { err = std::string("ncclAllReduce: ") + N->GetErrorString(r); return TSEM_ERR_HIP; }
+  return TSEM_OK;
+}
 
 // the per-iteration exchange: ONE sum all-reduce of the per-locus column sums + the error flag
 static int comm_allreduce_red(tsem_ctx* h, int64_t offset, int64_t count) {
-  if (!h->comm || !h->comm->nccl) return TSEM_OK;
-  TSEM_NCCL(ncclAllReduce(h->d_red + offset, h->d_red + offset, (size_t)count, ncclDouble, ncclSum, h->comm->nccl, h->stream));
-  return TSEM_OK;
+  if (!comm_on(h)) return TSEM_OK;
+  return comm_allreduce_dev(h->comm, h->d_red + offset, (size_t)count, 0, h->stream, h->err);
 }
 
 static int ensure_ctl(tsem_ctx* h) {
@@ -2483,8 +2651,7 @@ static int enqueue_lnl_reduce(tsem_ctx* h) {
   if (int rc = launch_lnl(h)) return rc;
   k_lnl_slots<<<1, 1, 0, h->stream>>>(h->d_red + h->K, (h->use_fused && h->nb > 0) ? h->d_xflags : nullptr, h->d_ctld + 1);
   TSEM_HIP(hipGetLastError());
-  if (h->comm && h->comm->nccl)
-    TSEM_NCCL(ncclAllReduce(h->d_ctld + 1, h->d_ctld + 1, 2, ncclDouble, ncclSum, h->comm->nccl, h->stream));
+  if (comm_on(h)) { if (int rc = comm_allreduce_dev(h->comm, h->d_ctld + 1, 2, 0, h->stream, h->err)) return rc; }
   return TSEM_OK;
 }
 
@@ -2494,14 +2661,18 @@ int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likeli
   if (int rc = ensure_device(h)) return rc;
   if (int rc = ensure_ctl(h)) return rc;
   if (first) {
-    const double inf = INFINITY;                           // model.py:683: self.lnl = inf before the first iteration
-    TSEM_HIP(hipMemcpyAsync(h->d_ctld, &inf, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // model.py:786 compares the first iteration's lnl with self.lnl as the previous run left it (inf on a fresh model,
+    // model.py:683): tsem_set_prev_lnl / the end of tsem_em_run keep that value for the next run
+    const double seed = h->lnl_prev_seed;
+    TSEM_HIP(hipMemcpy(h->d_ctld, &seed, sizeof(double), hipMemcpyHostToDevice));
     if (!h->d_pi_first) { TSEM_ALLOC(h->d_pi_first, h->K); TSEM_ALLOC(h->d_theta_first, h->K); }
     h->first_pending = true;
   }
   int done = 0, retries = 0;
   bool stop = false, lnl_pending = false;
-  while (done < n_max && !stop) {
+  // (an lnl pass that timed out in the LAST iteration of the chunk is redone before returning: its value is the
+  // iteration's log-likelihood and may end the run — ADVICE r2)
+  while ((done < n_max || lnl_pending) && !stop) {
     // enqueue everything that is left; the device stops itself
     TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 8, h->stream));
     const int base = done, want = n_max - done;
@@ -2536,8 +2707,8 @@ int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likeli
       lnl_pending = ctl[0] == 3u;
       continue;
     }
-    if (h->use_fused) {                                    // belt and braces: an error word the flags did not carry
-      uint32_t mine = 0;
+    if (h->use_fused && !comm_on(h)) {                     // belt and braces: an error word the flags did not carry.  (Row-sharded
+      uint32_t mine = 0;                                   //  runs rely on slot K alone: failing on ONE rank would leave the others in the next collective.)
       if (int rc = take_fused_error(h, &mine)) return rc;
       if (mine) TSEM_FAIL(TSEM_ERR_TIMEOUT, "fused EM kernel: hand-off watchdog fired (code " + std::to_string(mine) + ")");
     }
@@ -2605,9 +2776,16 @@ int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likel
   if (!use_likelihood) {                      // model.py:800-801
     if (int rc = final_lnl(h, &lnl)) return rc;
   }
+  h->lnl_prev_seed = lnl;                     // what the next run's first lnl is compared with (model.py:786)
   if (n_iter) *n_iter = inum;
   if (converged) *converged = conv ? 1 : 0;
   if (lnl_out) *lnl_out = lnl;
+  return TSEM_OK;
+}
+
+int tsem_set_prev_lnl(tsem_ctx* h, double lnl) {
+  if (!h) return TSEM_ERR_ARG;
+  h->lnl_prev_seed = lnl;
   return TSEM_OK;
 }
 
@@ -2617,12 +2795,29 @@ int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likel
 static std::string g_comm_err;
 const char* tsem_comm_last_error(void) { return g_comm_err.c_str(); }
 
+int tsem_comm_library_info(char* buf, int32_t cap) {
+  if (!buf || cap <= 0) return TSEM_ERR_ARG;
+  NcclApi* N = nccl_api();
+  std::string t;
+  if (N->ok) {
+    t = "rccl " + std::to_string(N->version / 10000) + "." + std::to_string(N->version / 100 % 100) + "." + std::to_string(N->version % 100) +
+        " (" + N->path + ")";
+    if (!N->others.empty()) t += "; other copies mapped: " + N->others;
+  } else {
+    t = "rccl unavailable: " + N->err;
+  }
+  snprintf(buf, (size_t)cap, "%s", t.c_str());
+  return N->ok ? TSEM_OK : TSEM_ERR_HIP;
+}
+
 int tsem_comm_unique_id(void* id128) {
   if (!id128) return TSEM_ERR_ARG;
   static_assert(sizeof(ncclUniqueId) == TSEM_COMM_ID_BYTES, "ncclUniqueId size");
+  NcclApi* N = nccl_api();
+  if (!N->ok) { g_comm_err = N->err; return TSEM_ERR_HIP; }
   ncclUniqueId id;
-  ncclResult_t r = ncclGetUniqueId(&id);
-  if (r != ncclSuccess) { g_comm_err = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r); return TSEM_ERR_HIP; }
+  ncclResult_t r = N->GetUniqueId(&id);
+  if (r != ncclSuccess) { g_comm_err = std::string("ncclGetUniqueId: ") + N->GetErrorString(r); return TSEM_ERR_HIP; }
   memcpy(id128, &id, sizeof(id));
   return TSEM_OK;
 }
@@ -2630,13 +2825,58 @@ int tsem_comm_unique_id(void* id128) {
 int tsem_comm_create(tsem_comm** out, int device, const void* id128, int rank, int world) {
   if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return TSEM_ERR_ARG;
   *out = nullptr;
+  NcclApi* N = nccl_api();
+  if (!N->ok) { g_comm_err = N->err; return TSEM_ERR_HIP; }
   if (hipSetDevice(device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return TSEM_ERR_HIP; }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   tsem_comm* c = new tsem_comm();
   c->device = device; c->rank = rank; c->world = world;
-  ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
-  if (r != ncclSuccess) { g_comm_err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); delete c; return TSEM_ERR_HIP; }
+  ncclResult_t r = N->CommInitRank(&c->nccl, world, id, rank);
+  if (r != ncclSuccess) { g_comm_err = std::string("ncclCommInitRank: ") + N->GetErrorString(r); delete c; return TSEM_ERR_HIP; }
+  *out = c;
+  return TSEM_OK;
+}
+
+int tsem_comm_local_group(tsem_local_group** out, int device, int world) {
+  if (!out || world < 1 || world > TS_LOCAL_MAXW) return TSEM_ERR_ARG;
+  *out = nullptr;
+  if (hipSetDevice(device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return TSEM_ERR_HIP; }
+  tsem_local_group* g = new tsem_local_group();
+  g->world = world; g->device = device;
+  for (int q = 0; q < world; ++q)
+    for (int par = 0; par < 2; ++par)
+      if (hipEventCreateWithFlags(&g->ready[q][par], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&g->done[q][par], hipEventDisableTiming) != hipSuccess) {
+        g_comm_err = "hipEventCreate failed"; delete g; return TSEM_ERR_HIP;
+      }
+  *out = g;
+  return TSEM_OK;
+}
+
+void tsem_comm_local_group_destroy(tsem_local_group* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < g->world; ++q)
+    for (int par = 0; par < 2; ++par) {
+      if (g->slot[q][par]) (void)hipFree(g->slot[q][par]);
+      if (g->ready[q][par]) (void)hipEventDestroy(g->ready[q][par]);
+      if (g->done[q][par]) (void)hipEventDestroy(g->done[q][par]);
+    }
+  delete g;
+}
+
+int tsem_comm_create_local(tsem_comm** out, tsem_local_group* g, int rank) {
+  if (!out || !g || rank < 0 || rank >= g->world) return TSEM_ERR_ARG;
+  *out = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->taken[rank]) { g_comm_err = "tsem_comm_create_local: this rank of the group is taken"; return TSEM_ERR_ARG; }
+    g->taken[rank] = true;
+  }
+  tsem_comm* c = new tsem_comm();
+  c->device = g->device; c->rank = rank; c->world = g->world; c->local = g;
   *out = c;
   return TSEM_OK;
 }
@@ -2645,7 +2885,8 @@ void tsem_comm_destroy(tsem_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->d_stage) (void)hipFree(c->d_stage);
-  if (c->nccl) (void)ncclCommDestroy(c->nccl);
+  if (c->nccl) (void)nccl_api()->CommDestroy(c->nccl);
+  if (c->local) { std::lock_guard<std::mutex> lk(c->local->mu); c->local->taken[c->rank] = false; }
   delete c;
 }
 
@@ -2663,7 +2904,7 @@ int tsem_comm_allreduce(tsem_ctx* h, int64_t offset, int64_t count) {
 }
 
 int tsem_comm_allreduce_host(tsem_comm* c, void* data, int64_t count, int dtype) {
-  if (!c || !c->nccl || (!data && count) || count < 0 || dtype < 0 || dtype > 3) return TSEM_ERR_ARG;
+  if (!c || !c->active() || (!data && count) || count < 0 || dtype < 0 || dtype > 3) return TSEM_ERR_ARG;
   if (count == 0) return TSEM_OK;
   if (hipSetDevice(c->device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return TSEM_ERR_HIP; }
   const size_t bytes = (size_t)count * 8;
@@ -2673,14 +2914,16 @@ int tsem_comm_allreduce_host(tsem_comm* c, void* data, int64_t count, int dtype)
     if (hipMalloc(&c->d_stage, bytes) != hipSuccess) { g_comm_err = "hipMalloc failed (all-reduce staging)"; return TSEM_ERR_NOMEM; }
     c->stage_bytes = bytes;
   }
-  const ncclDataType_t dt = dtype == 1 ? ncclUint64 : (dtype == 3 ? ncclInt64 : ncclDouble);
-  const ncclRedOp_t op = dtype >= 2 ? ncclMax : ncclSum;
-  hipError_t e = hipMemcpy(c->d_stage, data, bytes, hipMemcpyHostToDevice);
-  ncclResult_t r = ncclSuccess;
-  if (e == hipSuccess) r = ncclAllReduce(c->d_stage, c->d_stage, (size_t)count, dt, op, c->nccl, nullptr);
-  if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(nullptr);
-  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpy(data, c->d_stage, bytes, hipMemcpyDeviceToHost);
-  if (r != ncclSuccess) { g_comm_err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return TSEM_ERR_HIP; }
+  // Host vectors travel on the null stream.  The same communicator also serves an engine's own stream (tsem_em_chunk);
+  // RCCL wants one stream per communicator at a time, so everything the device still has queued is drained first
+  // (these are set-up and report sums: a device synchronisation costs nothing here).
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(c->d_stage, data, bytes, hipMemcpyHostToDevice);
+  int rc = TSEM_OK;
+  if (e == hipSuccess) rc = comm_allreduce_dev(c, c->d_stage, (size_t)count, dtype, nullptr, g_comm_err);
+  if (rc) return rc;
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  if (e == hipSuccess) e = hipMemcpy(data, c->d_stage, bytes, hipMemcpyDeviceToHost);
   if (e != hipSuccess) { g_comm_err = std::string("all-reduce staging: ") + hipGetErrorString(e); return TSEM_ERR_HIP; }
   return TSEM_OK;
 }
@@ -3054,8 +3297,9 @@ int tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat) 
   TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
   A.colsums = d_cs;
   if (h->N) k_mstep_rows<<<rowpass_grid(h), 256, 0, h->stream>>>(A, d_z);
-  if (h->comm && h->comm->nccl)                             // row-sharded: thetasum over all ranks (model.py:731)
-    TSEM_NCCL(ncclAllReduce(d_cs, d_cs, (size_t)h->K, ncclDouble, ncclSum, h->comm->nccl, h->stream));
+  if (comm_on(h)) {                                         // row-sharded: thetasum over all ranks (model.py:731)
+    if (int rc = comm_allreduce_dev(h->comm, d_cs, (size_t)h->K, 0, h->stream, h->err)) { (void)hipFree(d_z); (void)hipFree(d_cs); return rc; }
+  }
   const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;
   k_hats<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, d_cs, h->d_pisum0, tpw, h->W_amb + tpw * h->K, ppw,
                                                   h->W_tot + ppw * h->K, h->d_tmp_pi, h->d_tmp_theta);
@@ -3082,8 +3326,9 @@ int tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* 
   if (h->N) k_lnl_rows<<<grid, 256, 0, h->stream>>>(A, d_z, h->d_lnl_part);
   k_sum_parts<<<1, 256, 0, h->stream>>>(h->d_lnl_part, h->N ? grid : 0, h->d_lnl_part, 0, h->d_lnl_part + 8000);
   TSEM_HIP(hipGetLastError());
-  if (h->comm && h->comm->nccl)
-    TSEM_NCCL(ncclAllReduce(h->d_lnl_part + 8000, h->d_lnl_part + 8000, 1, ncclDouble, ncclSum, h->comm->nccl, h->stream));
+  if (comm_on(h)) {
+    if (int rc = comm_allreduce_dev(h->comm, h->d_lnl_part + 8000, 1, 0, h->stream, h->err)) { (void)hipFree(d_z); return rc; }
+  }
   TSEM_HIP(hipMemcpyAsync(lnl, h->d_lnl_part + 8000, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
   (void)hipFree(d_z);

@@ -2,10 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and enum values only: the library is resolved at run time (nccl_api, tsem.hip), never linked
 
 #include "telescope_em.h"
 
@@ -162,6 +163,7 @@ struct tsem_ctx {
   double* d_lnls = nullptr;         // [TS_DIFF_RING]
   double *d_pi_first = nullptr, *d_theta_first = nullptr;   // params after the first iteration of the run (model.py:776-778)
   bool first_pending = false;       // the next committed update saves them
+  double lnl_prev_seed = INFINITY;  // lnl the first iteration of the next run is compared with (model.py:683,786)
   int64_t n_fallbacks = 0;          // time-outs answered by switching to the two-pass kernels
 
   // ---- communicator (row-sharded runs) ----
@@ -176,9 +178,14 @@ struct tsem_ctx {
 
 constexpr int TS_DIFF_RING = 65536;
 
+struct tsem_local_group;            // in-process transport: several handles on ONE device (tsem_comm_create_local)
+
 struct tsem_comm {
-  ncclComm_t nccl = nullptr;
+  ncclComm_t nccl = nullptr;        // RCCL transport (one process per GPU)
+  tsem_local_group* local = nullptr;   // in-process transport (tests, several engines sharing a GPU)
   int device = 0, rank = 0, world = 1;
+  uint64_t epoch = 0;               // collectives issued so far (local transport: slot parity)
   void* d_stage = nullptr;          // staging buffer of tsem_comm_allreduce_host
   size_t stage_bytes = 0;
+  bool active() const { return nccl != nullptr || local != nullptr; }
 };

@@ -315,8 +315,12 @@ class TelescopeLikelihood(object):
         eng, comm, K = self._eng, self.comm, self.K
         chunked = getattr(comm, 'in_library', False) and hasattr(eng, 'em_chunk')
         timeouts = 0
+        timing_was = None
         if chunked and not getattr(self, 'keep_kernel_timing', False):
+            timing_was = getattr(eng, 'options', {}).get('kernel_timing', 1)
             eng.set_option('kernel_timing', 0)  # per-pass HIP events are for benchmarks (Engine.kernel_stats), not for em()
+        if chunked and hasattr(eng, 'set_prev_lnl'):
+            eng.set_prev_lnl(self.lnl)          # model.py:786: the first lnl is compared with what the last run left (inf at first)
         while not (converged or reached_max):
             xtime = perf_counter()
             if chunked:
@@ -355,6 +359,8 @@ class TelescopeLikelihood(object):
                     converged = diff_est < self.epsilon
             reached_max = inum >= self.max_iter
             lg.debug("time: {}".format(perf_counter() - xtime))
+        if timing_was is not None:
+            eng.set_option('kernel_timing', timing_was)
         if chunked:
             self.pi_init, self.theta_init = eng.get_params(Z_FIRST)
         self.pi, self.theta = eng.get_params(Z_CUR)

@@ -458,14 +458,13 @@ def test_conflict_aware_row_order_option(gpu_device):
 # ---------------------------------------------------------------------------------------------------
 # report passes: shortcuts from the setup counts, tie compaction for `choose`
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('name', ['bundled', 'tiny_ties', 'tiny_empty_rows', 'mid_zipf_20k'])
+@pytest.mark.parametrize('name', ['bundled', 'tiny_ties', 'tiny_empty_row', 'mid_zipf_20k'])
 def test_report_shortcuts_equal_the_row_pass(gpu_device, name):
     """`all` (initial) and `unique` are answered from counts taken at setup (tsem_reassign, option report_shortcuts);
     the generic row pass must give the same numbers — before and after EM, and a stored score of 0 or parameters set
     by the caller must switch the shortcut off."""
     from conftest import case_names
-    if name not in case_names():
-        pytest.skip('no such golden case')
+    assert name in case_names(), 'no such golden case: %s (a typo here once skipped the empty-row case silently)' % name
     c = load_case(name)
     raw = case_matrix(c)
     fast, slow = _tl_for(raw, Opts(c)), _tl_for(raw, Opts(c), options=(('report_shortcuts', 0),))

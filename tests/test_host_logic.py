@@ -52,6 +52,33 @@ def test_product_path_fails_loudly_without_gpu(built):
         _lib.csr_norm_rows(np.array([0, 1]), np.array([1.0]))
 
 
+@pytest.mark.skipif(has_gpu(), reason='a GPU is present')
+def test_bench_self_launches_its_ranks_and_fails_loudly_without_gpu(built):
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks itself (it used to exit
+    with "must be launched with torch.distributed.run"); here, without a GPU, BOTH ranks must get as far as the
+    engine and die of "no CPU fallback", and the parent must pass the failure on."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert 'must be launched' not in r.stderr + r.stdout
+    assert r.stderr.count('no CPU fallback') == 2, r.stderr[-2000:]
+
+
+def test_rccl_is_resolved_at_run_time_not_linked(built):
+    """One RCCL per process, chosen deliberately (the copy torch already mapped, else the loader's): the shared
+    library must not carry a DT_NEEDED librccl, and must say which copy it resolved."""
+    import subprocess
+    out = subprocess.run(['readelf', '-d', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'NEEDED' in out and 'librccl' not in out
+    info = _lib.comm_library_info()
+    assert info.startswith('rccl ') and ('librccl' in info or 'unavailable' in info), info
+
+
 def test_no_product_import_of_oracle():
     """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
     pkg = os.path.join(ROOT, 'telescope_amd')

@@ -90,11 +90,11 @@ def test_bundled_golden_report_columns():
 
 
 # --- golden vectors captured from the imported reference ---
-@pytest.mark.parametrize('name', case_names())
+@pytest.mark.parametrize('name', [pytest.param(n, marks=pytest.mark.gpu) if n.startswith('mid_uniform') else n
+                                  for n in case_names()])
 def test_oracle_equals_reference_vectors(name):
+    # (mid_uniform_200k takes the oracle ~40 s: it runs with the -m gpu suite, on the GPU box's host cores)
     c = load_case(name)
-    if name.startswith('mid_uniform'):
-        pytest.skip('covered on the GPU box (oracle takes ~40 s here)')
     raw = case_matrix(c)
     o = Opts(c)
     om = orc.OracleModel(raw, o.pi_prior, o.theta_prior)
