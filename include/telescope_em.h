@@ -254,6 +254,11 @@ int  tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out /* 3
 int  tsem_report_ties(tsem_ctx* h, int64_t cap, int32_t* rows, int32_t* counts);
 int  tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const int32_t* rows,
                         const int32_t* picks, int64_t n, double* colsums);
+/* The random picks of `choose` (sparse_plus.py:140-154: np.random.choice per row with several best hits) in numpy's
+ * LEGACY stream, on the host: out[i] = the draw np.random.randint(0, counts[i]) would return, taken in order from the
+ * MT19937 state (key624, *pos) = np.random.get_state()[1:3]; the state is advanced exactly as numpy advances it, so
+ * the caller's stream continues unchanged after np.random.set_state.  counts[i] >= 1 (1 consumes nothing). */
+int  tsem_legacy_randint(uint32_t* key624, int32_t* pos, const int32_t* counts, int64_t n, int32_t* out);
 /* the same assignment summed per GROUP of rows: scTelescope.output_report's per-barcode count matrix
  * `_assignments[_rows, :].sum(0)` for every barcode (model.py:611-625).  group_of_row[i] in
  * [0, n_groups) or -1 (row in no group); out is row-major [n_groups][K], caller-allocated. */

@@ -192,16 +192,21 @@ __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __re
     const double* __restrict__ lut, uint16_t* __restrict__ row_code, uint8_t* __restrict__ row_class,
     double* __restrict__ wsum_part /* [grid][2] */, uint32_t* __restrict__ maxcode,
     double* __restrict__ pisum0, uint32_t* __restrict__ ucount /* [K] unique rows with a positive score per column; [K] = 1 if any stored score is 0 */,
-    int K) {
+    int K, unsigned long long* __restrict__ len_gt /* [6] rows longer than 8, 16, 32, 64, 128, 256 entries */) {
   __shared__ double scratch[16];
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB;
   const int subs = blockDim.x / RS_SUB;
   double wt = 0.0, wa = 0.0;
   int mymax = 0;
+  unsigned lg[6] = {0, 0, 0, 0, 0, 0};
   for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
     int64_t s = indptr[row], e = indptr[row + 1];
     int m = 0;
     bool zero = false;
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) lg[q] += (e - s) > (8 << q) ? 1u : 0u;
+    }
     for (int64_t k = s + lane; k < e; k += RS_SUB) { const int r = (int)raw[k]; m = max(m, r); zero |= r == 0; }
     m = sg_max_i<RS_SUB>(m);
     if (zero) ucount[K] = 1u;                              // (a stored score of 0: the shortcuts of tsem_reassign do not apply)
@@ -218,6 +223,11 @@ __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __re
         if (raw[s]) atomicAdd(&ucount[indices[s]], 1u);
       }
     }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int t = sg_sum_i<64>((int)lg[q]);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(&len_gt[q], (unsigned long long)t);
   }
   double bt = block_sum(wt, scratch);
   double ba = block_sum(wa, scratch);
@@ -285,14 +295,16 @@ __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, 
 // entries of each ambiguous row per column part, packed 8 x 16 bit in two words (fused layout, P <= 8)
 __global__ __launch_bounds__(256) void k_row_partcounts(int64_t N_amb, const int32_t* __restrict__ amb_row,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap,
-    unsigned long long* __restrict__ out /* [N_amb][2] */) {
+    unsigned long long* __restrict__ out /* [N_amb][2] */, uint16_t* __restrict__ rid /* popularity ids (k_report_rows) or null */, int P) {
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
   for (int64_t a = (int64_t)blockIdx.x * subs + sub; a < N_amb; a += (int64_t)gridDim.x * subs) {
     int64_t i = amb_row[a];
     int64_t s = indptr[i], e = indptr[i + 1];
     int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t k = s + lane; k < e; k += RS_SUB) {
-      uint32_t p = colmap[indices[k]] >> 16;
+      const uint32_t cm = colmap[indices[k]];
+      const uint32_t p = cm >> 16;
+      if (rid) rid[k] = (uint16_t)((cm & 0x1FFFu) * P + p);   // the column map is gathered here anyway
 #pragma unroll
       for (int q = 0; q < 8; ++q) c[q] += p == (uint32_t)q;
     }
@@ -1210,6 +1222,331 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
   }
 }
 
+// ---- the report pass: conf | exclude | average of ONE z in one pass (model.py:432-457) ----------------------------
+// Round 2's RP_REPORT ran at 0.07 of the HBM peak (20 ms for 11.8 GB at 50M x 40, profiles/r02_report_kernel_stats.txt):
+// 16 lanes per row, one 4-byte + one 2-byte load per lane and sweep, every load behind the row pointers it depends on,
+// nothing in flight while a row is computed, ~700 instructions per four rows, one pi*theta gather per entry from a
+// 240 KB table in L2 (the vector cache takes ONE gather address per clock and CU: 2e9 gathers = 4 ms by themselves,
+// measured: the same pass without them 3.3 ms), global atomics on popular columns.  What this kernel changes:
+//   * it reads a 2-byte POPULARITY ID per entry (rid16, written while the layout is built: id = slot * P + part of the
+//     column's place in the blocked layout, so small ids are popular columns) and the 2-byte score code: 4 B per entry
+//     instead of 6, and the id indexes LDS tables directly — pi*theta of the HC most popular columns sits in LDS, only
+//     the cold tail is gathered from L2; the winner's scatter needs no column-map lookup; everything is accumulated per
+//     id and mapped back to columns by k_report_finish;
+//   * a lane holds E = 16 (or 8) CONSECUTIVE entries of its row, a row takes G = 1 .. 16 lanes (capacity G x E, chosen
+//     from the row-length histogram so that < 0.5 % of the rows overflow): the per-row work — butterflies, row
+//     pointers, the winner's scatter, loop control — is paid once per 64 / G rows of a wave, the per-entry work is a
+//     dozen instructions with no cross-lane step;
+//   * row pointers are fetched two iterations ahead and the entries one iteration ahead of the row they belong to,
+//     unconditionally (the entry arrays carry padding, rows past the end are clamped), so the next rows' loads are in
+//     flight while a row is reduced; the group reductions are DPP butterflies on the VALU;
+//   * a row has ONE winner in all but the tied rows: with conf_prob > 0.5 the entry with z >= conf_prob, if any, is the
+//     unique best hit.  The lane that holds it does one 32-bit LDS counter increment (`exclude` and the `average` of
+//     rows with one best hit are the same count) and one fp64 LDS add (`conf`); two-way ties (most of the 11 % tied rows of
+//     the initial z) increment a second counter, average = n1 + n2 / 2 + the shares of the wider ties.  Ids beyond the LDS
+//     slots use global atomics.  conf_prob <= 0.5 takes the general per-entry path.
+// Rows longer than G x E entries are appended to a list and reduced by k_report_slow afterwards (same arithmetic); a
+// caller-assigned z, score tables that do not fit LDS and layouts with more than 65536 slots stay on k_rowpass.  Integer
+// outputs are exact; floats differ by summation order only.
+struct ReportArgs {
+  int64_t N, nnz;
+  int32_t K, IDN;                      // ids 0 .. IDN-1 (= P * Kp)
+  const int64_t* indptr;
+  const uint16_t* rid;                 // [nnz + TS_ENTRY_PAD] popularity id of every entry's column
+  const uint16_t* raw;                 // [nnz + TS_ENTRY_PAD] score codes
+  const double* lut; int lut_len;      // staged in LDS (0 < lut_len <= 2048)
+  const double* cnat2;                 // [2 IDN] by id: pi*theta | pi (ambiguous rows use the first half, unique rows the second); null => initial z
+  double thresh;
+  int32_t* nbest;                      // [N] number of best hits per row (0: empty pattern)
+  double *g_conf, *g_n1, *g_n2, *g_avgt;   // [IDN] each, by id
+  int HC, Hs;                          // LDS slots: pi*theta of ids < HC; accumulators of ids < Hs
+  int32_t* defer_rows; unsigned long long* defer_n;   // rows left to k_report_slow
+  int dbg;                             // timing experiments (wrong results): 1 drop the emits that miss the LDS slots, 2 the row-count stores, 4 the ties
+};
+// 16- / 8-byte loads at the natural alignment of their ELEMENTS (a row starts at any entry): plain vector types with
+// a reduced alignment, so the compiler emits one global_load_dwordx4 / dwordx2 (the target allows unaligned access)
+typedef unsigned int rr_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef long long rr_i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+// butterflies over aligned groups of G = 1 .. 16 lanes on the VALU: after the two quad permutes every lane of a quad
+// holds the quad's total, the half-row mirror (lane i <-> 7 - i) then pairs the quads, the row mirror (i <-> 15 - i) the
+// halves.  Every lane of a group must be active.
+constexpr int RR_QP_X1 = 0xB1, RR_QP_X2 = 0x4E, RR_HALF_MIRROR = 0x141, RR_MIRROR = 0x140;
+template <int G> __device__ __forceinline__ double rr_sum(double v) {
+  if (G >= 2) v += fz_dpp_d<RR_QP_X1, 0xF>(v, v);
+  if (G >= 4) v += fz_dpp_d<RR_QP_X2, 0xF>(v, v);
+  if (G >= 8) v += fz_dpp_d<RR_HALF_MIRROR, 0xF>(v, v);
+  if (G >= 16) v += fz_dpp_d<RR_MIRROR, 0xF>(v, v);
+  return v;
+}
+template <int G> __device__ __forceinline__ double rr_max(double v) {
+  if (G >= 2) v = fmax(v, fz_dpp_d<RR_QP_X1, 0xF>(v, v));
+  if (G >= 4) v = fmax(v, fz_dpp_d<RR_QP_X2, 0xF>(v, v));
+  if (G >= 8) v = fmax(v, fz_dpp_d<RR_HALF_MIRROR, 0xF>(v, v));
+  if (G >= 16) v = fmax(v, fz_dpp_d<RR_MIRROR, 0xF>(v, v));
+  return v;
+}
+template <int G> __device__ __forceinline__ int rr_sum_i(int v) {
+  if (G >= 2) v += fz_dpp_i<RR_QP_X1, 0xF>(v, v);
+  if (G >= 4) v += fz_dpp_i<RR_QP_X2, 0xF>(v, v);
+  if (G >= 8) v += fz_dpp_i<RR_HALF_MIRROR, 0xF>(v, v);
+  if (G >= 16) v += fz_dpp_i<RR_MIRROR, 0xF>(v, v);
+  return v;
+}
+
+struct ReportEmit {                                        // where a row's values go (both report kernels), by id
+  const ReportArgs& A; double* hotF; uint32_t* hot1; uint32_t* hot2; int Hs;
+  __device__ __forceinline__ void conf(uint32_t id, double v) const {
+    if ((int)id < Hs) lds_add(&hotF[id], v);
+    else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_conf[id], v);
+  }
+  __device__ __forceinline__ void one(uint32_t id) const {           // the row's only best hit
+    if ((int)id < Hs) atomicAdd(&hot1[id], 1u);
+    else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_n1[id], 1.0);
+  }
+  __device__ __forceinline__ void tie(uint32_t id, int nb, double share) const {   // one of nb > 1 best hits
+    if (nb == 2) {
+      if ((int)id < Hs) atomicAdd(&hot2[id], 1u);
+      else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_n2[id], 1.0);
+    } else {
+      unsafeAtomicAdd(&A.g_avgt[id], share);
+    }
+  }
+};
+
+constexpr int RR_NT = 512;                                 // threads per workgroup (E = 16 needs ~150 VGPRs: 512 threads leave 256)
+template <int G, int E, bool INIT>
+__global__ __launch_bounds__(RR_NT) void k_report_rows(ReportArgs A) {
+  static_assert(E == 8 || E == 16, "entries per lane");
+  extern __shared__ double rr_lds[];   // [lut_len] score table | [HC] pi*theta | [Hs] conf (f64) | [Hs] single winners | [Hs] two-way ties (u32)
+  double* const lutS = rr_lds;
+  double* const cH = lutS + A.lut_len;
+  double* const hotF = cH + A.HC;
+  uint32_t* const hot1 = reinterpret_cast<uint32_t*>(hotF + A.Hs);
+  uint32_t* const hot2 = hot1 + A.Hs;
+  for (int t = threadIdx.x; t < A.lut_len; t += blockDim.x) lutS[t] = A.lut[t];
+  if (!INIT) for (int t = threadIdx.x; t < A.HC; t += blockDim.x) cH[t] = A.cnat2[t];
+  for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) { hotF[t] = 0.0; hot1[t] = 0u; hot2[t] = 0u; }
+  __syncthreads();
+  const ReportEmit EM{A, hotF, hot1, hot2, A.Hs};
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  const int64_t stride = (int64_t)gridDim.x * ngrp;
+  const int64_t nit = (A.N + stride - 1) / stride;
+  const bool one_winner = A.thresh > 0.51;                // an entry with z >= thresh is then the row's unique best hit
+  struct Ip { int64_t s; int len; };
+  struct Ent { rr_u32x4_a2 id[E / 8]; rr_u32x4_a2 cd[E / 8]; };   // 8 ids / 8 codes per 16-byte word
+  auto load_ip = [&](int64_t it) -> Ip {
+    const int64_t row = it * stride + (int64_t)blockIdx.x * ngrp + grp;
+    const int64_t rc = row < A.N ? row : A.N - 1;        // clamped, never branched around
+    const rr_i64x2_a8 se = *reinterpret_cast<const rr_i64x2_a8*>(A.indptr + rc);   // indptr[rc], indptr[rc + 1]
+    Ip r; r.s = se.x; r.len = row < A.N ? (int)min<int64_t>(se.y - se.x, 0x7FFFFFFF) : 0;
+    return r;
+  };
+  auto load_ent = [&](const Ip& p) -> Ent {
+    // lanes past the row's end read the entries that follow it (the arrays carry TS_ENTRY_PAD entries of padding: never
+    // out of bounds)
+    const int64_t k = p.s + E * gl;
+    Ent t;
+#pragma unroll
+    for (int q = 0; q < E / 8; ++q) {
+      t.id[q] = *reinterpret_cast<const rr_u32x4_a2*>(A.rid + k + 8 * q);
+      t.cd[q] = *reinterpret_cast<const rr_u32x4_a2*>(A.raw + k + 8 * q);
+    }
+    return t;
+  };
+  auto half = [](const rr_u32x4_a2* w, int j) -> uint32_t {          // 16-bit element j of the packed words
+    const uint32_t x = w[j / 8][(j / 2) & 3];
+    return (j & 1) ? x >> 16 : x & 0xFFFFu;
+  };
+  // prep: the lane's numerators (the gathers that depend on the entries); finish: everything else.  The loop issues the
+  // NEXT rows' loads between the two, so that waiting for the gathers (loads return in order) does not wait for the
+  // prefetch as well.
+  struct Prep { double n[E]; };
+  auto row_prep = [&](const Ip& p, const Ent& t) -> Prep {
+    const int k0 = E * gl;
+    const bool amb = p.len > 1;                           // ambiguous rows: pi*theta, unique rows: pi (model.py:706-714)
+    Prep q;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const bool v = k0 + j < p.len;
+      double x = lutS[v ? half(t.cd, j) : 0u];             // (lut[0] = expm1(0) = 0: a lane past the row's end holds zeros)
+      if (!INIT) {
+        const uint32_t id = v ? half(t.id, j) : 0u;
+        const bool hot = amb && (int)id < A.HC;
+        // UNCONDITIONAL gather: hot lanes read element 0 (one line for all of them) — a branch around the load would
+        // cost the compiler its count of the loads in flight
+        const double cg = A.cnat2[hot ? 0u : id + (amb ? 0u : (uint32_t)A.IDN)];
+        const double cl = cH[hot ? id : 0u];
+        x = x * (hot ? cl : cg);
+      }
+      q.n[j] = x;
+    }
+    return q;
+  };
+  auto row_finish = [&](int64_t row, const Ip& p, const Ent& t, const Prep& q) {
+    const int k0 = E * gl;
+    const double* n = q.n;
+    // row sum and the largest numerator of z's pattern (INIT: every stored entry; else the non-zero products, model.py:720)
+    double s = 0.0, nm = -1.0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      s += n[j];
+      const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+      nm = in ? fmax(nm, n[j]) : nm;
+    }
+    const double r = recip0(rr_sum<G>(s));
+    nm = rr_max<G>(nm);
+    const bool any = nm >= 0.0;
+    const double zmax = any ? nm * r : -1.0;               // = max_j fl(n_j r): rounding is monotone
+    int nbl = 0; uint32_t wid = 0u;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+      const bool b = in && (n[j] * r == zmax);
+      nbl += b ? 1 : 0;
+      wid = b ? half(t.id, j) : wid;
+    }
+    const int nb = rr_sum_i<G>(nbl);
+    if (gl == 0 && row < A.N && !(A.dbg & 2)) A.nbest[row] = any ? nb : 0;
+    if (one_winner) {
+      if (nbl != 0 && nb == 1) {                           // this lane holds the row's only best hit
+        EM.one(wid);
+        if (zmax >= A.thresh) { const double vc = zmax * recip0(zmax); if (vc != 0.0) EM.conf(wid, vc); }   // vsum = the winner's z
+      }
+      if (__builtin_amdgcn_ballot_w64(nb > 1) != 0ull && !(A.dbg & 4)) {   // tied rows
+        if (nbl == 1 && nb == 2) EM.tie(wid, 2, 0.5);      // (the usual tie: two best hits, this lane holds one of them)
+        if (__builtin_amdgcn_ballot_w64(nb > 1 && !(nbl == 1 && nb == 2) && nbl != 0) != 0ull) {
+          const double share = 1.0 * recip0((double)nb);
+#pragma unroll
+          for (int j = 0; j < E; ++j) {
+            const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+            if (nb > 1 && !(nbl == 1 && nb == 2) && in && n[j] * r == zmax) EM.tie(half(t.id, j), nb, share);
+          }
+        }
+      }
+    } else {                                               // conf_prob <= 0.5: several entries of a row may pass the threshold
+      double vs = 0.0;
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+        const double z = n[j] * r;
+        if (in && z >= A.thresh) vs += z;
+      }
+      const double rv = recip0(rr_sum<G>(vs)), share = 1.0 * recip0((double)nb);
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+        const double z = n[j] * r;
+        if (!in || !(z == zmax || z >= A.thresh)) continue;
+        const uint32_t id = half(t.id, j);
+        if (z >= A.thresh) { const double vc = z * rv; if (vc != 0.0) EM.conf(id, vc); }
+        if (z == zmax) { if (nb == 1) EM.one(id); else EM.tie(id, nb, share); }
+      }
+    }
+  };
+  if (nit > 0) {
+    Ip ip0 = load_ip(0), ip1 = load_ip(1);
+    Ent e0 = load_ent(ip0);
+    for (int64_t it = 0; it < nit; ++it) {
+      const int64_t row = it * stride + (int64_t)blockIdx.x * ngrp + grp;
+      const bool defer = ip0.len > G * E;                  // left to k_report_slow
+      Ip cur = ip0;
+      if (defer) cur.len = 0;
+      const Prep q = row_prep(cur, e0);                    // gathers of this row first ...
+      __builtin_amdgcn_sched_barrier(0);
+      const Ent e1 = load_ent(ip1);                        // ... then the loads of the next rows: they have this row's
+      const Ip ip2 = load_ip(it + 2);                      //     arithmetic to arrive in
+      __builtin_amdgcn_sched_barrier(0);
+      if (defer) {
+        if (gl == 0) A.defer_rows[atomicAdd(A.defer_n, 1ull)] = (int32_t)row;
+      } else {
+        row_finish(row, cur, e0, q);
+      }
+      ip0 = ip1; ip1 = ip2; e0 = e1;
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) {
+    const double v = hotF[t];
+    const uint32_t c1 = hot1[t], c2 = hot2[t];
+    if (v != 0.0) unsafeAtomicAdd(&A.g_conf[t], v);
+    if (c1) unsafeAtomicAdd(&A.g_n1[t], (double)c1);
+    if (c2) unsafeAtomicAdd(&A.g_n2[t], (double)c2);
+  }
+}
+
+// the rows k_report_rows left: any length, sweeps of 16 entries, one 16-lane group per row
+template <bool INIT>
+__global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
+  constexpr int G = 16;
+  const ReportEmit EM{A, nullptr, nullptr, nullptr, 0};  // (no LDS slots here: a handful of rows)
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  const int64_t nd = (int64_t)*A.defer_n;
+  for (int64_t d = (int64_t)blockIdx.x * ngrp + grp; d < nd; d += (int64_t)gridDim.x * ngrp) {
+    const int64_t row = A.defer_rows[d];
+    const int64_t s = A.indptr[row];
+    const int len = (int)(A.indptr[row + 1] - s);
+    const uint32_t coff = len > 1 ? 0u : (uint32_t)A.IDN;
+    auto numer = [&](int k) -> double {
+      double x = A.lut[A.raw[s + k]];
+      if (!INIT) x = x * A.cnat2[A.rid[s + k] + coff];
+      return x;
+    };
+    double y = 0.0;
+    for (int k = gl; k < len; k += G) y += numer(k);
+    const double r = recip0(sg_sum<G>(y));
+    double zmax = -1.0, vs = 0.0; int cnt = 0;
+    for (int k = gl; k < len; k += G) {
+      const double n = numer(k);
+      if (INIT || n != 0.0) { const double z = n * r; zmax = fmax(zmax, z); ++cnt; if (z >= A.thresh) vs += z; }
+    }
+    zmax = sg_max<G>(zmax); cnt = sg_sum_i<G>(cnt);
+    const double vsum = sg_sum<G>(vs);
+    int nb = 0;
+    for (int k = gl; k < len; k += G) { const double n = numer(k); if ((INIT || n != 0.0) && n * r == zmax) ++nb; }
+    nb = sg_sum_i<G>(nb);
+    if (gl == 0) A.nbest[row] = cnt ? nb : 0;
+    const double share = 1.0 * recip0((double)nb);
+    for (int k = gl; k < len; k += G) {
+      const double n = numer(k);
+      if (!(INIT || n != 0.0)) continue;
+      const double z = n * r;
+      if (!(z == zmax || z >= A.thresh)) continue;
+      const uint32_t id = A.rid[s + k];
+      if (z >= A.thresh) { const double vc = z * recip0(vsum); if (vc != 0.0) EM.conf(id, vc); }
+      if (z == zmax) { if (nb == 1) EM.one(id); else EM.tie(id, nb, share); }
+    }
+  }
+}
+// by id -> by column: out[0..K) = conf, out[K..2K) = exclude, out[2K..3K) = average = n1 + n2 / 2 + the wider ties' shares
+__global__ void k_report_finish(int IDN, int K, const int32_t* __restrict__ col_of_id, const double* __restrict__ g_conf,
+                                const double* __restrict__ g_n1, const double* __restrict__ g_n2, const double* __restrict__ g_avgt,
+                                double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= IDN) return;
+  const int j = col_of_id[i];
+  if (j < 0) return;
+  out[j] = g_conf[i]; out[K + j] = g_n1[i]; out[2 * (int64_t)K + j] = (g_n1[i] + 0.5 * g_n2[i]) + g_avgt[i];
+}
+// popularity ids: id = slot * P + part of the column's first slot in the blocked layout (popular columns come first in
+// every part, so small ids are popular columns); cnat2 by id
+__global__ __launch_bounds__(256) void k_rid16_rows(int64_t N, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const uint32_t* __restrict__ colmap, int P, int only_short, uint16_t* __restrict__ rid) {
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int64_t i = (int64_t)blockIdx.x * subs + sub; i < N; i += (int64_t)gridDim.x * subs) {
+    const int64_t s = indptr[i], e = indptr[i + 1];
+    if (only_short && e - s > 1) continue;                 // (the ambiguous rows were written by k_row_partcounts)
+    for (int64_t k = s + lane; k < e; k += RS_SUB) { const uint32_t cm = colmap[indices[k]]; rid[k] = (uint16_t)((cm & 0x1FFFu) * P + (cm >> 16)); }
+  }
+}
+__global__ void k_cnat2_id(int IDN, const int32_t* __restrict__ col_of_id, const double* __restrict__ pi, const double* __restrict__ theta,
+                           double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= IDN) return;
+  const int j = col_of_id[i];
+  out[i] = j >= 0 ? pi[j] * theta[j] : 0.0; out[IDN + i] = j >= 0 ? pi[j] : 0.0;
+}
+
 // mstep(z) on caller-supplied z (model.py:724-742): colsums[j] = sum_i (z_ij * w_i) * Y_i
 __global__ __launch_bounds__(256) void k_mstep_rows(RowPassArgs A, const double* __restrict__ zin) {
   const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
@@ -1435,7 +1772,7 @@ static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
 }
 
 static void free_layout(tsem_ctx* h) {
-  dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_pcode); dfree(h->d_prc);
+  dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_rid16); dfree(h->d_col_of_id); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_pcode); dfree(h->d_prc);
   dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fz_aux); h->fz_clean = false; dfree(h->d_fpartial); dfree(h->d_amb_w); dfree(h->d_sb_q32);
   h->fused_launched = false;
 }
@@ -1523,6 +1860,10 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "kernel_timing") h->opt_timing = v;
   else if (k == "report_shortcuts") h->opt_shortcuts = v;
   else if (k == "rowpass_wgs") h->opt_rowpass_wgs = v;
+  else if (k == "report_kernel") h->opt_report_kernel = v;   // 0: the generic row pass (k_rowpass<RP_REPORT>) instead of k_report_rows
+  else if (k == "report_wgs2") h->opt_report_wgs2 = v;
+  else if (k == "report_dbg") h->opt_report_dbg = v;
+  else if (k == "report_lanes") h->opt_report_lanes = v;     // capacity (lanes per row x entries per lane) of k_report_rows: 8 .. 256 (0 = from the row lengths)
   else if (k == "issue_early") h->opt_issue = v;       // (kept for old scripts; the exchange has one order now)
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
@@ -1593,8 +1934,8 @@ int tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols, const int64_t*
   }
   h->N = n_rows; h->K = n_cols; h->nnz = nnz;
   TSEM_ALLOC(h->d_indptr, n_rows + 1);
-  TSEM_ALLOC(h->d_indices, nnz);
-  TSEM_ALLOC(h->d_raw, nnz);
+  TSEM_ALLOC(h->d_indices, nnz + TS_ENTRY_PAD);           // (k_report_rows reads whole lanes of 16 entries past a row's end)
+  TSEM_ALLOC(h->d_raw, nnz + TS_ENTRY_PAD);
   // plain hipMemcpy from the caller's pageable arrays: 55 GB/s on the GPU box (tools/time_host_upload.py; a pipeline
   // through pinned staging buffers filled by 8 host threads was slower: 37 GB/s)
   TSEM_HIP(hipMemcpy(h->d_indptr, indptr, sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice));
@@ -1657,8 +1998,8 @@ int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_col
   int64_t nnz = 0;
   TSEM_HIP(hipMemcpy(&nnz, h->d_indptr + n, sizeof(int64_t), hipMemcpyDeviceToHost));
   h->nnz = nnz;
-  TSEM_ALLOC(h->d_indices, nnz);
-  TSEM_ALLOC(h->d_raw, nnz);
+  TSEM_ALLOC(h->d_indices, nnz + TS_ENTRY_PAD);
+  TSEM_ALLOC(h->d_raw, nnz + TS_ENTRY_PAD);
   if (n) {
     k_gen_rows<<<cdiv64(n, 128), 128, 0, h->stream>>>(row_begin, n, n_cols, seed, dist, h->d_indptr, h->d_indices, h->d_raw);
     TSEM_HIP(hipGetLastError());
@@ -1799,10 +2140,14 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   TSEM_HIP(hipMemsetAsync(h->d_pisum0, 0, sizeof(double) * K, h->stream));
   TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
   TSEM_HIP(hipMemsetAsync(d_wpart, 0, sizeof(double) * 2 * grid, h->stream));
+  unsigned long long* d_lg = nullptr;
+  TSEM_ALLOC(d_lg, 8);
+  TSEM_HIP(hipMemsetAsync(d_lg, 0, 64, h->stream));
   if (N)
     k_rowstats<<<grid, 256, 0, h->stream>>>(N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, d_code, d_cls,
-                                           d_wpart, h->d_maxcode, h->d_pisum0, h->d_ucount, K);
+                                           d_wpart, h->d_maxcode, h->d_pisum0, h->d_ucount, K, d_lg);
   TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipMemcpyAsync(h->len_gt, d_lg, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   std::vector<double> wpart(2 * grid);
   uint32_t maxcode = 0;
   TSEM_HIP(hipMemcpyAsync(wpart.data(), d_wpart, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, h->stream));
@@ -1864,7 +2209,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
                                                          h->d_uni_code);
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_code); (void)hipFree(d_cls); (void)hipFree(d_wpart); (void)hipFree(d_fa); (void)hipFree(d_fu);
+  (void)hipFree(d_code); (void)hipFree(d_cls); (void)hipFree(d_wpart); (void)hipFree(d_fa); (void)hipFree(d_fu); (void)hipFree(d_lg);
   h->have_rowstats = true;
   return TSEM_OK;
 }
@@ -1921,6 +2266,16 @@ static int build_layout(tsem_ctx* h) {
   TSEM_ALLOC(h->d_col_of_pc, h->Kpad);
   TSEM_HIP(hipMemcpy(h->d_colmap, colmap.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice));
   TSEM_HIP(hipMemcpy(h->d_col_of_pc, col_of_pc.data(), sizeof(int32_t) * h->Kpad, hipMemcpyHostToDevice));
+  // popularity ids for the report pass (k_report_rows): id = slot * P + part, 2 bytes per stored entry
+  const bool want_rid = h->Kpad <= 65536 && h->opt_report_kernel != 0 && h->nnz > 0;
+  if (want_rid) {
+    std::vector<int32_t> col_of_id(h->Kpad, -1);
+    for (int p = 0; p < P; ++p)
+      for (int sl = 0; sl < Kp; ++sl) col_of_id[sl * P + p] = col_of_pc[p * Kp + sl];
+    TSEM_ALLOC(h->d_col_of_id, h->Kpad);
+    TSEM_HIP(hipMemcpy(h->d_col_of_id, col_of_id.data(), sizeof(int32_t) * h->Kpad, hipMemcpyHostToDevice));
+    TSEM_ALLOC(h->d_rid16, h->nnz + TS_ENTRY_PAD);
+  }
   // 3. row blocks.  Two-pass layout: R rows each.  Fused layout: as many consecutive rows as the
   //    register tile takes (no part may exceed FZ_CAP entries, at most R rows) — rows per block vary,
   //    every block still owns R row SLOTS (holes at the end), so all kernels keep b*R+lr indexing.
@@ -1928,11 +2283,13 @@ static int build_layout(tsem_ctx* h) {
   int64_t nb = 0;
   int64_t* d_bs = nullptr;                                 // first compact row of every block, [nb + 1]
   unsigned long long* d_pc = nullptr;                      // per-row part counts (fused layout only)
+  bool rid_amb_done = false;
   if (h->use_fused && na > 0 && P <= FZ_MAX_P) {
     TSEM_ALLOC(d_pc, 2 * na);
     k_row_partcounts<<<(unsigned)std::min<int64_t>(65535, (na + 15) / 16), 256, 0, h->stream>>>(
-        na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc);
+        na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc, h->d_rid16, P);
     TSEM_HIP(hipGetLastError());
+    rid_amb_done = true;
     const int cap = fz_cap(h->geo) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
     const int64_t L = std::max<int64_t>((int64_t)R * 256, (na + 4095) / 4096);
     const int64_t nch = (na + L - 1) / L;
@@ -1970,6 +2327,11 @@ static int build_layout(tsem_ctx* h) {
     nb = (na + R - 1) / R;
     TSEM_ALLOC(d_bs, nb + 1);
     k_fixed_blocks<<<cdiv64(nb + 1, 256), 256, 0, h->stream>>>(nb, R, na, d_bs);
+    TSEM_HIP(hipGetLastError());
+  }
+  if (h->d_rid16 && h->N) {                                // the rows k_row_partcounts did not visit (all of them without the fused layout)
+    k_rid16_rows<<<(unsigned)std::min<int64_t>(65535, (h->N + 15) / 16), 256, 0, h->stream>>>(
+        h->N, h->d_indptr, h->d_indices, h->d_colmap, P, rid_amb_done ? 1 : 0, h->d_rid16);
     TSEM_HIP(hipGetLastError());
   }
   h->nb = nb;
@@ -3164,7 +3526,56 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
     TSEM_ALLOC(d_nb, h->N); TSEM_ALLOC(d_rows, h->N); TSEM_ALLOC(d_n, 1);
     A.thresh = thresh; A.colsums = d_cs; A.nbest = d_nb;
     void (*kern)(RowPassArgs) = k_rowpass<RP_REPORT>;
-    if (h->d_colmap && h->d_col_of_pc && h->P > 0) {
+    if (h->opt_report_kernel != 0 && which != TSEM_Z_USER && h->d_rid16 && h->d_col_of_id && A.lut_len > 0) {
+      // the streaming report kernel (k_report_rows): lanes per row x entries per lane = the smallest capacity that
+      // fewer than 0.5 % of the rows exceed (row-length histogram of tsem_rowstats); the rest goes to k_report_slow
+      const int IDN = h->Kpad;
+      ReportArgs R;
+      R.N = h->N; R.nnz = h->nnz; R.K = K; R.IDN = IDN; R.indptr = h->d_indptr; R.rid = h->d_rid16; R.raw = h->d_raw;
+      R.lut = h->d_lut; R.lut_len = A.lut_len; R.cnat2 = nullptr; R.thresh = thresh; R.nbest = d_nb;
+      const bool init = A.pi == nullptr;
+      double *d_g = nullptr, *d_c2 = nullptr;
+      TSEM_ALLOC(d_g, 4 * (int64_t)IDN);
+      TSEM_HIP(hipMemsetAsync(d_g, 0, sizeof(double) * 4 * IDN, h->stream));
+      if (!init) {
+        TSEM_ALLOC(d_c2, 2 * (int64_t)IDN);
+        k_cnat2_id<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, h->d_col_of_id, A.pi, A.theta, d_c2);
+        R.cnat2 = d_c2;
+      }
+      R.g_conf = d_g; R.g_n1 = d_g + IDN; R.g_n2 = d_g + 2 * (int64_t)IDN; R.g_avgt = d_g + 3 * (int64_t)IDN;
+      // LDS: one workgroup of RR_NT threads per CU (or two, option rowpass_wgs).  The final z wants pi*theta of as many
+      // ids as fit (8 B each) next to a few thousand accumulator slots (16 B each); the initial z has no pi*theta.
+      const int wgs = h->opt_rowpass_wgs >= 2 && h->opt_report_wgs2 ? 2 : 1;
+      const int lds_avail = TS_LDS_MAX / wgs - 2048 - R.lut_len * 8;
+      R.Hs = std::min(IDN, init ? lds_avail / 16 : std::min(3072, lds_avail / 16 / 4));
+      R.HC = init ? 0 : std::max(0, std::min(IDN, (lds_avail - R.Hs * 16) / 8));
+      int cap = 256;                                       // G x E
+      if (h->opt_report_lanes > 0) {
+        cap = (int)h->opt_report_lanes;
+      } else if (h->have_rowstats) {
+        for (int q = 0; q < 6; ++q)
+          if ((double)h->len_gt[q] <= 0.005 * (double)h->N) { cap = 8 << q; break; }
+      }
+      void (*rk)(ReportArgs) = nullptr;
+#define RK(G_, E_) (init ? k_report_rows<G_, E_, true> : k_report_rows<G_, E_, false>)
+      if (cap <= 8) rk = RK(1, 8); else if (cap <= 16) rk = RK(1, 16); else if (cap <= 32) rk = RK(2, 16);
+      else if (cap <= 64) rk = RK(4, 16); else if (cap <= 128) rk = RK(8, 16); else rk = RK(16, 16);
+#undef RK
+      TSEM_HIP(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      R.dbg = (int)h->opt_report_dbg;
+      R.defer_rows = d_rows; R.defer_n = d_n;               // (d_rows is the tie list later: the slow kernel is done with it by then)
+      TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
+      rk<<<h->n_cu * wgs, RR_NT, (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * 16, h->stream>>>(R);
+      TSEM_HIP(hipGetLastError());
+      if (init) k_report_slow<true><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
+      else k_report_slow<false><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
+      TSEM_HIP(hipGetLastError());
+      k_report_finish<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, K, h->d_col_of_id, R.g_conf, R.g_n1, R.g_n2, R.g_avgt, d_cs);
+      TSEM_HIP(hipGetLastError());
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      (void)hipFree(d_g);
+      if (d_c2) (void)hipFree(d_c2);
+    } else if (h->d_colmap && h->d_col_of_pc && h->P > 0) {
       const int wgs = h->opt_rowpass_wgs < 2 ? 1 : 2;
       A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;
       A.Hs = std::max(0, std::min(h->Kp, (int)((TS_LDS_MAX / wgs - 8192 / wgs - 1024 - A.lut_len * 8) / 8 / h->P / 3)));
@@ -3332,6 +3743,52 @@ int tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* 
   TSEM_HIP(hipMemcpyAsync(lnl, h->d_lnl_part + 8000, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
   (void)hipFree(d_z);
+  return TSEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// numpy's LEGACY random stream for `choose` (sparse_plus.py:140-154)
+// ---------------------------------------------------------------------------
+// choose_random draws one np.random.choice per row with several best hits, on numpy's global legacy RandomState — the
+// stream `telescope assign` seeds (telescope_assign.py:429-431).  One draw below a bound c is, in numpy's C
+// (legacy-distributions / _bounded_integers, masked rejection): mask = the smallest 2^b - 1 >= c - 1, then 32-bit
+// Mersenne-Twister outputs until (output & mask) <= c - 1.  np.random.randint(0, counts) on an array does exactly that
+// per element (46 ms for the 5.6e6 tied rows of the 50M-row benchmark: it was the largest item of the whole report);
+// this is the same loop in C on the caller's MT19937 state (np.random.get_state() -> here -> np.random.set_state()),
+// bit for bit the same picks and the same state afterwards (tests/test_host_logic.py).  Host code: the stream is
+// sequential by definition.
+int tsem_legacy_randint(uint32_t* key624, int32_t* pos, const int32_t* counts, int64_t n, int32_t* out) {
+  if (!key624 || !pos || (!counts && n) || (!out && n) || n < 0 || *pos < 0 || *pos > 624) return TSEM_ERR_ARG;
+  constexpr int NN = 624, MM = 397;
+  constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+  uint32_t* mt = key624;
+  int p = *pos;
+  auto refill = [&]() {
+    int kk = 0;
+    for (; kk < NN - MM; ++kk) { const uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER); mt[kk] = mt[kk + MM] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u); }
+    for (; kk < NN - 1; ++kk) { const uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER); mt[kk] = mt[kk + (MM - NN)] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u); }
+    const uint32_t y = (mt[NN - 1] & UPPER) | (mt[0] & LOWER);
+    mt[NN - 1] = mt[MM - 1] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+    p = 0;
+  };
+  auto next32 = [&]() -> uint32_t {
+    if (p == NN) refill();
+    uint32_t y = mt[p++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+  };
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t c = counts[i];
+    if (c <= 0) return TSEM_ERR_ARG;                       // (numpy raises "low >= high")
+    const uint32_t rng = (uint32_t)c - 1u;
+    if (rng == 0) { out[i] = 0; continue; }                // no random number is consumed
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    do { v = next32() & mask; } while (v > rng);
+    out[i] = (int32_t)v;
+  }
+  *pos = p;
   return TSEM_OK;
 }
 

@@ -49,6 +49,7 @@ __host__ __device__ inline uint64_t ts_hash3(uint64_t seed, uint64_t row, uint64
 constexpr int TS_LDS_TABLE_BYTES = 120 * 1024;
 constexpr int TS_MAX_KP = TS_LDS_TABLE_BYTES / 16;   // 7680 columns per part
 constexpr int TS_LDS_MAX = 160 * 1024;
+constexpr int TS_ENTRY_PAD = 320;   // entries of padding behind indices[] / raw[] (k_report_rows reads 16-entry lanes past a row's end)
 constexpr int TS_STRANDS = 16;   // strand-transposed entry order inside a sub-block
 
 struct tsem_ctx {
@@ -87,6 +88,11 @@ struct tsem_ctx {
   bool em_cur = false, em_prev = false;    // current / previous pi, theta come from tsem_set_model or the M-step, not from tsem_set_params
   int64_t opt_issue = -1;                  // fused kernel, exchange wave: partner loads before the combine (1), after it (0), -1 auto
   int64_t opt_rowpass_wgs = 2;             // workgroups per CU of the reassign row pass (modes other than `all`)
+  int64_t opt_report_kernel = 1;           // tsem_report_colsums runs k_report_rows (0: the generic k_rowpass<RP_REPORT>)
+  int64_t opt_report_dbg = 0;
+  int64_t opt_report_wgs2 = 0;             // 1: two of its workgroups per CU with half the LDS tables each (experiments)
+  int64_t opt_report_lanes = 0;            // its capacity per row, lanes x entries per lane (0 = auto)
+  unsigned long long len_gt[6] = {0, 0, 0, 0, 0, 0};   // rows with more than 8, 16, 32, 64, 128, 256 entries (tsem_rowstats)
   int64_t opt_shortcuts = 1;               // tsem_reassign answers `all`(initial) and `unique` from the setup counts
   int32_t* d_twin_rep = nullptr;  // [K] representative column of each exact-twin class
   std::vector<uint64_t> col_count;  // global entries per column
@@ -100,6 +106,8 @@ struct tsem_ctx {
   int64_t nb = 0, N_amb_pad = 0, nnz_pad = 0;
   uint32_t* d_colmap = nullptr;     // [K]    col -> (part<<16 | lcol)
   int32_t* d_col_of_pc = nullptr;   // [Kpad] part*Kp+lcol -> col or -1
+  uint16_t* d_rid16 = nullptr;      // [nnz + TS_ENTRY_PAD] popularity id (slot * P + part) of every stored entry's column: the report pass
+  int32_t* d_col_of_id = nullptr;   // [Kpad] id -> col or -1
   int64_t* d_sb_off = nullptr;      // [nb*P+1] entry offsets (multiples of 4)
   double* d_pval = nullptr;         // [nnz_pad]  Q values (fp64 entry format)
   uint16_t* d_pcode = nullptr;      // [nnz_pad]  raw score codes (code16 entry format: Q = lut[code])

@@ -418,7 +418,7 @@ class TelescopeLikelihood(object):
         parts = self.comm.gather_rows(counts)                 # rank order == global row order
         if self.comm.rank == 0:
             allc = parts[0] if len(parts) == 1 else np.concatenate(parts)
-            draws = np.random.randint(0, allc) if allc.size else np.zeros(0, np.int64)
+            draws = _lib.legacy_randint(allc) if allc.size else np.zeros(0, np.int32)   # == np.random.randint(0, allc), same stream
             cuts = np.cumsum([len(p) for p in parts])[:-1]
             parts = np.split(np.asarray(draws, dtype=np.int32), cuts)
         mine = self.comm.scatter_rows(parts)

@@ -79,6 +79,30 @@ def test_rccl_is_resolved_at_run_time_not_linked(built):
     assert info.startswith('rccl ') and ('librccl' in info or 'unavailable' in info), info
 
 
+def test_legacy_randint_is_numpys_stream(built):
+    """`choose` draws in numpy's legacy global stream (sparse_plus.py:140-154).  The library's C loop must return
+    np.random.randint(0, counts) element for element and leave the global state exactly where numpy leaves it — for any
+    position in the 624-word block, counts of 1 (nothing consumed), powers of two and the rejection cases."""
+    rs = np.random.RandomState(7)
+    for trial, n in enumerate((1, 5, 623, 624, 625, 5000, 200_000)):
+        counts = rs.randint(1, [2, 3, 4, 5, 9, 17, 255, 70000][trial % 8] + 1, size=n).astype(np.int32)
+        counts[::7] = 1
+        np.random.seed(1000 + trial)
+        np.random.random_sample(trial * 37)                # start somewhere inside a block (and leave a cached state alone)
+        np.random.standard_normal(trial % 2)               # odd trials leave a cached Gaussian behind
+        s0 = np.random.get_state()
+        want = np.random.randint(0, counts)
+        s_want = np.random.get_state()
+        np.random.set_state(s0)
+        got = _lib.legacy_randint(counts)
+        s_got = np.random.get_state()
+        assert np.array_equal(got, want)
+        assert s_got[0] == s_want[0] and np.array_equal(s_got[1], s_want[1]) and s_got[2:] == s_want[2:]
+        assert np.random.randint(0, 1 << 30) == (np.random.set_state(s_want) or np.random.randint(0, 1 << 30))
+    with pytest.raises(ValueError):
+        _lib.legacy_randint(np.array([2, 0, 3]))
+
+
 def test_no_product_import_of_oracle():
     """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
     pkg = os.path.join(ROOT, 'telescope_amd')
