@@ -1786,6 +1786,8 @@ static void free_matrix(tsem_ctx* h) {
   dfree(h->d_c32); dfree(h->d_cs32); dfree(h->d_lut32); dfree(h->d_cnat);
   dfree(h->d_ctl); dfree(h->d_ctld); dfree(h->d_lnls); dfree(h->d_pi_first); dfree(h->d_theta_first); dfree(h->d_user_z);
   dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;
+  dfree(h->d_rep_nb); dfree(h->d_rep_rows); dfree(h->d_rep_n);
+  if (h->d_rep_tmp) { (void)hipFree(h->d_rep_tmp); h->d_rep_tmp = nullptr; h->rep_tmp_bytes = 0; }
   h->first_pending = false;
   h->d_red = nullptr;
   h->have_rowstats = h->have_model = false;
@@ -3518,12 +3520,14 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
   if (n_ties) *n_ties = 0;
   const int K = h->K;
   double* d_cs = nullptr;
-  int32_t *d_nb = nullptr, *d_rows = nullptr;
-  unsigned long long* d_n = nullptr;
   TSEM_ALLOC(d_cs, 3 * (int64_t)K);
   TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * 3 * K, h->stream));
   if (h->N) {
-    TSEM_ALLOC(d_nb, h->N); TSEM_ALLOC(d_rows, h->N); TSEM_ALLOC(d_n, 1);
+    // per-row best-hit counts, the compacted tie list and the scan's scratch stay allocated between reports (two N-sized
+    // vectors: allocating and freeing them cost more than the pass's kernels)
+    if (!h->d_rep_nb) { TSEM_ALLOC(h->d_rep_nb, h->N); TSEM_ALLOC(h->d_rep_rows, h->N); TSEM_ALLOC(h->d_rep_n, 1); }
+    int32_t *const d_nb = h->d_rep_nb, *const d_rows = h->d_rep_rows;
+    unsigned long long* const d_n = h->d_rep_n;
     A.thresh = thresh; A.colsums = d_cs; A.nbest = d_nb;
     void (*kern)(RowPassArgs) = k_rowpass<RP_REPORT>;
     if (h->opt_report_kernel != 0 && which != TSEM_Z_USER && h->d_rid16 && h->d_col_of_id && A.lut_len > 0) {
@@ -3589,14 +3593,18 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
     TiedRow pred{d_nb};
     rocprim::counting_iterator<int32_t> first(0);
     TSEM_HIP(rocprim::select(nullptr, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
-    void* tmp = nullptr;
-    TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+    if (h->rep_tmp_bytes < tb || !h->d_rep_tmp) {
+      if (h->d_rep_tmp) (void)hipFree(h->d_rep_tmp);
+      h->d_rep_tmp = nullptr; h->rep_tmp_bytes = 0;
+      TSEM_HIP(hipMalloc(&h->d_rep_tmp, tb ? tb : 1));
+      h->rep_tmp_bytes = tb;
+    }
+    void* const tmp = h->d_rep_tmp;
     TSEM_HIP(rocprim::select(tmp, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
     unsigned long long n = 0;
     TSEM_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipMemcpyAsync(out3K, d_cs, sizeof(double) * 3 * K, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
-    (void)hipFree(tmp);
     if (n) {
       TSEM_ALLOC(h->d_tie_rows, n); TSEM_ALLOC(h->d_tie_cnt, n);
       TSEM_HIP(hipMemcpyAsync(h->d_tie_rows, d_rows, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, h->stream));
@@ -3605,7 +3613,6 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
     }
     h->n_ties = (int64_t)n;
     if (n_ties) *n_ties = (int64_t)n;
-    (void)hipFree(d_nb); (void)hipFree(d_rows); (void)hipFree(d_n);
   } else {
     for (int64_t j = 0; j < 3 * (int64_t)K; ++j) out3K[j] = 0.0;
   }

@@ -151,6 +151,9 @@ struct tsem_ctx {
   int32_t* d_tie_rows = nullptr;    // rows with several best hits, in row order, and their counts: left by the last
   int32_t* d_tie_cnt = nullptr;     // tsem_report_colsums for tsem_report_ties / tsem_reassign_rows
   int64_t n_ties = 0;
+  int32_t *d_rep_nb = nullptr, *d_rep_rows = nullptr;   // [N] scratch of tsem_report_colsums, kept between calls
+  unsigned long long* d_rep_n = nullptr;
+  void* d_rep_tmp = nullptr; size_t rep_tmp_bytes = 0;
   double* d_red = nullptr;          // reduce buffer (K+2), internal or bound
   double* d_red_own = nullptr;
   int64_t red_count = 0;

@@ -402,6 +402,7 @@ class TelescopeLikelihood(object):
         if key not in cache:
             other = [k for k in cache if k[0] == which]
             sums, rows, counts = self._eng.report_colsums(which, thresh)
+            self._dev_ties = (which, len(rows))                  # the device keeps this pass's tie rows until the next one
             flat = self.comm.sum_array(np.concatenate([sums['conf'], sums['exclude'], sums['average']]))
             K = self.K
             rep = {'conf': flat[:K], 'exclude': np.rint(flat[K:2 * K]).astype(np.int64), 'average': flat[2 * K:],
@@ -457,7 +458,8 @@ class TelescopeLikelihood(object):
             if method == 'choose':                               # = exclude + the picked entries of the tied rows
                 rep = self._report(which, self._cached_thresh(which, 0.9))
                 rows, picks = sparse_picks
-                cs = self.comm.sum_array(eng.reassign_rows('choose', thresh, which, rows, picks))
+                on_dev = getattr(self, '_dev_ties', None) == (which, len(rows)) and rows is rep['rows']
+                cs = self.comm.sum_array(eng.reassign_rows('choose', thresh, which, None if on_dev else rows, picks, n=len(rows)))
                 return rep['exclude'] + np.rint(cs).astype(np.int64)
             rep = self._report(which, thresh if method == 'conf' else self._cached_thresh(which, thresh))
             return rep[method].copy()
