@@ -76,9 +76,9 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *   "report_shortcuts" 1 (default): tsem_reassign answers `all` (initial) and `unique` from counts taken at
  *                  setup instead of a pass over the matrix (the same numbers; 0 forces the pass)
  *   "kernel_timing" n: HIP events around every n-th EM pass for tsem_kernel_stats (default 1, 0 = off)
- *   "deconflict"   1: conflict-aware entry order inside the rows of the row-ordered code layout (LDS bank
- *                  conflicts of the column scatter 3.2 -> 2.4 lanes per class: -5 % per EM pass, +14 ms of setup at
- *                  2e9 entries, i.e. worth it beyond ~70 iterations; default 0)
+ *   "deconflict"   conflict-aware entry order inside the rows of the row-ordered code layout (LDS bank conflicts of the
+ *                  column scatter 3.2 -> 2.4 lanes per class: -6 % per EM pass for ~4 ms of setup at 2e9 entries);
+ *                  default -1 = on, 0 = off
  *   "em_precision" 1: the EM pass in fp32 arithmetic (row sums, posteriors and column sums in fp32) — a
  *                  DIAGNOSTIC for the fp32-vs-fp64 tolerance sweep of BASELINE config 3, not a product path
  *   "fused_dbg", "fused_prof", "chunk_blocks"     timing experiments */

@@ -556,90 +556,67 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
 // packed in registers — no LDS, no memory access, no divergent loop.  The permutation is applied while copying
 // the window into fresh arrays.  The padding at the end of a sub-block (code 0) stays where it is.
 constexpr int DC_NT = 256;
+// Round 3: the window lives in REGISTERS (64 packed row/column words + 64 codes) and the chosen entry is swapped into
+// place with selects — every position is a compile-time constant of the unrolled walk.  The round-2 version built a
+// permutation and applied it with 128 scattered loads per window afterwards: 8192 vector-cache address cycles per
+// wave against 1536 for reading the window, which was most of its 14 ms at 2e9 entries.
 __global__ __launch_bounds__(DC_NT) void k_sb_deconflict(int64_t n_win, const uint32_t* __restrict__ prc_in, const uint16_t* __restrict__ code_in,
                                                           uint32_t* __restrict__ prc_out, uint16_t* __restrict__ code_out) {
   for (int64_t w = (int64_t)blockIdx.x * DC_NT + threadIdx.x; w < n_win; w += (int64_t)gridDim.x * DC_NT) {
     const int64_t base = w * 64;
     const uint4* pin = reinterpret_cast<const uint4*>(prc_in + base);
     const uint2* cin = reinterpret_cast<const uint2*>(code_in + base);
-    uint32_t W[8] = {0, 0, 0, 0, 0, 0, 0, 0};              // class (slot mod 16) of entry i: nibble i & 7 of W[i >> 3]
-    uint32_t pm[16];                                       // source index of position i: byte i & 3 of pm[i >> 2]
-    unsigned long long cont = 0ull;                        // bit i: entry i continues the row of entry i-1 (and neither is padding)
-    uint32_t prev_row = 0xFFFFFFFFu;
+    uint32_t P[64], Cd[64];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const uint4 a = pin[q];
       const uint2 cd = cin[q];
-      const uint32_t wd[4] = {a.x, a.y, a.z, a.w};
-      const uint32_t cv[4] = {cd.x & 0xFFFFu, cd.x >> 16, cd.y & 0xFFFFu, cd.y >> 16};
-      pm[q] = (uint32_t)(4 * q) * 0x01010101u + 0x03020100u;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int i = q * 4 + t;
-        W[i >> 3] |= (wd[t] & 15u) << ((i & 7) * 4);
-        const uint32_t row = cv[t] != 0u ? (wd[t] >> 16) : 0xFFFFFFFEu - (uint32_t)i;   // padding never continues anything
-        if (row == prev_row) cont |= 1ull << i;
-        prev_row = row;
-      }
+      P[4 * q] = a.x; P[4 * q + 1] = a.y; P[4 * q + 2] = a.z; P[4 * q + 3] = a.w;
+      Cd[4 * q] = cd.x & 0xFFFFu; Cd[4 * q + 1] = cd.x >> 16; Cd[4 * q + 2] = cd.y & 0xFFFFu; Cd[4 * q + 3] = cd.y >> 16;
     }
+    unsigned long long cont = 0ull;                        // bit i: entry i continues the row of entry i-1 (and neither is padding)
+#pragma unroll
+    for (int i = 1; i < 64; ++i)
+      if (Cd[i] != 0u && Cd[i - 1] != 0u && (P[i] >> 16) == (P[i - 1] >> 16)) cont |= 1ull << i;
     unsigned long long h[4] = {0ull, 0ull, 0ull, 0ull};   // per instruction slot j: 16 four-bit counters, one per class
 #pragma unroll
     for (int pos = 0; pos < 64; ++pos) {
       const int j = pos & 3;
-      const uint32_t c0 = (W[pos >> 3] >> ((pos & 7) * 4)) & 15u;
+      const uint32_t c0 = P[pos] & 15u;
       uint32_t best = 0u, cb = c0, lb = (uint32_t)(h[j] >> (c0 * 4u)) & 15u;
       if (pos + 1 < 64) {
         const bool ok1 = (cont >> (pos + 1)) & 1ull;
-        const uint32_t c1 = (W[(pos + 1) >> 3] >> (((pos + 1) & 7) * 4)) & 15u;
+        const uint32_t c1 = P[pos + 1] & 15u;
         const uint32_t l1 = (uint32_t)(h[j] >> (c1 * 4u)) & 15u;
         if (ok1 && l1 < lb) { best = 1u; cb = c1; lb = l1; }
         if (pos + 2 < 64) {
           const bool ok2 = ok1 && ((cont >> (pos + 2)) & 1ull);
-          const uint32_t c2 = (W[(pos + 2) >> 3] >> (((pos + 2) & 7) * 4)) & 15u;
+          const uint32_t c2 = P[pos + 2] & 15u;
           const uint32_t l2 = (uint32_t)(h[j] >> (c2 * 4u)) & 15u;
           if (ok2 && l2 < lb) { best = 2u; cb = c2; lb = l2; }
         }
-      }
-      // swap entry pos with entry pos + best: classes and source indices (all positions are compile-time constants)
-      {
-        const uint32_t b0 = (pm[pos >> 2] >> ((pos & 3) * 8)) & 0xFFu;
-        if (pos + 1 < 64) {
-          const uint32_t m1c = 15u << (((pos + 1) & 7) * 4), m1p = 0xFFu << (((pos + 1) & 3) * 8);
-          const uint32_t b1 = (pm[(pos + 1) >> 2] >> (((pos + 1) & 3) * 8)) & 0xFFu;
-          uint32_t bsel = b0;
-          if (best == 1u) {
-            W[(pos + 1) >> 3] = (W[(pos + 1) >> 3] & ~m1c) | (c0 << (((pos + 1) & 7) * 4));
-            pm[(pos + 1) >> 2] = (pm[(pos + 1) >> 2] & ~m1p) | (b0 << (((pos + 1) & 3) * 8));
-            bsel = b1;
-          }
-          if (pos + 2 < 64) {
-            const uint32_t m2c = 15u << (((pos + 2) & 7) * 4), m2p = 0xFFu << (((pos + 2) & 3) * 8);
-            const uint32_t b2 = (pm[(pos + 2) >> 2] >> (((pos + 2) & 3) * 8)) & 0xFFu;
-            if (best == 2u) {
-              W[(pos + 2) >> 3] = (W[(pos + 2) >> 3] & ~m2c) | (c0 << (((pos + 2) & 7) * 4));
-              pm[(pos + 2) >> 2] = (pm[(pos + 2) >> 2] & ~m2p) | (b0 << (((pos + 2) & 3) * 8));
-              bsel = b2;
-            }
-          }
-          const uint32_t m0c = 15u << ((pos & 7) * 4), m0p = 0xFFu << ((pos & 3) * 8);
-          W[pos >> 3] = (W[pos >> 3] & ~m0c) | (cb << ((pos & 7) * 4));
-          pm[pos >> 2] = (pm[pos >> 2] & ~m0p) | (bsel << ((pos & 3) * 8));
+        // swap entry pos with entry pos + best (same row: the continuation bits stay valid)
+        const uint32_t tp = P[pos], tc = Cd[pos];
+        if (pos + 2 < 64) {
+          P[pos] = best == 1u ? P[pos + 1] : (best == 2u ? P[pos + 2] : tp);
+          Cd[pos] = best == 1u ? Cd[pos + 1] : (best == 2u ? Cd[pos + 2] : tc);
+          P[pos + 2] = best == 2u ? tp : P[pos + 2];
+          Cd[pos + 2] = best == 2u ? tc : Cd[pos + 2];
+        } else {
+          P[pos] = best == 1u ? P[pos + 1] : tp;
+          Cd[pos] = best == 1u ? Cd[pos + 1] : tc;
         }
+        P[pos + 1] = best == 1u ? tp : P[pos + 1];
+        Cd[pos + 1] = best == 1u ? tc : Cd[pos + 1];
       }
       h[j] += (unsigned long long)(lb < 15u ? 1u : 0u) << (cb * 4u);
     }
-    // apply: out[pos] = in[source of pos] (the window was read a moment ago: these gathers hit L1 / L2)
     uint4* pout = reinterpret_cast<uint4*>(prc_out + base);
     uint2* cout = reinterpret_cast<uint2*>(code_out + base);
 #pragma unroll
-    for (int q4 = 0; q4 < 16; ++q4) {
-      const uint32_t pb = pm[q4];
-      const uint32_t s0 = pb & 0xFFu, s1 = (pb >> 8) & 0xFFu, s2 = (pb >> 16) & 0xFFu, s3 = pb >> 24;
-      uint4 o; uint2 oc;
-      o.x = prc_in[base + s0]; o.y = prc_in[base + s1]; o.z = prc_in[base + s2]; o.w = prc_in[base + s3];
-      oc.x = (uint32_t)code_in[base + s0] | ((uint32_t)code_in[base + s1] << 16);
-      oc.y = (uint32_t)code_in[base + s2] | ((uint32_t)code_in[base + s3] << 16);
-      pout[q4] = o; cout[q4] = oc;
+    for (int q = 0; q < 16; ++q) {
+      pout[q] = make_uint4(P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]);
+      cout[q] = make_uint2(Cd[4 * q] | (Cd[4 * q + 1] << 16), Cd[4 * q + 2] | (Cd[4 * q + 3] << 16));
     }
   }
 }
@@ -2410,7 +2387,7 @@ static int build_layout(tsem_ctx* h) {
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
                                                          d_pc ? d_bs : nullptr, d_pc);
     TSEM_HIP(hipGetLastError());
-    if (h->fmt_code && h->opt_deconflict && off >= 64) {
+    if (h->fmt_code && h->opt_deconflict != 0 && off >= 64) {
       const int64_t n_win = off / 64;
       uint32_t* prc2 = nullptr; uint16_t* code2 = nullptr;
       TSEM_ALLOC(prc2, off); TSEM_ALLOC(code2, off);

@@ -115,8 +115,8 @@ struct tsem_ctx {
   int64_t opt_timing = 1;           // HIP events around every n-th EM pass (tsem_kernel_stats); 0 = none
   int64_t opt_precision = 0;        // 1: the EM pass in fp32 arithmetic (diagnostic for the config-3 tolerance sweep)
   float *d_c32 = nullptr, *d_cs32 = nullptr, *d_lut32 = nullptr;
-  int64_t opt_deconflict = 0;       // 1: conflict-aware entry order inside the rows of the row-ordered code layout (k_sb_deconflict):
-                                    //    -5 % per EM pass for +14 ms of setup at 50M x 40 (pays after ~70 iterations), hence opt-in
+  int64_t opt_deconflict = -1;      // conflict-aware entry order inside the rows of the row-ordered code layout (k_sb_deconflict): -1 auto = on
+                                    //    (round 3: 4 ms of setup at 2e9 entries for -6 % per EM pass; round 2's version cost 14 ms and was opt-in)
   int64_t opt_geo = -1;             // -1 auto; 0 / 2 force the geometry of teams of 1-4 (experiments)
   double run_len_est = 0.0;         // mean entries per ambiguous row and column part (set by tsem_rowstats)
   bool sorted_layout = false;       // sub-blocks stored in row order (k_sb_fill_sorted)

@@ -59,6 +59,9 @@ constexpr int FZ_LAG = 3 + FZ_GAP;     // scatter lag (steps) = FZ_NS - FZ_DL
 constexpr int FZ_YR = 4;               // y ring: row sums of block k live from step k to k+3 (combine), GAP = 1
 constexpr int FZ_XS = 8;               // exchange slots per team (ring)
 constexpr unsigned FZ_SPIN_LIMIT = 2000000u;
+#ifndef FZ_SKIP_IDLE_WAVES
+#define FZ_SKIP_IDLE_WAVES 1
+#endif
 constexpr int FZ_PROF_SLOTS = 16;
 
 // sync words (uint32): [0..7] per-XCD tickets, [8] registered WGs, [9] error
@@ -582,9 +585,23 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       const bool pr = A.prof && team == 0 && p == 0 && tid == 0 && (int)i < A.prof_blocks;
       if (pr) A.prof[i * FZ_PROF_SLOTS + 0] = clock64();
       const int64_t k2 = i - FZ_LAG;
-      // ---- gathers ----
       const uint32_t on0 = offs[((i + FZ_DL + 1) & 7) * 2], on1 = offs[((i + FZ_DL + 1) & 7) * 2 + 1];   // burst of the NEXT step
       const bool idle2 = rs.rc.x == 0xFFFFFFFFu;
+      // (padding has code 0 / value 0 -> numerator 0: no branch needed around the products)
+      const bool idle = FMT == 1 ? (rp.cd.x | rp.cd.y) == 0u
+                                 : (rp.v0.x == 0.0) & (rp.v0.y == 0.0) & (rp.v1.x == 0.0) & (rp.v1.y == 0.0);
+      // A WAVE whose lanes hold nothing in either set — the tail waves of a sub-block that short rows cannot fill: at
+      // 10 entries per row 768 row slots fill 58 % of the register tile — skips the step's LDS work altogether.  The
+      // step has a floor of LDS instruction ISSUE (~22 wave-instructions per data wave, ~8 clk each even with every lane
+      // masked); idle waves used to pay it in full.  (Wave-uniform branch around LDS operations only: the
+      // streaming loads below stay unconditional.)
+      const bool wave_idle = FZ_SKIP_IDLE_WAVES && GEO == 2 &&   // (only the short-row geometry leaves whole waves idle; elsewhere the branch costs 1.5 %)
+                             (__builtin_amdgcn_ballot_w64(!idle) | __builtin_amdgcn_ballot_w64(!idle2)) == 0ull;
+      if (wave_idle) {
+        rp.rc.x = 0xFFFFFFFFu;
+        if (pr) { A.prof[i * FZ_PROF_SLOTS + 1] = clock64(); A.prof[i * FZ_PROF_SLOTS + 3] = clock64(); }
+      } else {
+      // ---- gathers ----
       const uint32_t a0 = idle2 ? 0u : rs.rc.x, a1 = rs.rc.y, a2 = rs.rc.z, a3 = rs.rc.w;
       const double* sb = s + (k2 & 1) * R;
       // (Row order: gathering only the outer two row factors of a lane when no lane of the wave spans three rows
@@ -593,15 +610,17 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       // compares and the selects cost more issue slots than the two broadcast reads they save.)
       const double s0 = sb[a0 >> 16], s1 = sb[a1 >> 16], s2 = sb[a2 >> 16], s3 = sb[a3 >> 16];
       double2 q0 = rp.v0, q1 = rp.v1;
+#ifdef FZ_EXPERIMENT   // upper bounds (WRONG RESULTS): what conflict-free LDS accesses would buy, per kind of access
+      const uint32_t xm_l = (A.dbg & 128) ? 3u : 0xFFFFu, xm_c = (A.dbg & 256) ? 31u : 0xFFFFu;
+#else
+      constexpr uint32_t xm_l = 0xFFFFu, xm_c = 0xFFFFu;
+#endif
       if (FMT == 1) {                                     // Q from the score table: the same fp64 the fp64 layout stores
-        q0 = make_double2(lutS[rp.cd.x & 0xFFFFu], lutS[rp.cd.x >> 16]);
-        q1 = make_double2(lutS[rp.cd.y & 0xFFFFu], lutS[rp.cd.y >> 16]);
+        q0 = make_double2(lutS[rp.cd.x & xm_l], lutS[(rp.cd.x >> 16) & xm_l]);
+        q1 = make_double2(lutS[rp.cd.y & xm_l], lutS[(rp.cd.y >> 16) & xm_l]);
       }
-      const double c0 = c[rp.rc.x & 0xFFFF], c1 = c[rp.rc.y & 0xFFFF], c2 = c[rp.rc.z & 0xFFFF], c3 = c[rp.rc.w & 0xFFFF];
+      const double c0 = c[rp.rc.x & xm_c], c1 = c[rp.rc.y & xm_c], c2 = c[rp.rc.z & xm_c], c3 = c[rp.rc.w & xm_c];
       // ---- phase 1 of block i: numerators stay in the set, partial row sums into y(i) ----
-      // (padding has code 0 / value 0 -> numerator 0: no branch needed around the products)
-      const bool idle = FMT == 1 ? (rp.cd.x | rp.cd.y) == 0u
-                                 : (rp.v0.x == 0.0) & (rp.v0.y == 0.0) & (rp.v1.x == 0.0) & (rp.v1.y == 0.0);
       const double m0 = q0.x * c0, m1 = q0.y * c1, m2 = q1.x * c2, m3 = q1.y * c3;
       rp.v0 = make_double2(m0, m1); rp.v1 = make_double2(m2, m3);
       double* yb = y + (i & (FZ_YR - 1)) * R;
@@ -620,12 +639,19 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       // ---- phase 2 of block i-LAG: w*z into the part's column accumulators; ALWAYS four atomics, issued last ----
       {
         const uint32_t dj = (uint32_t)(dum - acc) + (uint32_t)lane_id;   // the lane's dummy slot as an index into acc[]
+#ifdef FZ_EXPERIMENT
+        const bool xa = (A.dbg & 512) != 0;                // every lane its own slot: no conflicts, no shared addresses
+        const uint32_t j0 = (idle2 | xa) ? dj : (a0 & 0xFFFFu), j1 = (idle2 | xa) ? dj : (a1 & 0xFFFFu);
+        const uint32_t j2 = (idle2 | xa) ? dj : (a2 & 0xFFFFu), j3 = (idle2 | xa) ? dj : (a3 & 0xFFFFu);
+#else
         const uint32_t j0 = idle2 ? dj : (a0 & 0xFFFFu), j1 = idle2 ? dj : (a1 & 0xFFFFu);
         const uint32_t j2 = idle2 ? dj : (a2 & 0xFFFFu), j3 = idle2 ? dj : (a3 & 0xFFFFu);
+#endif
         lds_add(&acc[j0], rs.v0.x * s0);
         lds_add(&acc[j1], rs.v0.y * s1);
         lds_add(&acc[j2], rs.v1.x * s2);
         lds_add(&acc[j3], rs.v1.y * s3);
+      }
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);

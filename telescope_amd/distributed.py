@@ -217,7 +217,7 @@ class Comm(object):
         buffer inside `em_chunk` and nothing below is used.  Otherwise (gloo + the tests-only engine):
         give the engine a reduce buffer that torch can all-reduce in place."""
         self._eng = engine
-        if self.lib is not None and hasattr(engine, 'comm_attach'):
+        if self.lib is not None:
             engine.comm_attach(self.lib.handle)
             self.in_library = True
             return

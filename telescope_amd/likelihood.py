@@ -313,13 +313,13 @@ class TelescopeLikelihood(object):
         msgL = 'Iteration {:d}, lnl= {:.5e}, diff={:.5g}'
         from time import perf_counter
         eng, comm, K = self._eng, self.comm, self.K
-        chunked = getattr(comm, 'in_library', False) and hasattr(eng, 'em_chunk')
+        chunked = getattr(comm, 'in_library', False)          # the engine all-reduces by itself: whole chunks per host round trip
         timeouts = 0
         timing_was = None
         if chunked and not getattr(self, 'keep_kernel_timing', False):
             timing_was = getattr(eng, 'options', {}).get('kernel_timing', 1)
             eng.set_option('kernel_timing', 0)  # per-pass HIP events are for benchmarks (Engine.kernel_stats), not for em()
-        if chunked and hasattr(eng, 'set_prev_lnl'):
+        if chunked:
             eng.set_prev_lnl(self.lnl)          # model.py:786: the first lnl is compared with what the last run left (inf at first)
         while not (converged or reached_max):
             xtime = perf_counter()
@@ -427,14 +427,8 @@ class TelescopeLikelihood(object):
 
     def _picks(self, which):
         """(rows, picks) of the tied rows for `choose` (sparse); consumes the caller's RNG stream NOW."""
-        eng = self._eng
-        if hasattr(eng, 'report_colsums'):                    # compacted on the device: only the tied rows travel
-            rep = self._report(which, self._cached_thresh(which, 0.9))
-            rows, counts = rep['rows'], rep['counts']
-        else:                                                 # (tests-only oracle engine)
-            nbest = eng.best_counts(which)
-            rows = np.flatnonzero(nbest > 1).astype(np.int32)
-            counts = nbest[rows]
+        rep = self._report(which, self._cached_thresh(which, 0.9))   # compacted on the device: only the tied rows travel
+        rows, counts = rep['rows'], rep['counts']
         return rows, self._draw_picks(counts)
 
     def _dense_picks(self, sparse):
@@ -453,8 +447,7 @@ class TelescopeLikelihood(object):
 
     def _colsums(self, method, thresh, which, sparse_picks):
         eng = self._eng
-        if hasattr(eng, 'report_colsums') and method in ('conf', 'exclude', 'average', 'choose') \
-                and which != Z_USER:
+        if method in ('conf', 'exclude', 'average', 'choose') and which != Z_USER:
             if method == 'choose':                               # = exclude + the picked entries of the tied rows
                 rep = self._report(which, self._cached_thresh(which, 0.9))
                 rows, picks = sparse_picks

@@ -113,6 +113,26 @@ class OracleShardEngine(object):
         v = orc.binmax_rows(self._z(which))
         return np.diff(v.indptr).astype(np.int32)
 
+    def report_colsums(self, which, thresh):
+        """Engine.report_colsums: conf | exclude | average of one z and the rows with several best hits."""
+        self.om.z = self._z(which)
+        sums = {m: np.asarray(self.om.reassign(m, thresh, initial=False).sum(0)).ravel().astype(np.float64)
+                for m in ('conf', 'exclude', 'average')}
+        nbest = self.best_counts(which)
+        rows = np.flatnonzero(nbest > 1).astype(np.int32)
+        self._ties = rows
+        return sums, rows, nbest[rows].astype(np.int32)
+
+    def reassign_rows(self, method, thresh, which, rows, picks, n=None):
+        """Engine.reassign_rows for `choose`: the picked best hit of every listed (tied) row."""
+        assert method == 'choose'
+        rows = self._ties if rows is None else np.asarray(rows)
+        v = orc.binmax_rows(self._z(which))
+        cs = np.zeros(self.K)
+        for r, pk in zip(rows, np.asarray(picks)):
+            cs[v.indices[v.indptr[r] + int(pk)]] += 1.0
+        return cs
+
     def reassign(self, method, thresh, which, picks=None, want_mask=False):
         self.om.z = self._z(which)
         if method == 'choose':
