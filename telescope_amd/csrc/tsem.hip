@@ -268,6 +268,13 @@ constexpr int SIG_WIN = 18432;      // 8 B of LDS per column: 147 KB
 // accumulated sums agree to 1e-12, so a 32-bit signature is a filter, not the proof.  (Round 1: a 32-bit counter and
 // a 64-bit hash, 12 B per column: three passes over the matrix at K = 30k instead of two, and two atomics per entry:
 // 29 -> 14 ms at 2e9 entries.)
+// Round 3: G lanes per row, SIXTEEN consecutive entries per lane (two 16-byte loads of column ids... four, and two of
+// scores), the row half of the hash formed once per lane — the round-2 kernel (16 lanes per row, one 4-byte and one
+// 2-byte load per lane and step, both hash rounds per entry) took 9.9 ms per sweep at 2e9 entries, bound by instruction
+// issue like the row pass it resembled.  Same signature values.
+typedef unsigned int cs_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int cs_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+template <int G>
 __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, const int64_t* __restrict__ indptr,
     const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw, int col_base, int K,
     unsigned long long* __restrict__ counts, unsigned long long* __restrict__ hashes) {
@@ -275,13 +282,27 @@ __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, 
   unsigned long long* hh = reinterpret_cast<unsigned long long*>(smem);
   for (int t = threadIdx.x; t < SIG_WIN; t += blockDim.x) hh[t] = 0;
   __syncthreads();
-  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
-  for (int64_t i = (int64_t)blockIdx.x * subs + sub; i < N; i += (int64_t)gridDim.x * subs) {
-    int64_t s = indptr[i], e = indptr[i + 1];
-    for (int64_t k = s + lane; k < e; k += RS_SUB) {
-      int c = indices[k] - col_base;
-      if (c >= 0 && c < SIG_WIN)
-        atomicAdd(&hh[c], (ts_hash3(0x7715ull, (uint64_t)(row_offset + i), (uint64_t)raw[k]) & 0xFFFFFFFF00000000ull) | 1ull);
+  constexpr int E = 16;
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  for (int64_t i = (int64_t)blockIdx.x * ngrp + grp; i < N; i += (int64_t)gridDim.x * ngrp) {
+    const int64_t s = indptr[i];
+    const int len = (int)(indptr[i + 1] - s);
+    const uint64_t hrow = ts_mix64(0x7715ull ^ ((uint64_t)(row_offset + i) * TS_GOLDEN));   // the row half of ts_hash3
+    for (int k0 = E * gl; k0 < len; k0 += E * G) {         // (the arrays carry TS_ENTRY_PAD entries of padding)
+      cs_u32x4_a4 ix[4]; cs_u32x4_a2 cd[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ix[q] = *reinterpret_cast<const cs_u32x4_a4*>(indices + s + k0 + 4 * q);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) cd[q] = *reinterpret_cast<const cs_u32x4_a2*>(raw + s + k0 + 8 * q);
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const int c = (int)ix[j / 4][j & 3] - col_base;
+        if (k0 + j < len && c >= 0 && c < SIG_WIN) {
+          const uint32_t w = cd[j / 8][(j / 2) & 3];
+          const uint64_t r = (j & 1) ? w >> 16 : w & 0xFFFFu;
+          atomicAdd(&hh[c], (ts_mix64(hrow ^ (r * TS_M1)) & 0xFFFFFFFF00000000ull) | 1ull);
+        }
+      }
     }
   }
   __syncthreads();
@@ -292,29 +313,56 @@ __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, 
     }
 }
 
-// entries of each ambiguous row per column part, packed 8 x 16 bit in two words (fused layout, P <= 8)
+// entries of each ambiguous row per column part, packed 8 x 16 bit in two words (fused layout, P <= 8); the popularity
+// ids of the report pass are written on the way (the column map is gathered here anyway).  G lanes per row, sixteen
+// consecutive entries per lane (round 2: 16 lanes per row, one entry per lane and step: 8.3 ms at 2e9 entries).
+template <int G>
 __global__ __launch_bounds__(256) void k_row_partcounts(int64_t N_amb, const int32_t* __restrict__ amb_row,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap,
     unsigned long long* __restrict__ out /* [N_amb][2] */, uint16_t* __restrict__ rid /* popularity ids (k_report_rows) or null */, int P) {
-  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
-  for (int64_t a = (int64_t)blockIdx.x * subs + sub; a < N_amb; a += (int64_t)gridDim.x * subs) {
-    int64_t i = amb_row[a];
-    int64_t s = indptr[i], e = indptr[i + 1];
-    int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t k = s + lane; k < e; k += RS_SUB) {
-      const uint32_t cm = colmap[indices[k]];
-      const uint32_t p = cm >> 16;
-      if (rid) rid[k] = (uint16_t)((cm & 0x1FFFu) * P + p);   // the column map is gathered here anyway
+  constexpr int E = 16;
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  for (int64_t a = (int64_t)blockIdx.x * ngrp + grp; a < N_amb; a += (int64_t)gridDim.x * ngrp) {
+    const int64_t i = amb_row[a];
+    const int64_t s = indptr[i];
+    const int len = (int)(indptr[i + 1] - s);
+    unsigned long long lo = 0, hi = 0;                     // 4 x 16-bit counters each (a lane sees at most 16 entries per step; rows < 65536)
+    for (int k0 = E * gl; k0 < len; k0 += E * G) {
+      cs_u32x4_a4 ix[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) c[q] += p == (uint32_t)q;
-    }
-    unsigned long long lo = 0, hi = 0;
+      for (int q = 0; q < 4; ++q) ix[q] = *reinterpret_cast<const cs_u32x4_a4*>(indices + s + k0 + 4 * q);
+      uint32_t cm[E];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      int v = min(sg_sum_i<RS_SUB>(c[q]), 65535);
-      if (q < 4) lo |= (unsigned long long)v << (16 * q); else hi |= (unsigned long long)v << (16 * (q - 4));
+      for (int j = 0; j < E; ++j) cm[j] = colmap[k0 + j < len ? ix[j / 4][j & 3] : 0u];
+      uint32_t idv[E];
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const uint32_t p = cm[j] >> 16;
+        idv[j] = (cm[j] & 0x1FFFu) * P + p;
+        if (k0 + j < len) {
+          const unsigned long long one = 1ull << (16 * (p & 3));
+          if (p < 4) lo += one; else hi += one;
+        }
+      }
+      if (rid) {
+        if (k0 + E <= len) {                               // a full lane: two 16-byte stores instead of sixteen 2-byte ones
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            cs_u32x4_a2 w;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = idv[8 * q + 2 * t] | (idv[8 * q + 2 * t + 1] << 16);
+            *reinterpret_cast<cs_u32x4_a2*>(rid + s + k0 + 8 * q) = w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < E; ++j) if (k0 + j < len) rid[s + k0 + j] = (uint16_t)idv[j];
+        }
+      }
     }
-    if (lane == 0) { out[2 * a] = lo; out[2 * a + 1] = hi; }
+    // sums over the group (the packed 16-bit fields cannot carry into each other: a row has fewer than 65536 entries)
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { lo += __shfl_xor(lo, o, G); hi += __shfl_xor(hi, o, G); }
+    if (gl == 0) { out[2 * a] = lo; out[2 * a + 1] = hi; }
   }
 }
 
@@ -2145,10 +2193,17 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     TSEM_HIP(hipMemsetAsync(d_hash, 0, sizeof(unsigned long long) * K, h->stream));
     if (N) {
       const int lds = SIG_WIN * 8;
-      TSEM_HIP(hipFuncSetAttribute((const void*)k_colsig, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      // lanes per row from the row-length histogram taken a moment ago: 16 entries per lane, the smallest group that
+      // takes 99.5 % of the rows in one step (longer rows loop)
+      int cap = 256;
+      for (int q = 1; q < 6; ++q)
+        if ((double)h->len_gt[q] <= 0.005 * (double)N) { cap = 8 << q; break; }
+      void (*ck)(int64_t, int64_t, const int64_t*, const int32_t*, const uint16_t*, int, int, unsigned long long*, unsigned long long*) =
+          cap <= 16 ? k_colsig<1> : cap <= 32 ? k_colsig<2> : cap <= 64 ? k_colsig<4> : cap <= 128 ? k_colsig<8> : k_colsig<16>;
+      TSEM_HIP(hipFuncSetAttribute((const void*)ck, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       int g2 = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, (N + 63) / 64));
       for (int base = 0; base < K; base += SIG_WIN)
-        k_colsig<<<g2, 1024, lds, h->stream>>>(N, h->row_offset, h->d_indptr, h->d_indices, h->d_raw, base, K, d_cnt, d_hash);
+        ck<<<g2, 1024, lds, h->stream>>>(N, h->row_offset, h->d_indptr, h->d_indices, h->d_raw, base, K, d_cnt, d_hash);
       TSEM_HIP(hipGetLastError());
     }
     TSEM_HIP(hipMemcpyAsync(col_count, d_cnt, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
@@ -2265,8 +2320,15 @@ static int build_layout(tsem_ctx* h) {
   bool rid_amb_done = false;
   if (h->use_fused && na > 0 && P <= FZ_MAX_P) {
     TSEM_ALLOC(d_pc, 2 * na);
-    k_row_partcounts<<<(unsigned)std::min<int64_t>(65535, (na + 15) / 16), 256, 0, h->stream>>>(
-        na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc, h->d_rid16, P);
+    {
+      int capc = 256;                                      // lanes per row x 16 entries, from the row-length histogram
+      for (int q = 1; q < 6; ++q)
+        if ((double)h->len_gt[q] <= 0.005 * (double)h->N) { capc = 8 << q; break; }
+      const int G = capc <= 16 ? 1 : capc <= 32 ? 2 : capc <= 64 ? 4 : capc <= 128 ? 8 : 16;
+      const unsigned grid = (unsigned)std::min<int64_t>(65535, (na + 256 / G - 1) / (256 / G));
+      auto pk = G == 1 ? k_row_partcounts<1> : G == 2 ? k_row_partcounts<2> : G == 4 ? k_row_partcounts<4> : G == 8 ? k_row_partcounts<8> : k_row_partcounts<16>;
+      pk<<<grid, 256, 0, h->stream>>>(na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc, h->d_rid16, P);
+    }
     TSEM_HIP(hipGetLastError());
     rid_amb_done = true;
     const int cap = fz_cap(h->geo) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
