@@ -268,6 +268,13 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   auto combine = [&](Gen& g, int64_t k, int64_t ko) {
     if (offw && lane < 2 && ko >= 5 && ko < nblk) offs[(ko & 7) * 2 + lane] = g.off;   // blocks 0..4: prologue
     if (k < 0 || k >= nblk) return;
+#ifdef FZ_EXPERIMENT
+    if (A.dbg & 2048) return;                             // timing experiment: no combine at all (s stays 0, members free-run)
+#endif
+    // (Round 3 tried carrying this member's OWN sums in registers from the publish to the combine, zeroing y at the
+    // publish: two LDS operations and one LDS wait less per step — and 2.3x the tag misses, code16 3.33 -> 3.37 ms, fp64
+    // unchanged, with one or two steps of gap alike (profiles/r03_exchange_bounds.txt): what the combine costs is
+    // WAITING for the slowest member of the team, not its LDS traffic.)
     const unsigned long long tag = tag_of(k);
 #pragma unroll
     for (int j = 0; j < FZ_RP; ++j) {
@@ -345,7 +352,12 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       const int64_t kp = i - 1;
       const bool pv = kp >= 0 && kp < nblk;
       const unsigned long long tag = tag_of(kp);
-      __amdgpu_buffer_rsrc_t xs = fz_rsrc(xbase, 0, pv ? (unsigned)(FZ_XS * P * R * 8) : 0u);   // (an empty resource drops the store)
+#ifdef FZ_EXPERIMENT
+      const bool xnp = (A.dbg & 1024) != 0;               // timing experiment: publish stores dropped
+#else
+      constexpr bool xnp = false;
+#endif
+      __amdgpu_buffer_rsrc_t xs = fz_rsrc(xbase, 0, (pv && !xnp) ? (unsigned)(FZ_XS * P * R * 8) : 0u);   // (an empty resource drops the store)
 #pragma unroll
       for (int j = 0; j < FZ_RP; ++j) {
         const int r = min(rlo + 2 * (lane + 64 * j), R - 2);   // lanes past the last row pair store row pair R-2 again (same bytes)
