@@ -471,6 +471,9 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   __syncthreads();
 
   double lsum = 0.0;                                      // lnl mode: this thread's share of the sum
+#ifdef FZ_EXPERIMENT
+  const unsigned long long fz_t0 = clock64();
+#endif
   if (tid >= FZ_DT) {
     // ============================ exchange wave ===============================
     // dispatched on the member index so every register array is statically indexed
@@ -721,6 +724,12 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     }
     return;
   }
+#ifdef FZ_EXPERIMENT
+  if ((A.dbg & 4096) && A.prof && tid == 0) {             // per-member loop time (cycles) and blocks: prof[(team*P+p)*2 ..]
+    A.prof[(team * P + p) * 2] = clock64() - fz_t0;
+    A.prof[(team * P + p) * 2 + 1] = (unsigned long long)nblk;
+  }
+#endif
   double* out = A.partial + (int64_t)team * (P * Kp) + p * Kp;
   for (int t = tid; t < Kp; t += FZ_NT) out[t] = acc[t];
 }
