@@ -16,7 +16,11 @@ def lap(name):
     eng.synchronize(); t.append(time.perf_counter()); print('%-40s %8.1f ms' % (name, (t[-1] - t[-2]) * 1e3))
 sums, r, c = eng.report_colsums(Z_INITIAL, 0.9); lap('report pass + tie list to the host (%d tied rows)' % len(r))
 np.random.seed(1)
-d = np.random.randint(0, c); lap('np.random.randint(0, counts)')
+d = np.random.randint(0, c); lap('np.random.randint(0, counts)  [numpy, for comparison]')
+from telescope_amd import _lib
+np.random.seed(1)
+d2 = _lib.legacy_randint(c); lap('_lib.legacy_randint(counts)    [what choose uses: same picks, same state]')
+assert np.array_equal(d, d2)
 d = d.astype(np.int32); lap('astype int32')
 cs = eng.reassign_rows('choose', 0.9, Z_INITIAL, r, d); lap('reassign_rows (upload rows + picks, kernel)')
 cs = eng.reassign_rows('choose', 0.9, Z_INITIAL, None, d, n=len(r)); lap('reassign_rows (rows left on the device)')
