@@ -513,12 +513,15 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
 // a thread's four consecutive entries and its neighbours' mostly share a row and the row sums can be
 // reduced in registers / across lanes instead of one LDS atomic per entry (tsem_fused.h, phase 1).
 // The padding at the end of a sub-block repeats the last row with value 0.
+constexpr int FILL_MAX_RP = 1152 * 4;                      // row slots x parts of a block the row-order fill can take
 __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
     const double* __restrict__ lut, const uint32_t* __restrict__ colmap, const int64_t* __restrict__ sb_off,
     double* __restrict__ pval, uint16_t* __restrict__ pcode, uint32_t* __restrict__ prc,
-    const int64_t* __restrict__ bstart, const unsigned long long* __restrict__ pc) {
-  __shared__ uint32_t cnt[512 * 8];                        // [row slot][part]: counts, then write cursors
+    const int64_t* __restrict__ bstart, const unsigned long long* __restrict__ pc,
+    const uint16_t* __restrict__ rid /* popularity ids (slot * P + part) instead of the column-map gather, or null */,
+    uint32_t magicP /* ceil(2^32 / P) */, int nsplit /* ids below this may be split columns */, const uint8_t* __restrict__ lgtab) {
+  __shared__ uint32_t cnt[FILL_MAX_RP];                    // [row slot][part]: counts, then write cursors
   __shared__ uint32_t total[8], lastrow[8];
   const int64_t b = blockIdx.x;
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
@@ -563,7 +566,15 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
     for (int64_t k0 = s; k0 < e; k0 += RS_SUB) {          // (all 16 lanes stay in the loop: the ballots need them)
       const int64_t k = k0 + lane;
       const bool valid = k < e;
-      const uint32_t cm = valid ? colmap[indices[k]] : 0u;
+      uint32_t cm = 0u;
+      if (rid) {                                           // (round 3) the ids k_row_partcounts wrote: a coalesced 2-byte read instead of a gather
+        const uint32_t id = valid ? (uint32_t)rid[k] : 0u;
+        const uint32_t slot = P == 1 ? id : __umulhi(id, magicP);   // id / P, exact for 16-bit ids and 2 <= P <= 8 (ceil(2^32 / 1) does not fit 32 bits)
+        const uint32_t lg = (int)id < nsplit ? (uint32_t)lgtab[id] : 0u;
+        cm = ((id - slot * (uint32_t)P) << 16) | (lg << 13) | slot;
+      } else {
+        cm = valid ? colmap[indices[k]] : 0u;
+      }
       const uint32_t p = valid ? cm >> 16 : 0xFFFFu;
       uint32_t t = 0;
 #pragma unroll
@@ -1767,7 +1778,7 @@ template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
 }
 template <int P> static fz_fn fz_pick(int mode, int fmt, int geo) {
   if constexpr (P > 4) return fz_pick2<P, 1>(mode, fmt);   // teams of 5-8: one geometry
-  else return geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 0>(mode, fmt);
+  else return geo == 3 ? fz_pick2<P, 3>(mode, fmt) : (geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 0>(mode, fmt));
 }
 static int fz_fmt(const tsem_ctx* h) { return h->fmt_code ? 1 : (h->fmt_wcode ? 2 : 0); }
 static fz_fn fz_kernel(int P, int mode, int fmt, int geo) {
@@ -1793,7 +1804,7 @@ static bool fz_wants_codes(const tsem_ctx* h) {
   return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048;
 }
 static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
-  return (size_t)(2 * h->Kp + (FZ_YR + 2) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0);
+  return (size_t)(2 * h->Kp + (fz_yr(h->geo) + 2) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0);
 }
 
 static void free_layout(tsem_ctx* h) {
@@ -2038,7 +2049,16 @@ int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_col
 
 __global__ void k_max_u16(const uint16_t* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
   uint32_t m = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  // eight scores per 16-byte load (hipMalloc alignment); the tail one by one
+  const uint4* v4 = reinterpret_cast<const uint4*>(v);
+  const int64_t n8 = n / 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 w = v4[i];
+    const uint32_t a = max(max(w.x & 0xFFFFu, w.x >> 16), max(w.y & 0xFFFFu, w.y >> 16));
+    const uint32_t b = max(max(w.z & 0xFFFFu, w.z >> 16), max(w.w & 0xFFFFu, w.w >> 16));
+    m = max(m, max(a, b));
+  }
+  for (int64_t i = n8 * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     m = max(m, (uint32_t)v[i]);
   m = (uint32_t)sg_max_i<64>((int)m);
   if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
@@ -2130,10 +2150,15 @@ static int choose_geometry(tsem_ctx* h) {
       // needs more than ~1.25x the 512 row slots of geometry 0 — 20 entries per row: codes 2.21 -> 1.98 ms, fp64
       // 2.63 -> 2.57; 28 per row: codes 2.55 -> 2.66, fp64 equal)
       h->geo = P > 4 ? 1 : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > 1.25 * fz_rmax(0)) ? 2 : 0);
-      if (h->opt_geo >= 0 && P <= 4) h->geo = h->opt_geo == 2 ? 2 : 0;
+      // rows so short that 768 of them cannot fill the tile either: geometry 3 (32 B of LDS per row slot instead of 48)
+      // (profiles/r03_sweep_short.txt: 8 / 10 / 12 entries per row 1.27 / 1.31 / 1.39 -> 1.18 / 1.23 / 1.34 ms, 14 equal, 16 and more slower:
+      //  the exchange of a step grows with its row slots)
+      if (h->geo == 2 && 1.07 * fz_cap(2) * P / std::max(2.0, mean_len) > 1.4 * fz_rmax(2)) h->geo = 3;
+      if (h->opt_geo >= 0 && P <= 4) h->geo = (h->opt_geo == 2 || h->opt_geo == 3) ? (int)h->opt_geo : 0;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
-      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - 2 * Kp * 8 - lut_bytes) / ((FZ_YR + 2) * 8));
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - 2 * Kp * 8 - lut_bytes) / ((fz_yr(h->geo) + 2) * 8));
+      rmax = std::min(rmax, FILL_MAX_RP / P);                // (k_sb_fill_sorted keeps R x P counters in LDS)
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
       R = std::min(R, rmax / 8 * 8);
@@ -2332,7 +2357,9 @@ static int build_layout(tsem_ctx* h) {
     TSEM_HIP(hipGetLastError());
     rid_amb_done = true;
     const int cap = fz_cap(h->geo) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
-    const int64_t L = std::max<int64_t>((int64_t)R * 256, (na + 4095) / 4096);
+    // chunk length: >= 64 blocks' worth of rows (the forced break at a chunk end costs ~0.8 % more blocks; round 2 used 256 blocks' worth,
+    // 484 sequential waves for 47M rows: 2 x 2.5 ms; four times as many waves walk a quarter each)
+    const int64_t L = std::max<int64_t>((int64_t)R * 64, (na + 16383) / 16384);
     const int64_t nch = (na + L - 1) / L;
     int64_t *d_cnt = nullptr, *d_off = nullptr;
     int* d_flag = nullptr;
@@ -2442,12 +2469,34 @@ static int build_layout(tsem_ctx* h) {
   // since the exchange is one generation per step, the step ends when the LDS queue has drained, and less LDS work
   // shortens it for them too: 40 per row 4.33 -> 4.14 ms (0.73 of the HBM peak), teams of 8 4.42 -> 4.20, 20 per
   // row 2.70 -> 2.48 (profiles/r02_sweep.txt, r02_sweep_short.txt).
-  h->sorted_layout = h->use_fused && R * P <= 512 * 8 &&   // (the fill kernel keeps R x P counters in LDS)
+  h->sorted_layout = h->use_fused && R * P <= FILL_MAX_RP &&   // (the fill kernel keeps R x P counters in LDS)
                      (h->opt_sorted >= 0 ? h->opt_sorted != 0 : true);
   if (nb && h->sorted_layout) {
+    // the popularity ids stand in for the column-map gather when every row's ids are written (they are: k_row_partcounts +
+    // k_rid16_rows above) and the split columns' ids fit the small table
+    const uint16_t* rid_fill = nullptr;
+    uint8_t* d_lgtab = nullptr;
+    int nsplit = 0;
+    if (h->d_rid16 && P <= 8) {
+      std::vector<uint8_t> lgt;
+      for (int j = 0; j < K; ++j) {
+        const uint32_t cm = colmap[j], lg = (cm >> 13) & 7u;
+        if (lg) { const uint32_t id = (cm & 0x1FFFu) * P + (cm >> 16); if (id >= lgt.size()) lgt.resize(id + 1, 0); lgt[id] = (uint8_t)lg; }
+      }
+      nsplit = (int)lgt.size();
+      if (nsplit <= 4096) {
+        TSEM_ALLOC(d_lgtab, std::max(1, nsplit));
+        if (nsplit) TSEM_HIP(hipMemcpyAsync(d_lgtab, lgt.data(), nsplit, hipMemcpyHostToDevice, h->stream));
+        TSEM_HIP(hipStreamSynchronize(h->stream));         // (lgt is a local)
+        rid_fill = h->d_rid16;
+      }
+    }
+    const uint32_t magicP = (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P);
     k_sb_fill_sorted<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
-                                                         d_pc ? d_bs : nullptr, d_pc);
+                                                         d_pc ? d_bs : nullptr, d_pc, rid_fill, magicP, nsplit, d_lgtab);
+    TSEM_HIP(hipGetLastError());
+    if (d_lgtab) { TSEM_HIP(hipStreamSynchronize(h->stream)); (void)hipFree(d_lgtab); }
     TSEM_HIP(hipGetLastError());
     if (h->fmt_code && h->opt_deconflict != 0 && off >= 64) {
       const int64_t n_win = off / 64;

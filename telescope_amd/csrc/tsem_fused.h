@@ -43,8 +43,14 @@ constexpr int FZ_NT = 1024;            // threads per workgroup
 //   0 : 2 exchange waves x 2 row pairs per lane (R <= 512), 14 data waves   teams of 1-4
 //   1 : 3 exchange waves x 1 row pair  per lane (R <= 384), 13 data waves   teams of 5-8
 //   2 : 3 exchange waves x 2 row pairs per lane (R <= 768), 13 data waves   teams of 1-4, short rows
+//   3 : 3 exchange waves x 3 row pairs per lane (R <= 1152), 13 data waves  teams of 1-4, rows too short to fill the tile with
+//       768 of them (round 3).  The row slots are what limits such a block: 48 B of LDS each (y ring 4 deep + s ring 2 deep)
+//       next to 121 KB of tables.  Here the exchange wave reads a block's partial sums ONCE, at the publish, keeps its own
+//       copy in registers until the combine and zeroes the LDS slot at once: the y ring is 2 deep, a row slot costs 32 B,
+//       and 1024-1152 rows fit where 768 did.
 __host__ __device__ constexpr int fz_nxw(int g) { return g == 0 ? 2 : 3; }          // exchange waves
-__host__ __device__ constexpr int fz_rp(int g) { return g == 1 ? 1 : 2; }           // row pairs per lane
+__host__ __device__ constexpr int fz_rp(int g) { return g == 1 ? 1 : (g == 3 ? 3 : 2); }   // row pairs per lane
+__host__ __device__ constexpr int fz_yr(int g) { return g == 3 ? 2 : 4; }           // depth of the y ring
 __host__ __device__ constexpr int fz_dt(int g) { return FZ_NT - 64 * fz_nxw(g); }   // data threads
 __host__ __device__ constexpr int fz_cap(int g) { return fz_dt(g) * 4; }            // entries per register tile
 __host__ __device__ constexpr int fz_rmax(int g) { return 2 * 64 * fz_rp(g) * fz_nxw(g); }
@@ -56,7 +62,7 @@ constexpr int FZ_GAP = FZ_GAP_STEPS;   // steps between a block's publish and th
 constexpr int FZ_NS = 5 + FZ_GAP;      // register sets: block k lives in set k % FZ_NS
 constexpr int FZ_DL = 2;               // prefetch distance (steps)
 constexpr int FZ_LAG = 3 + FZ_GAP;     // scatter lag (steps) = FZ_NS - FZ_DL
-constexpr int FZ_YR = 4;               // y ring: row sums of block k live from step k to k+3 (combine), GAP = 1
+// (y ring, fz_yr(GEO) deep: row sums of block k live from step k to its combine at k+3 — or, geometry 3, to its publish at k+1)
 constexpr int FZ_XS = 8;               // exchange slots per team (ring)
 constexpr unsigned FZ_SPIN_LIMIT = 2000000u;
 #ifndef FZ_SKIP_IDLE_WAVES
@@ -200,6 +206,8 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   constexpr int p = PP;
   constexpr int FZ_RP = fz_rp(GEO);
+  constexpr int FZ_YR = fz_yr(GEO);
+  constexpr bool OWNREG = GEO == 3;                            // own partial sums travel in registers from publish to combine
   constexpr int NPART = P > 1 ? P - 1 : 1;
   double* const y = X.y; double* const s = X.s; uint32_t* const offs = X.offs; uint32_t* const err = X.err;
   unsigned long long* const xbase = X.xbase;
@@ -221,6 +229,12 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   struct Gen { u64x2 pv[NPART][FZ_RP]; double2 w[FZ_RP]; uint32_t wc[FZ_RP]; uint32_t off; };
   Gen g1;
   g1.off = 0;
+  struct Own { u64x2 v[FZ_RP]; };
+  Own own_q[2 + FZ_GAP];                                  // (geometry 3) own_q[d]: read d + 1 steps ago
+#pragma unroll
+  for (int d = 0; d < 2 + FZ_GAP; ++d)
+#pragma unroll
+    for (int j = 0; j < FZ_RP; ++j) own_q[d].v[j] = (u64x2){0ull, 0ull};
   // issue the partner / weight loads of block k and the offset fetch of block ko (never branched around)
   auto issue = [&](Gen& g, int64_t k, int64_t ko) {
     {
@@ -265,7 +279,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     }
   };
   // combine block k from generation g: s = w * recip0(sum of the P partials), fixed order
-  auto combine = [&](Gen& g, int64_t k, int64_t ko) {
+  auto combine = [&](Gen& g, const Own& mine, int64_t k, int64_t ko) {
     if (offw && lane < 2 && ko >= 5 && ko < nblk) offs[(ko & 7) * 2 + lane] = g.off;   // blocks 0..4: prologue
     if (k < 0 || k >= nblk) return;
 #ifdef FZ_EXPERIMENT
@@ -280,7 +294,8 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     for (int j = 0; j < FZ_RP; ++j) {
       const int r = rlo + 2 * (lane + 64 * j);
       if (r < rhi) {
-        u64x2 own = *reinterpret_cast<const u64x2*>(&y[(k & (FZ_YR - 1)) * R + r]);
+        u64x2 own;
+        if (OWNREG) own = mine.v[j]; else own = *reinterpret_cast<const u64x2*>(&y[(k & (FZ_YR - 1)) * R + r]);
         if (P > 1 && !nopart) {
           unsigned spins = 0;
           for (;;) {                                    // normally true at once: published 2 steps ago
@@ -312,7 +327,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
         if (MODE == 0) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
         // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730)
         *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(recip0(ys0) * w.x, recip0(ys1) * w.y);
-        *reinterpret_cast<double2*>(&y[(k & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
+        if (!OWNREG) *reinterpret_cast<double2*>(&y[(k & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
       }
     }
   };
@@ -348,6 +363,31 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     // publish y(i-1): tagged granules, 16-byte stores (a tear between halves is harmless).  PLAIN
     // stores: the line stays in the XCD's L2, where the partners' sc1 loads find it (a write-through
     // sc1 store drops it from L2: measured 14 M tag misses per pass vs 0.14 M)
+    if (OWNREG) {
+      // geometry 3: read y(i-1) once — publish it, keep it for the combine three steps on, zero the slot now (it is
+      // complete since the barrier that ended step i-1 and nobody else reads it; only the lanes that own a row pair zero
+      // it: a clamped lane would race with the owner's read)
+      const int64_t kp = i - 1;
+      const bool pv = kp >= 0 && kp < nblk;
+      const unsigned long long tag = tag_of(kp);
+      __amdgpu_buffer_rsrc_t xs = fz_rsrc(xbase, 0, (pv && P > 1) ? (unsigned)(FZ_XS * P * R * 8) : 0u);
+#pragma unroll
+      for (int d = 1 + FZ_GAP; d > 0; --d) own_q[d] = own_q[d - 1];
+#pragma unroll
+      for (int j = 0; j < FZ_RP; ++j) {
+        const int r0 = rlo + 2 * (lane + 64 * j);
+        const int r = min(r0, R - 2);
+        fz_u32x4 gq = *reinterpret_cast<const fz_u32x4*>(&y[(kp & (FZ_YR - 1)) * R + r]);
+        own_q[0].v[j] = (u64x2){((unsigned long long)gq.y << 32) | gq.x, ((unsigned long long)gq.w << 32) | gq.z};
+        if (pv && r0 < rhi) *reinterpret_cast<double2*>(&y[(kp & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
+        gq.x = (gq.x & ~1u) | (unsigned)tag;
+        gq.z = (gq.z & ~1u) | (unsigned)tag;
+        // only the OWNER of a row pair stores it: a clamped lane (of this or another exchange wave) may read the slot after the
+        // owner zeroed it and would publish zeros over the owner's values (out-of-range offset: the store is dropped)
+        const unsigned boff = r0 < rhi ? (unsigned)((((kp & (FZ_XS - 1)) * P + p) * R + r) * 8) : FZ_OOB;
+        if (P > 1) __builtin_amdgcn_raw_buffer_store_b128(gq, xs, boff, 0, 0);
+      }
+    } else
     if (P > 1) {
       const int64_t kp = i - 1;
       const bool pv = kp >= 0 && kp < nblk;
@@ -371,7 +411,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     if (pr) A.prof[i * FZ_PROF_SLOTS + 10] = clock64();   // (waits for the LDS reads of the publish: lgkmcnt)
     issue(g1, i - 2 - FZ_GAP, i + FZ_DL + 2);
     if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
-    combine(g1, i - 2 - FZ_GAP, i + FZ_DL + 2);
+    combine(g1, own_q[1 + FZ_GAP], i - 2 - FZ_GAP, i + FZ_DL + 2);   // (geometry 3: block i-2-GAP was read 1+GAP publishes before this one's)
     if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
     if (A.prof && team == 0 && p == 0 && lane == 0 && X.xw == 1 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 9] = clock64();
     __syncthreads();
@@ -385,6 +425,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int P = PT;
   constexpr int FZ_DT = fz_dt(GEO);
+  constexpr int FZ_YR = fz_yr(GEO);
   const int Kp = A.Kp, R = A.R;
   double* c = reinterpret_cast<double*>(smem);
   double* acc = c + Kp;
@@ -610,7 +651,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       // step has a floor of LDS instruction ISSUE (~22 wave-instructions per data wave, ~8 clk each even with every lane
       // masked); idle waves used to pay it in full.  (Wave-uniform branch around LDS operations only: the
       // streaming loads below stay unconditional.)
-      const bool wave_idle = FZ_SKIP_IDLE_WAVES && GEO == 2 &&   // (only the short-row geometry leaves whole waves idle; elsewhere the branch costs 1.5 %)
+      const bool wave_idle = FZ_SKIP_IDLE_WAVES && GEO >= 2 &&   // (only the short-row geometry leaves whole waves idle; elsewhere the branch costs 1.5 %)
                              (__builtin_amdgcn_ballot_w64(!idle) | __builtin_amdgcn_ballot_w64(!idle2)) == 0ull;
       if (wave_idle) {
         rp.rc.x = 0xFFFFFFFFu;

@@ -178,3 +178,39 @@ def test_device_side_convergence_below_max_iter_on_large_matrices(gpu_device, ro
     assert 8 < ref['n_iter'] < 1000 and tl.n_iter == ref['n_iter']
     assert abs(tl.lnl - ref['lnl']) <= RTOL * abs(ref['lnl'])
     assert np.allclose(tl.pi, ref['pi'], rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize('block_rows,fmt,parts', [(64, 0, 0), (128, 1, 0), (640, 0, 0), (1152, 1, 0), (0, 0, 4), (200, 0, 0)])
+def test_short_row_geometry_with_any_block_size(gpu_device, block_rows, fmt, parts):
+    """Geometry 3 of the fused kernel (rows so short that 768 of them cannot fill the register tile: the exchange wave
+    keeps its own partial sums in registers from the publish to the combine and zeroes the 2-deep y ring at the
+    publish) against the oracle — with forced block sizes far below what its three exchange waves cover: lanes clamped
+    to the last row pair must neither zero nor publish it (a race found by test_random_shapes_against_oracle[3])."""
+    from oracle.telescope_oracle import OracleModel
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+    rng = np.random.RandomState(77)
+    n, k = 30000, 16000
+    lens = rng.randint(2, 7, n)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.randint(139, 213, indptr[-1]).astype(np.uint16)
+    raw = sp.csr_matrix((data, indices, indptr), shape=(n, k))
+    o = Opts(max_iter=4, em_epsilon=0.0)
+    eng = _lib.Engine(0)
+    eng.set_option('value_format', fmt)
+    if block_rows:
+        eng.set_option('block_rows', block_rows)
+    if parts:
+        eng.set_option('parts', parts)
+    eng.load_scores(raw.indptr, raw.indices, raw.data, k, score_lut(int(raw.data.max())))
+    tl = TelescopeLikelihood.from_engine(eng, o)
+    tl._raw = raw
+    tl.em()
+    info = eng.layout_info()
+    assert info['fused'] == 1 and info['geometry'] == 3, info
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    om.em(0.0, o.max_iter)
+    assert abs(tl.lnl - om.lnl) <= RTOL * abs(om.lnl), info
+    assert np.allclose(tl.pi, om.pi, rtol=RTOL, atol=1e-300) and np.allclose(tl.theta, om.theta, rtol=RTOL, atol=1e-300), info
+    assert np.array_equal(tl.reassign_colsums('exclude'), np.asarray(om.reassign('exclude').sum(0)).ravel())
