@@ -214,3 +214,35 @@ def test_short_row_geometry_with_any_block_size(gpu_device, block_rows, fmt, par
     assert abs(tl.lnl - om.lnl) <= RTOL * abs(om.lnl), info
     assert np.allclose(tl.pi, om.pi, rtol=RTOL, atol=1e-300) and np.allclose(tl.theta, om.theta, rtol=RTOL, atol=1e-300), info
     assert np.array_equal(tl.reassign_colsums('exclude'), np.asarray(om.reassign('exclude').sum(0)).ravel())
+
+
+def test_report_pass_falls_back_beyond_65536_slots(gpu_device):
+    """The streaming report kernel indexes LDS with 16-bit popularity ids; a matrix with more column slots than that
+    (K = 70 000: ten column parts, the two-pass EM kernels) must take the generic row pass — and agree with the oracle."""
+    from oracle.telescope_oracle import OracleModel
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+    rng = np.random.RandomState(5)
+    n, k = 20000, 70000
+    lens = np.where(rng.rand(n) < 0.1, 1, rng.randint(2, 30, n))
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.randint(139, 213, indptr[-1]).astype(np.uint16)
+    raw = sp.csr_matrix((data, indices, indptr), shape=(n, k))
+    o = Opts(max_iter=3, em_epsilon=0.0)
+    eng = _lib.Engine(0)
+    eng.load_scores(raw.indptr, raw.indices, raw.data, k, score_lut(int(raw.data.max())))
+    tl = TelescopeLikelihood.from_engine(eng, o)
+    tl._raw = raw
+    tl.em()
+    info = eng.layout_info()
+    assert info['fused'] == 0 and info['P'] * info['Kp'] > 65536, info
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    om.em(0.0, o.max_iter)
+    assert abs(tl.lnl - om.lnl) <= RTOL * abs(om.lnl)
+    np.random.seed(3); got = {m: tl.reassign_colsums(m, 0.9, init) for m, init in (('exclude', False), ('choose', True), ('average', True), ('conf', False))}
+    np.random.seed(3)
+    assert np.array_equal(got['exclude'], np.asarray(om.reassign('exclude').sum(0)).ravel())
+    assert np.array_equal(got['choose'], np.asarray(om.reassign('choose', initial=True).sum(0)).ravel())
+    assert np.allclose(got['average'], np.asarray(om.reassign('average', initial=True).sum(0)).ravel(), rtol=1e-12, atol=1e-12)
+    assert np.allclose(got['conf'], np.asarray(om.reassign('conf', 0.9).sum(0)).ravel(), rtol=1e-12, atol=1e-12)
