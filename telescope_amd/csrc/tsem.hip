@@ -3244,7 +3244,7 @@ int tsem_set_prev_lnl(tsem_ctx* h, double lnl) {
 // ---------------------------------------------------------------------------
 // communicator (RCCL over xGMI; one per process / GPU)
 // ---------------------------------------------------------------------------
-static std::string g_comm_err;
+static thread_local std::string g_comm_err;            // (per host thread: the in-process transport runs one rank per thread)
 const char* tsem_comm_last_error(void) { return g_comm_err.c_str(); }
 
 int tsem_comm_library_info(char* buf, int32_t cap) {
