@@ -79,6 +79,15 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *   "deconflict"   conflict-aware entry order inside the rows of the row-ordered code layout (LDS bank conflicts of the
  *                  column scatter 3.2 -> 2.4 lanes per class: -6 % per EM pass for ~4 ms of setup at 2e9 entries);
  *                  default -1 = on, 0 = off
+ *   "reproducible" 1: ORDER-INDEPENDENT column sums in the fused EM pass.  Every contribution w*z is cut into a high and a low piece on
+ *                  a per-column power-of-two grid; sums of such pieces are exact in fp64, so the unordered LDS atomics add up to
+ *                  the same bits whatever their order: pi, theta, lnl and the iteration count are bit-identical from run to run
+ *                  (same build, same device type, same number of ranks).  Two passes per iteration, plus a repeated pass when a
+ *                  column's grid has to move (tsem_layout_info[20] counts them); the rows keep their entry order ("deconflict"
+ *                  is off), so that a row's partial sum is one run ending in at most two atomics.  That holds for rows of up to
+ *                  256 entries; with longer rows tsem_layout_info[21] reports 2 instead of 1 and the last bit of such a row's
+ *                  sum may depend on timing.  Needs the fused kernel and a score table of <= 2048 entries; column sums are
+ *                  within (entries of the column) x 2^-41 of exact, typically one fp64 rounding.  Default 0.
  *   "em_precision" 1: the EM pass in fp32 arithmetic (row sums, posteriors and column sums in fp32) — a
  *                  DIAGNOSTIC for the fp32-vs-fp64 tolerance sweep of BASELINE config 3, not a product path
  *   "fused_dbg", "fused_prof", "chunk_blocks"     timing experiments */
@@ -280,7 +289,7 @@ int  tsem_csr_scale(int device, int mode, int64_t n_rows, int32_t n_cols, const 
  * algorithmic bytes one EM pass reads.  */
 int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launches,
                        int64_t* algo_bytes_per_pass);
-int  tsem_layout_info(tsem_ctx* h, int64_t* info20);
+int  tsem_layout_info(tsem_ctx* h, int64_t* info24);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
 /* the packed local row / local column words of one sub-block of the blocked layout (layout studies) */

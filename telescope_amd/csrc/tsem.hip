@@ -185,13 +185,18 @@ __global__ void k_gen_rows(int64_t row_begin, int64_t n, int32_t K, uint64_t see
 // ============================================================================
 // One 16-lane group per row.  Outputs: per-row (len>=2 ? max raw code : 0),
 // flags, per-WG partial sums of w (total / ambiguous), global max code,
-// pisum0[col] += Q for unique rows.
+// pisum0[col] += Q for unique rows — EXACTLY, so that the result does not depend on the order of the atomics (round 3; the
+// fp64 atomics this replaced made pi differ in the last bit from run to run): Q is cut into pieces on PIS_LEVELS fixed grids
+// 26 bits apart, from the largest score-table value down past the last mantissa bit of the smallest; a level's sum of up to
+// 2^26 pieces is exact in fp64, k_pisum_finish adds the levels in a fixed order.  A 53-bit Q has pieces on 3-4 levels.
+constexpr int PIS_LEVELS = 9, PIS_W = 26;
 constexpr int RS_SUB = 16;
 __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __restrict__ indptr,
     const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
     const double* __restrict__ lut, uint16_t* __restrict__ row_code, uint8_t* __restrict__ row_class,
     double* __restrict__ wsum_part /* [grid][2] */, uint32_t* __restrict__ maxcode,
-    double* __restrict__ pisum0, uint32_t* __restrict__ ucount /* [K] unique rows with a positive score per column; [K] = 1 if any stored score is 0 */,
+    double* __restrict__ pis_lv /* [PIS_LEVELS][K] */, int pis_e0 /* biased exponent of a power of two above every Q */,
+    uint32_t* __restrict__ ucount /* [K] unique rows with a positive score per column; [K] = 1 if any stored score is 0 */,
     int K, unsigned long long* __restrict__ len_gt /* [6] rows longer than 8, 16, 32, 64, 128, 256 entries */) {
   __shared__ double scratch[16];
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB;
@@ -219,8 +224,17 @@ __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __re
       row_class[row] = (len > 1) ? 2 : (len == 1 ? 1 : 0);
       mymax = max(mymax, m);
       if (len == 1) {
-        unsafeAtomicAdd(&pisum0[indices[s]], lut[raw[s]]);
-        if (raw[s]) atomicAdd(&ucount[indices[s]], 1u);
+        double r = lut[raw[s]];
+        const int col = indices[s];
+        for (int lv = 0; lv < PIS_LEVELS && r != 0.0; ++lv) {
+          const int eb = pis_e0 - PIS_W * lv;               // pieces of this level: |piece| <= 2^(eb-1023), multiples of 2^(eb-1023-PIS_W)
+          if (eb + 52 - PIS_W < 1) break;                   // (below the normal range: nothing of a finite score table gets here)
+          const double m = __hiloint2double((int)(((uint32_t)(eb + 52 - PIS_W) << 20) | 0x80000u), 0);
+          const double piece = (r + m) - m;
+          if (piece != 0.0) unsafeAtomicAdd(&pis_lv[(size_t)lv * K + col], piece);
+          r -= piece;
+        }
+        if (raw[s]) atomicAdd(&ucount[col], 1u);
       }
     }
   }
@@ -1763,6 +1777,22 @@ static int dalloc(tsem_ctx* h, T** p, size_t n) {
 template <typename T>
 static void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
+// option "reproducible": the slots' bounds as a run finds them: 2^E > the largest fragment weight >= every contribution w * z
+// (refined column by column, see k_bin_check).  Called when parameters are set from outside, so that a run's bits depend on its
+// starting point only, not on what the context computed before.
+static int bin_reset(tsem_ctx* h) {
+  if (!h->d_ebias) return TSEM_OK;
+  int e2 = 0;
+  (void)std::frexp(h->w_max > 0 ? h->w_max : 1.0, &e2);    // w_max = m * 2^e2, m in [0.5, 1)  ->  w_max < 2^e2
+  std::vector<uint16_t> eb((size_t)h->Kpad, (uint16_t)std::min(2000, std::max(64, e2 + 1023)));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  TSEM_HIP(hipMemcpy(h->d_ebias, eb.data(), sizeof(uint16_t) * h->Kpad, hipMemcpyHostToDevice));
+  TSEM_HIP(hipMemset(h->d_ovf, 0, (size_t)h->Kpad));
+  TSEM_HIP(hipMemset(h->d_ehist, 0, sizeof(int16_t) * (2 * (size_t)h->K + 2)));
+  return TSEM_OK;
+}
+
+
 static inline int cdiv64(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 static int ensure_device(tsem_ctx* h) {
@@ -1772,6 +1802,15 @@ static int ensure_device(tsem_ctx* h) {
 
 typedef void (*fz_fn)(FusedArgs);
 template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
+  if (mode == 2) {                                         // exact (binned) column sums: needs the score table in LDS (formats 1, 2)
+#ifdef TSEM_NO_REPRO
+    return nullptr;
+#else
+    if (fmt == 1) return k_em_fused<P, 2, 1, GEO>;
+    if (fmt == 2) return k_em_fused<P, 2, 2, GEO>;
+    return nullptr;
+#endif
+  }
   if (fmt == 1) return mode ? k_em_fused<P, 1, 1, GEO> : k_em_fused<P, 0, 1, GEO>;
   if (fmt == 2) return mode ? k_em_fused<P, 1, 2, GEO> : k_em_fused<P, 0, 2, GEO>;
   return mode ? k_em_fused<P, 1, 0, GEO> : k_em_fused<P, 0, 0, GEO>;
@@ -1804,10 +1843,12 @@ static bool fz_wants_codes(const tsem_ctx* h) {
   return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048;
 }
 static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
-  return (size_t)(2 * h->Kp + (fz_yr(h->geo) + 2) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0);
+  return (size_t)(2 * h->Kp + (fz_yr(h->geo) + 2) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0) +
+         (h->opt_reproducible ? (size_t)h->Kp * 2 + 16 : 0);   // (+ the slots' exponent table)
 }
 
 static void free_layout(tsem_ctx* h) {
+  dfree(h->d_ebias); dfree(h->d_ovf); dfree(h->d_red_hi); dfree(h->d_binflag); dfree(h->d_ehist);
   dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_rid16); dfree(h->d_col_of_id); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_pcode); dfree(h->d_prc);
   dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fz_aux); h->fz_clean = false; dfree(h->d_fpartial); dfree(h->d_amb_w); dfree(h->d_sb_q32);
   h->fused_launched = false;
@@ -1894,6 +1935,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "geometry") h->opt_geo = v;
   else if (k == "sorted_fill") h->opt_sorted = v;
   else if (k == "deconflict") h->opt_deconflict = v;
+  else if (k == "reproducible") h->opt_reproducible = v;
   else if (k == "em_precision") h->opt_precision = v;
   else if (k == "kernel_timing") h->opt_timing = v;
   else if (k == "report_shortcuts") h->opt_shortcuts = v;
@@ -2157,7 +2199,7 @@ static int choose_geometry(tsem_ctx* h) {
       if (h->opt_geo >= 0 && P <= 4) h->geo = (h->opt_geo == 2 || h->opt_geo == 3) ? (int)h->opt_geo : 0;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
-      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - 2 * Kp * 8 - lut_bytes) / ((fz_yr(h->geo) + 2) * 8));
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - 2 * Kp * 8 - lut_bytes - (h->opt_reproducible ? Kp * 2 + 16 : 0)) / ((fz_yr(h->geo) + 2) * 8));
       rmax = std::min(rmax, FILL_MAX_RP / P);                // (k_sb_fill_sorted keeps R x P counters in LDS)
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
@@ -2175,6 +2217,14 @@ static int choose_geometry(tsem_ctx* h) {
 // ---------------------------------------------------------------------------
 // rowstats: classes, weights, local sums; compacts ambiguous / unique rows
 // ---------------------------------------------------------------------------
+__global__ void k_pisum_finish(int K, const double* __restrict__ lv, double* __restrict__ pisum0) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  double t = 0.0;
+  for (int l = PIS_LEVELS - 1; l >= 0; --l) t += lv[(size_t)l * K + j];   // small to large
+  pisum0[j] = t;
+}
+
 int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_count, uint64_t* col_hash) {
   if (!h || !h->d_indptr) return TSEM_ERR_ARG;
   if (!h->d_lut || h->lut_len <= 0) TSEM_FAIL(TSEM_ERR_ARG, "no score table: call tsem_set_lut after tsem_generate");
@@ -2189,7 +2239,11 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   TSEM_ALLOC(h->d_pisum0, K);
   TSEM_ALLOC(h->d_ucount, K + 1);
   TSEM_HIP(hipMemsetAsync(h->d_ucount, 0, sizeof(uint32_t) * (K + 1), h->stream));
-  TSEM_HIP(hipMemsetAsync(h->d_pisum0, 0, sizeof(double) * K, h->stream));
+  double* d_pis_lv = nullptr;
+  TSEM_ALLOC(d_pis_lv, (size_t)PIS_LEVELS * K);
+  TSEM_HIP(hipMemsetAsync(d_pis_lv, 0, sizeof(double) * PIS_LEVELS * K, h->stream));
+  int pis_e2 = 0;
+  (void)std::frexp(h->lut_host[h->lut_len - 1] > 0 ? h->lut_host[h->lut_len - 1] : 1.0, &pis_e2);   // Q < 2^e2 (the table is increasing)
   TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
   TSEM_HIP(hipMemsetAsync(d_wpart, 0, sizeof(double) * 2 * grid, h->stream));
   unsigned long long* d_lg = nullptr;
@@ -2197,7 +2251,8 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   TSEM_HIP(hipMemsetAsync(d_lg, 0, 64, h->stream));
   if (N)
     k_rowstats<<<grid, 256, 0, h->stream>>>(N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, d_code, d_cls,
-                                           d_wpart, h->d_maxcode, h->d_pisum0, h->d_ucount, K, d_lg);
+                                           d_wpart, h->d_maxcode, d_pis_lv, pis_e2 + 1023, h->d_ucount, K, d_lg);
+  k_pisum_finish<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, d_pis_lv, h->d_pisum0);
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipMemcpyAsync(h->len_gt, d_lg, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   std::vector<double> wpart(2 * grid);
@@ -2268,7 +2323,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
                                                          h->d_uni_code);
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_code); (void)hipFree(d_cls); (void)hipFree(d_wpart); (void)hipFree(d_fa); (void)hipFree(d_fu); (void)hipFree(d_lg);
+  (void)hipFree(d_code); (void)hipFree(d_cls); (void)hipFree(d_wpart); (void)hipFree(d_fa); (void)hipFree(d_fu); (void)hipFree(d_lg); (void)hipFree(d_pis_lv);
   h->have_rowstats = true;
   return TSEM_OK;
 }
@@ -2454,6 +2509,9 @@ static int build_layout(tsem_ctx* h) {
                  fz_lds_bytes(h, true) <= (size_t)TS_LDS_MAX - 1024;
   if (h->opt_format == 2 && !h->fmt_code)
     TSEM_FAIL(TSEM_ERR_ARG, "value_format=codes needs the fused kernel and a score table of at most 2048 entries");
+  if (h->opt_reproducible && !(h->use_fused && (h->fmt_code || h->fmt_wcode)))
+    TSEM_FAIL(TSEM_ERR_ARG, "reproducible mode needs the fused kernel (at most 8 column parts, every row within the register tile) and a score "
+                            "table of at most 2048 entries");
   TSEM_ALLOC(h->d_prc, off);
   TSEM_HIP(hipMemsetAsync(h->d_prc, 0, sizeof(uint32_t) * std::max<int64_t>(1, off), h->stream));
   if (h->fmt_code) {
@@ -2498,7 +2556,9 @@ static int build_layout(tsem_ctx* h) {
     TSEM_HIP(hipGetLastError());
     if (d_lgtab) { TSEM_HIP(hipStreamSynchronize(h->stream)); (void)hipFree(d_lgtab); }
     TSEM_HIP(hipGetLastError());
-    if (h->fmt_code && h->opt_deconflict != 0 && off >= 64) {
+    // (reproducible mode keeps the row order: a row's entries in a sub-block then form ONE run, which ends in at most two LDS
+    // atomics on its row sum — two additions commute, three need not)
+    if (h->fmt_code && h->opt_deconflict != 0 && !h->opt_reproducible && off >= 64) {
       const int64_t n_win = off / 64;
       uint32_t* prc2 = nullptr; uint16_t* code2 = nullptr;
       TSEM_ALLOC(prc2, off); TSEM_ALLOC(code2, off);
@@ -2541,6 +2601,14 @@ static int build_layout(tsem_ctx* h) {
       for (int mode = 0; mode < 2; ++mode)
         TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h), h->geo),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      if (h->opt_reproducible) {
+        fz_fn f2 = fz_kernel(P, 2, fz_fmt(h), h->geo);
+        if (!f2) TSEM_FAIL(TSEM_ERR_ARG, "reproducible mode needs the fused kernel with a score table of at most 2048 entries");
+        TSEM_HIP(hipFuncSetAttribute((const void*)f2, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        TSEM_ALLOC(h->d_ebias, h->Kpad); TSEM_ALLOC(h->d_ovf, h->Kpad); TSEM_ALLOC(h->d_red_hi, K + 2); TSEM_ALLOC(h->d_binflag, 4);
+        TSEM_ALLOC(h->d_ehist, 2 * (size_t)K + 2);
+        if (int rc = bin_reset(h)) return rc;
+      }
     }
   }
   TSEM_HIP(hipFuncSetAttribute((const void*)k_phase1<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
@@ -2627,7 +2695,7 @@ int tsem_set_params(tsem_ctx* h, const double* pi, const double* theta) {
   k_make_ctab<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, h->d_colmap, h->Kp, h->d_ctab);
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  return TSEM_OK;
+  return bin_reset(h);
 }
 
 int tsem_get_params(tsem_ctx* h, int which, double* pi, double* theta) {
@@ -2691,7 +2759,7 @@ static int begin_timing(tsem_ctx* h, hipEvent_t** pair) {
 
 // One launch of the persistent fused kernel.  mode 0: EM pass (column sums of w*z into d_fpartial);
 // mode 1: log-likelihood of the ambiguous rows (one partial per workgroup into d_lnl_part).
-static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
+static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
   if (!h->fz_clean) {                                      // (k_update leaves them zero after every EM pass)
     if (h->fused_launched && h->d_fz_aux)                  // keep the error word of a launch nobody cleaned up after
       k_keep_err<<<1, 1, 0, h->stream>>>(h->d_xflags, h->d_fz_aux + 2);
@@ -2703,17 +2771,20 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair) {
   FusedArgs A;
   A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
   A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc;
-  A.ctab = mode ? h->d_ctab_prev : h->d_ctab; A.ctab2 = h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = mode;
+  const bool lnl = mode == 1;                               // mode 2 is an EM pass (exact column sums), not the lnl pass
+  A.ctab = lnl ? h->d_ctab_prev : h->d_ctab; A.ctab2 = h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = lnl ? 1 : 0;
   A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg; A.sorted = h->sorted_layout ? 1 : 0;
   A.sync = h->d_xflags;
   A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.dbg = (int)h->opt_dbg;
   A.ctl = h->d_ctl;
+  A.ebias = h->d_ebias; A.bin = bin; A.ovf = h->d_ovf;
 
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
   const size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
-  if (mode && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
+  if (lnl && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
   fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h), h->geo);
-  if (!fn) TSEM_FAIL(TSEM_ERR_ARG, "fused kernel supports at most 8 column parts");
+  if (!fn) TSEM_FAIL(TSEM_ERR_ARG, mode == 2 ? "reproducible mode needs the fused kernel with a score table of at most 2048 entries"
+                                               : "fused kernel supports at most 8 column parts");
   if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
   fn<<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
@@ -2740,6 +2811,71 @@ static int em_pass_f32(tsem_ctx* h) {
   return TSEM_OK;
 }
 
+// option "reproducible".  Every contribution to a column sum is cut into a high and a low piece on a per-slot grid (tsem_fused.h,
+// phase 2), one pass each; sums of such pieces are exact in fp64, so they do not depend on the order of the LDS atomics.  The grid
+// hangs on the slot's bound 2^E (ebias = E + 1023): pieces are multiples of 2^(E-30) and 2^(E-60).  All decisions below are functions
+// of exact sums, hence identical in every run.
+//   k_bin_check, after the high pass: a contribution reached the bound -> raise it;  the high sum lies more than BIN_SLACK bits
+//     under what the bound was chosen for (or is zero although the column has entries and a non-zero pi * theta) -> lower it.  Either
+//     way the high pass is repeated (one pass lost, the low pass has not run yet).
+//   k_bin_finish, after the low pass: S = high + low, and the bound of the NEXT iteration = 16 x the sum this column is expected to
+//     have then: columns that fall by d bits per iteration (linear EM convergence) or by d, 2d, 4d, ... bits (a column dying under a
+//     zero prior) are followed, so that later iterations rarely repeat a pass.
+// Worst-case relative error of a column sum: (entries of the column) x 2^-(57 - BIN_SLACK); typically the fp64 rounding of S.
+constexpr int BIN_SLACK = 16;
+__device__ __forceinline__ int bin_slot(uint32_t cm, int Kp, int* copies) {
+  *copies = 1 << ((cm >> 13) & 7u);
+  return (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu);
+}
+__global__ void k_bin_check(int K, const double* __restrict__ red, const uint32_t* __restrict__ colmap, int Kp,
+                            const unsigned long long* __restrict__ colcount, const double* __restrict__ pi, const double* __restrict__ theta,
+                            uint16_t* __restrict__ ebias, uint8_t* __restrict__ ovf, uint32_t* __restrict__ flag) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  int copies;
+  const int pc = bin_slot(colmap[j], Kp, &copies);
+  const int eb = ebias[pc];
+  bool over = false;
+  for (int c = 0; c < copies; ++c) { over |= ovf[pc + c] != 0; ovf[pc + c] = 0; }
+  const double S = red[j];
+  int eb_new = eb;
+  if (over) eb_new = eb + 12;
+  else if (S == 0.0) { if (colcount && colcount[j] > 0 && pi[j] * theta[j] != 0.0 && eb > 120) eb_new = eb - 24; }
+  else {
+    // (a high sum a few grid steps large says little about S: move by at most 24 bits and keep 6 bits in hand)
+    const int ex4 = (int)((__double2hiint(S) >> 20) & 0x7FF) + 4;
+    if (eb - ex4 > BIN_SLACK) eb_new = max(ex4 + 6, eb - 24);
+    else if (ex4 - eb > 20) eb_new = ex4;                     // a sum 2^16 bounds large: more would not be exact (53 - 30 bits of room)
+  }
+  eb_new = min(2000, max(64, eb_new));
+  if (eb_new != eb) {
+    for (int c = 0; c < copies; ++c) ebias[pc + c] = (uint16_t)eb_new;
+    atomicOr(flag, 1u);
+  }
+}
+__global__ void k_bin_finish(int K, const double* __restrict__ red_hi, double* __restrict__ red, const uint32_t* __restrict__ colmap, int Kp,
+                             uint16_t* __restrict__ ebias, uint8_t* __restrict__ ovf, int16_t* __restrict__ hist) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) red[K] = fmax(red[K], red_hi[K]);             // a time-out of either pass
+  if (j >= K) return;
+  const double S = red_hi[j] + red[j];
+  red[j] = S;
+  int copies;
+  const int pc = bin_slot(colmap[j], Kp, &copies);
+  for (int c = 0; c < copies; ++c) ovf[pc + c] = 0;          // (the low pass sees the same contributions as the high pass: nothing new)
+  if (S == 0.0) return;                                       // no information: keep the bound
+  const int ex4 = (int)((__double2hiint(S) >> 20) & 0x7FF) + 4;
+  const int eprev = hist[j], dprev = hist[K + j];
+  const int drop = eprev ? eprev - ex4 : 0;
+  int pred = drop;
+  if (drop >= 4 && dprev >= 2) pred = min(drop * drop / dprev, 2 * drop + 2);
+  pred = max(-10, min(40, pred));
+  const int shift = pred > 3 ? pred - 3 : (pred < 0 ? pred : 0);
+  const int eb_new = min(2000, max(64, ex4 - shift));
+  for (int c = 0; c < copies; ++c) ebias[pc + c] = (uint16_t)eb_new;
+  hist[j] = (int16_t)ex4; hist[K + j] = (int16_t)max(-1000, min(1000, drop));
+}
+
 int tsem_em_pass(tsem_ctx* h) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
@@ -2747,7 +2883,45 @@ int tsem_em_pass(tsem_ctx* h) {
   hipEvent_t* pair = nullptr;
   if (int rc = begin_timing(h, &pair)) return rc;
   bool fused_done = false;
-  if (h->nb > 0 && h->use_fused) {
+  if (h->nb > 0 && h->use_fused && h->opt_reproducible) {
+    // two exact passes (high and low pieces of every contribution); the high pass is repeated while a column's bound has to move:
+    // the first iteration of a run takes a few repeats (the bounds start at the largest fragment weight), later ones rarely any
+    if (h->d_ctl) {                                          // a chunk that has stopped: nothing to compute (the passes would return at once)
+      uint32_t st = 0;
+      TSEM_HIP(hipMemcpyAsync(&st, h->d_ctl, 4, hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      if (st) { h->em_launches += 1; return TSEM_OK; }
+    }
+    auto pass = [&](int bin, hipEvent_t* ev) -> int {
+      if (int rc = launch_fused(h, 2, ev, bin)) return rc;
+      k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                              h->d_xflags, h->P, h->d_ctl,
+                                                              h->P > 1 ? reinterpret_cast<unsigned long long*>(h->d_xchg) : nullptr,
+                                                              h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
+      // (k_colreduce cleared the exchange ring; the sync words are cleared by the memset of the next launch)
+      TSEM_HIP(hipGetLastError());
+      return TSEM_OK;
+    };
+    for (int attempt = 0;; ++attempt) {
+      if (int rc = pass(1, attempt == 0 ? pair : nullptr)) return rc;
+      TSEM_HIP(hipMemsetAsync(h->d_binflag, 0, 4, h->stream));
+      k_bin_check<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_red, h->d_colmap, h->Kp, h->d_colcount, h->d_pi, h->d_theta,
+                                                            h->d_ebias, h->d_ovf, h->d_binflag);
+      TSEM_HIP(hipGetLastError());
+      uint32_t redo = 0;
+      TSEM_HIP(hipMemcpyAsync(&redo, h->d_binflag, 4, hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      if (!redo || attempt >= 40) break;                     // (40 x 24 bits: from the largest weight down to the smallest normal number)
+      h->n_bin_repeats += 1;
+    }
+    TSEM_HIP(hipMemcpyAsync(h->d_red_hi, h->d_red, sizeof(double) * (h->K + 2), hipMemcpyDeviceToDevice, h->stream));
+    if (int rc = pass(2, nullptr)) return rc;
+    k_bin_finish<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_red_hi, h->d_red, h->d_colmap, h->Kp, h->d_ebias, h->d_ovf, h->d_ehist);
+    TSEM_HIP(hipGetLastError());
+    if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
+    h->em_launches += 1;
+    return TSEM_OK;
+  } else if (h->nb > 0 && h->use_fused) {
     if (int rc = launch_fused(h, 0, pair)) return rc;
     fused_done = true;
   } else if (h->nb > 0) {
@@ -4039,6 +4213,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[12] = h->last_slow_path; info[13] = h->max_subblock; info[14] = h->fmt_code ? 2 : 8; info[15] = h->n_hot_cols;
   info[16] = h->use_fused ? (int64_t)fz_lds_bytes(h, fz_fmt(h) != 0) : 0;   // dynamic LDS per workgroup of the fused kernel
   info[17] = h->sorted_layout ? 1 : 0; info[18] = h->geo; info[19] = h->n_fallbacks;
+  info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->len_gt[5] ? 2 : 1) : 0;     // 2: some row has more than 256 entries, see telescope_em.h info[22] = 0; info[23] = 0;
   return TSEM_OK;
 }
 

@@ -115,6 +115,14 @@ struct tsem_ctx {
   int64_t opt_timing = 1;           // HIP events around every n-th EM pass (tsem_kernel_stats); 0 = none
   int64_t opt_precision = 0;        // 1: the EM pass in fp32 arithmetic (diagnostic for the config-3 tolerance sweep)
   float *d_c32 = nullptr, *d_cs32 = nullptr, *d_lut32 = nullptr;
+  int64_t opt_reproducible = 0;     // 1: order-independent (exact, binned) column sums in the fused EM pass: pi / theta / lnl bit-identical from run to run,
+                                    //    two passes per iteration
+  uint16_t* d_ebias = nullptr;      // [Kpad] per slot: biased exponent of the bound 2^E of its contributions
+  uint8_t* d_ovf = nullptr;         // [Kpad] a contribution reached its slot's bound in the last pass
+  double* d_red_hi = nullptr;       // [K+2] column sums of the high pieces
+  int16_t* d_ehist = nullptr;       // [2K] per column: exponent (+4) of its last sum, and by how many bits it fell in the last iteration
+  uint32_t* d_binflag = nullptr;    // [1] some column wants the pass repeated with another exponent
+  int64_t n_bin_repeats = 0;        // passes repeated because an exponent had to move
   int64_t opt_deconflict = -1;      // conflict-aware entry order inside the rows of the row-ordered code layout (k_sb_deconflict): -1 auto = on
                                     //    (round 3: 4 ms of setup at 2e9 entries for -6 % per EM pass; round 2's version cost 14 ms and was opt-in)
   int64_t opt_geo = -1;             // -1 auto; 0 / 2 force the geometry of teams of 1-4 (experiments)

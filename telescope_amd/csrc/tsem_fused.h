@@ -96,6 +96,11 @@ struct FusedArgs {
   double* xchg;         // [team][FZ_XS][P][R] tagged granules, zero-filled before launch
   uint32_t* sync;       // zero-filled before launch
   const uint32_t* ctl;  // device-side loop control (tsem_em_chunk): ctl[0] != 0 -> the run has stopped, return at once
+  // MODE 2 (option "reproducible"): the column scatter adds pre-rounded pieces of w*z, so that every LDS accumulator sums EXACTLY
+  // and the order in which the hardware serves the atomics stops mattering
+  const uint16_t* ebias;  // [P*Kp] biased exponent eb of the slot's bound 2^E (every contribution of the slot is < 2^E)
+  int bin;                // 1: the high piece (multiples of 2^(E-30)), 2: the low piece (the remainder in multiples of 2^(E-60))
+  uint8_t* ovf;           // [P*Kp] set to 1 when a contribution reached its slot's bound (the host raises E and repeats the pass)
   int dbg;              // bit0: skip partner loads (timing experiments only; wrong results)
                         // bit5 / bit6: behave like a hand-off time-out in the EM / lnl pass (tests of the recovery path)
   unsigned long long* prof;   // optional per-step timestamps of team 0 / member 0
@@ -243,7 +248,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     }
     const bool kv = k >= 0 && k < nblk;
     const uint64_t blk = kv ? (uint64_t)(team + k * T) : 0;
-    if (MODE == 0) {                                            // row weights (the lnl pass uses w = 1)
+    if (MODE != 1) {                                            // row weights (the lnl pass uses w = 1)
       if (FMT != 0) {
         __amdgpu_buffer_rsrc_t wr = fz_rsrc(A.wcode, blk * R * 2, kv ? (unsigned)R * 2 : 0);
 #pragma unroll
@@ -324,7 +329,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
           ys1 += __longlong_as_double((long long)v.y);
         }
         double2 w = make_double2(1.0, 1.0);
-        if (MODE == 0) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
+        if (MODE != 1) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
         // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730)
         *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(recip0(ys0) * w.x, recip0(ys1) * w.y);
         if (!OWNREG) *reinterpret_cast<double2*>(&y[(k & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   uint32_t* const sync = A.sync;
   uint32_t* const err = sync + 9;
   if (A.ctl && fz_ld_u32(A.ctl) != 0u) return;            // stopped by an earlier update kernel of this chunk
-  if (A.dbg & (MODE == 0 ? 32 : 64)) {                    // test hook: what a watchdog time-out leaves behind
+  if (A.dbg & (MODE != 1 ? 32 : 64)) {                    // test hook: what a watchdog time-out leaves behind
     if (blockIdx.x == 0 && tid == 0) atomicOr(err, 2u);
     return;
   }
@@ -503,6 +508,9 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   if (tid < 64) dum[tid] = 0.0;
   if (FMT != 0)
     for (int t = tid; t < A.lut_len; t += FZ_NT) lutS[t] = A.lut[t];
+  uint16_t* const eS = reinterpret_cast<uint16_t*>(lutS + A.lut_len);   // MODE 2: [Kp] the slots' exponent bounds
+  if (MODE == 2)
+    for (int t = tid; t < Kp; t += FZ_NT) eS[t] = A.ebias[p * Kp + t];
   const int64_t nsteps = nblk + FZ_LAG + 1;               // last scatter is block nblk-1 at step nblk+3
   // prologue: offsets of blocks 0..4 straight into LDS
   if (tid < 10) {
@@ -703,10 +711,28 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
         const uint32_t j0 = idle2 ? dj : (a0 & 0xFFFFu), j1 = idle2 ? dj : (a1 & 0xFFFFu);
         const uint32_t j2 = idle2 ? dj : (a2 & 0xFFFFu), j3 = idle2 ? dj : (a3 & 0xFFFFu);
 #endif
+        if (MODE == 2) {
+          // Exact accumulation (Demmel-Nguyen style pre-rounding on a per-slot grid): v = hi + lo + rest with hi a multiple of
+          // 2^(E-30) and lo a multiple of 2^(E-60); the sums of the hi pieces (and, in the second pass, of the lo pieces) of up to
+          // 2^23 contributions below 2^E are exact in fp64, hence the same whatever order the LDS serves the atomics in.
+          auto piece = [&](double v, uint32_t j, bool live) -> double {
+            const uint32_t eb = live ? (uint32_t)eS[j] : 1023u;
+            if (live && (uint32_t)(__double2hiint(v) >> 20) >= eb) A.ovf[p * Kp + j] = 1;    // v >= 2^E: the bound was too low
+            const double m1 = __hiloint2double((int)(((eb + 22u) << 20) | 0x80000u), 0);    // 1.5 * 2^(E+22): ulp = 2^(E-30)
+            const double hi = (v + m1) - m1;
+            if (A.bin == 1) return hi;
+            const double m2 = __hiloint2double((int)(((eb - 8u) << 20) | 0x80000u), 0);     // 1.5 * 2^(E-8):  ulp = 2^(E-60)
+            return ((v - hi) + m2) - m2;
+          };
+          const double p0 = piece(rs.v0.x * s0, j0, !idle2), p1 = piece(rs.v0.y * s1, j1, !idle2);
+          const double p2 = piece(rs.v1.x * s2, j2, !idle2), p3 = piece(rs.v1.y * s3, j3, !idle2);
+          lds_add(&acc[j0], p0); lds_add(&acc[j1], p1); lds_add(&acc[j2], p2); lds_add(&acc[j3], p3);
+        } else {
         lds_add(&acc[j0], rs.v0.x * s0);
         lds_add(&acc[j1], rs.v0.y * s1);
         lds_add(&acc[j2], rs.v1.x * s2);
         lds_add(&acc[j3], rs.v1.y * s3);
+        }
       }
       }
       asm volatile("" ::: "memory");

@@ -246,3 +246,66 @@ def test_report_pass_falls_back_beyond_65536_slots(gpu_device):
     assert np.array_equal(got['choose'], np.asarray(om.reassign('choose', initial=True).sum(0)).ravel())
     assert np.allclose(got['average'], np.asarray(om.reassign('average', initial=True).sum(0)).ravel(), rtol=1e-12, atol=1e-12)
     assert np.allclose(got['conf'], np.asarray(om.reassign('conf', 0.9).sum(0)).ravel(), rtol=1e-12, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------
+# option "reproducible": order-independent column sums
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('rows,d,fmt', [(300_000, 24, 0), (5_000_000, 40, 0), (2_000_000, 10, 1)])
+def test_reproducible_mode_is_bitwise_reproducible(gpu_device, rows, d, fmt):
+    """With `reproducible` = 1 every contribution to a column sum is split into pieces whose sums are exact in fp64, so the
+    unordered LDS atomics of the fused pass add up to the same bits in every run: pi, theta, lnl and the iteration count
+    of two independent runs are IDENTICAL — and agree with the C oracle like the default
+    mode does.  The default mode is checked to be only tolerance-equal on the same matrix (if it ever becomes bitwise
+    equal by itself this assertion can go)."""
+    from oracle import em_fused as oc
+    runs = []
+    for rep in range(2):
+        tl = _synthetic_tl(rows, 30_000, d, 'zipf', uniq=0.05, options=(('value_format', fmt), ('reproducible', 1)),
+                           opts=Opts(max_iter=200, em_epsilon=1e-4))
+        tl.em()
+        info = tl._eng.layout_info()
+        assert info['reproducible'] == 1 and info['fused'] == 1
+        runs.append((tl.n_iter, tl.pi.copy(), tl.theta.copy(), tl.lnl, tl.pi_init.copy(), info['bin_repeats']))
+        if rep == 0:
+            ip, ix, rw = tl._eng.export_csr()
+            ref = oc.em_fused_arrays(ip, ix, rw, 30_000, 0, 200000, 1e-4, 200)
+        del tl
+    a, b = runs
+    assert a[0] == b[0] == ref['n_iter'] and 3 < a[0] < 200
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3] and np.array_equal(a[4], b[4])
+    assert a[5] == b[5] and a[5] <= 4 + a[0] // 2, a[5]          # passes repeated because a column's grid had to move
+    print('reproducible: %d iterations, %d repeated passes' % (a[0], a[5]))
+    assert abs(a[3] - ref['lnl']) <= RTOL * abs(ref['lnl'])
+    assert np.allclose(a[1], ref['pi'], rtol=RTOL, atol=0) and np.allclose(a[2], ref['theta'], rtol=RTOL, atol=0)
+
+
+def test_reproducible_mode_on_goldens(gpu_device):
+    """The same option on the reference's golden cases (tiny matrices, exact twins): same iteration counts and outputs as
+    the default mode's tests demand.  A case the mode cannot take (a 65 535-wide score range does not fit the LDS table)
+    is an ERROR at set-up, not a silent switch to the order-dependent path."""
+    from telescope_amd.likelihood import TelescopeLikelihood
+    from telescope_amd._lib import EngineError
+    ran = []
+    for name in ('bundled', 'tiny_twins', 'tiny_ties', 'tiny_wide_range', 'mid_zipf_20k', 'bundled_lnl'):
+        c = load_case(name)
+        raw = case_matrix(c)
+        res = []
+        for rep in range(2):
+            try:
+                tl = TelescopeLikelihood(raw, Opts(c), device=0, engine_options={'reproducible': 1})
+            except EngineError as e:
+                assert 'reproducible mode needs' in str(e), name
+                break
+            assert tl._eng.layout_info()['fused'] == 1 and tl._eng.layout_info()['reproducible'] == 1
+            tl.em(use_likelihood=bool(c['use_likelihood']))
+            res.append((tl.n_iter, tl.pi.copy(), tl.lnl, tl.reassign_colsums('exclude')))
+        if not res:
+            continue
+        ran.append(name)
+        assert res[0][0] == res[1][0] == int(c['n_iter']), name
+        assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2], name
+        assert np.allclose(res[0][1], c['pi'], rtol=1e-10, atol=0) and abs(res[0][2] - float(c['lnl'])) <= 1e-10 * abs(float(c['lnl'])), name
+        assert np.array_equal(res[0][3], c['ra_exclude_0_colsum']), name
+    print('reproducible goldens:', ran)
+    assert len(ran) >= 4, ran
