@@ -2831,7 +2831,7 @@ __global__ void k_bin_check(int K, const double* __restrict__ red, const uint32_
                             const unsigned long long* __restrict__ colcount, const double* __restrict__ pi, const double* __restrict__ theta,
                             uint16_t* __restrict__ ebias, uint8_t* __restrict__ ovf, uint32_t* __restrict__ flag) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= K) return;
+  if (j >= K || red[K] > 0.0) return;                       // (a pass that timed out: the sums mean nothing, the update kernel refuses them)
   int copies;
   const int pc = bin_slot(colmap[j], Kp, &copies);
   const int eb = ebias[pc];

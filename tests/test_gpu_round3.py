@@ -309,3 +309,17 @@ def test_reproducible_mode_on_goldens(gpu_device):
         assert np.array_equal(res[0][3], c['ra_exclude_0_colsum']), name
     print('reproducible goldens:', ran)
     assert len(ran) >= 4, ran
+
+def test_reproducible_mode_has_no_order_dependent_fallback(gpu_device):
+    """A fused pass that times out (fused_dbg bit 5) makes the default mode rebuild its layout for the two-pass kernels;
+    those add in hardware order, so with `reproducible` the run ENDS with the error instead of continuing on them."""
+    from telescope_amd.likelihood import TelescopeLikelihood
+    from telescope_amd._lib import EngineError
+    c = load_case('mid_zipf_20k')
+    tl = TelescopeLikelihood(case_matrix(c), Opts(c), device=0, engine_options={'reproducible': 1, 'fused_dbg': 32})
+    before = tl._eng.get_params()
+    with pytest.raises(EngineError) as ei:
+        tl.em()
+    assert 'reproducible' in str(ei.value)
+    after = tl._eng.get_params()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])   # nothing was committed
