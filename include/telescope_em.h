@@ -87,7 +87,9 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *                  is off), so that a row's partial sum is one run ending in at most two atomics.  That holds for rows of up to
  *                  256 entries; with longer rows tsem_layout_info[21] reports 2 instead of 1 and the last bit of such a row's
  *                  sum may depend on timing.  Needs the fused kernel and a score table of <= 2048 entries; column sums are
- *                  within (entries of the column) x 2^-41 of exact, typically one fp64 rounding.  Default 0.
+ *                  within (entries of the column) x 2^-41 of exact, typically one fp64 rounding.  The float-valued sums of
+ *                  tsem_reassign / _rows / _groups / tsem_report_colsums (conf, average) are accumulated exactly as well
+ *                  (two atomics per value).  Default 0.
  *   "em_precision" 1: the EM pass in fp32 arithmetic (row sums, posteriors and column sums in fp32) — a
  *                  DIAGNOSTIC for the fp32-vs-fp64 tolerance sweep of BASELINE config 3, not a product path
  *   "fused_dbg", "fused_prof", "chunk_blocks"     timing experiments */

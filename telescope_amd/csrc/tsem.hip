@@ -1019,6 +1019,18 @@ static_assert(FZ_SYNC_WORDS == 16, "k_update clears 16 sync words");
 enum { RP_EXPORT_Z = 0, RP_BEST = 1, RP_REASSIGN = 2, RP_REPORT = 3 };
 constexpr int RP_SUB = 16;
 
+// Option "reproducible": values in [0, 2) — posteriors, shares of a tie — cut into a multiple of 2^-26 and the rest on the 2^-53
+// grid: up to 2^26 of either add exactly in fp64, whatever order the atomics are served in; the two sums are added once at the end.
+__device__ __forceinline__ void exact_split01(double v, double& hi, double& lo) {
+  const double m1 = 100663296.0;                            // 1.5 * 2^26: ulp 2^-26
+  hi = (v + m1) - m1;
+  lo = ((v - hi) + 0.75) - 0.75;                            // ulp(0.75) = 2^-53
+}
+__global__ void k_add_lo(int64_t n, double* __restrict__ a, const double* __restrict__ lo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += lo[i];
+}
+
 struct RowPassArgs {
   int64_t N;
   int32_t K;
@@ -1043,6 +1055,7 @@ struct RowPassArgs {
   // REASSIGN without groups: the Hs most popular slots of every column part are summed in LDS per
   // workgroup and flushed once (global fp64 atomics: 22 G/s, 2 G/s on a popular column)
   const uint32_t* colmap; const int32_t* col_of_pc; int P, Kp, Hs;
+  double* colsums_lo = nullptr;   // option "reproducible": the low pieces of every value (same shape as colsums; no LDS slots then)
 };
 
 // METH >= 0 fixes the reassign method at compile time (the per-entry switch and the reductions a method does not
@@ -1069,7 +1082,12 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
     const bool amb = (e - s) > 1;
     // one value of report column m (0 for a plain reassign) for column `col`: popular columns in LDS, the rest global
     auto emit = [&](int m, int col, uint32_t cm, double val, int64_t grp_off) {
-      if (nhot1 && (int)(cm & 0x1FFFu) < A.Hs) lds_add(&hot[m * nhot1 + (cm >> 16) * A.Hs + (cm & 0x1FFFu)], val);
+      if (A.colsums_lo) {
+        double hi, lo;
+        exact_split01(val, hi, lo);
+        unsafeAtomicAdd(&A.colsums[(int64_t)m * A.K + grp_off + col], hi);
+        if (lo != 0.0) unsafeAtomicAdd(&A.colsums_lo[(int64_t)m * A.K + grp_off + col], lo);
+      } else if (nhot1 && (int)(cm & 0x1FFFu) < A.Hs) lds_add(&hot[m * nhot1 + (cm >> 16) * A.Hs + (cm & 0x1FFFu)], val);
       else unsafeAtomicAdd(&A.colsums[(int64_t)m * A.K + grp_off + col], val);
     };
     auto numer = [&](int64_t k) -> double {
@@ -1309,6 +1327,7 @@ struct ReportArgs {
   double thresh;
   int32_t* nbest;                      // [N] number of best hits per row (0: empty pattern)
   double *g_conf, *g_n1, *g_n2, *g_avgt;   // [IDN] each, by id
+  double *g_conf_lo = nullptr, *g_avgt_lo = nullptr;   // option "reproducible": low pieces (exact_split01); LDS then holds [Hs] more doubles
   int HC, Hs;                          // LDS slots: pi*theta of ids < HC; accumulators of ids < Hs
   int32_t* defer_rows; unsigned long long* defer_n;   // rows left to k_report_slow
   int dbg;                             // timing experiments (wrong results): 1 drop the emits that miss the LDS slots, 2 the row-count stores, 4 the ties
@@ -1345,8 +1364,15 @@ template <int G> __device__ __forceinline__ int rr_sum_i(int v) {
 }
 
 struct ReportEmit {                                        // where a row's values go (both report kernels), by id
-  const ReportArgs& A; double* hotF; uint32_t* hot1; uint32_t* hot2; int Hs;
+  const ReportArgs& A; double* hotF; uint32_t* hot1; uint32_t* hot2; int Hs; double* hotL;
   __device__ __forceinline__ void conf(uint32_t id, double v) const {
+    if (A.g_conf_lo) {
+      double hi, lo;
+      exact_split01(v, hi, lo);
+      if ((int)id < Hs) { lds_add(&hotF[id], hi); if (lo != 0.0) lds_add(&hotL[id], lo); }
+      else { unsafeAtomicAdd(&A.g_conf[id], hi); if (lo != 0.0) unsafeAtomicAdd(&A.g_conf_lo[id], lo); }
+      return;
+    }
     if ((int)id < Hs) lds_add(&hotF[id], v);
     else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_conf[id], v);
   }
@@ -1358,6 +1384,11 @@ struct ReportEmit {                                        // where a row's valu
     if (nb == 2) {
       if ((int)id < Hs) atomicAdd(&hot2[id], 1u);
       else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_n2[id], 1.0);
+    } else if (A.g_avgt_lo) {
+      double hi, lo;
+      exact_split01(share, hi, lo);
+      unsafeAtomicAdd(&A.g_avgt[id], hi);
+      if (lo != 0.0) unsafeAtomicAdd(&A.g_avgt_lo[id], lo);
     } else {
       unsafeAtomicAdd(&A.g_avgt[id], share);
     }
@@ -1374,11 +1405,13 @@ __global__ __launch_bounds__(RR_NT) void k_report_rows(ReportArgs A) {
   double* const hotF = cH + A.HC;
   uint32_t* const hot1 = reinterpret_cast<uint32_t*>(hotF + A.Hs);
   uint32_t* const hot2 = hot1 + A.Hs;
+  double* const hotL = reinterpret_cast<double*>(hot2 + A.Hs);   // (only with g_conf_lo)
+  if (A.g_conf_lo) for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) hotL[t] = 0.0;
   for (int t = threadIdx.x; t < A.lut_len; t += blockDim.x) lutS[t] = A.lut[t];
   if (!INIT) for (int t = threadIdx.x; t < A.HC; t += blockDim.x) cH[t] = A.cnat2[t];
   for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) { hotF[t] = 0.0; hot1[t] = 0u; hot2[t] = 0u; }
   __syncthreads();
-  const ReportEmit EM{A, hotF, hot1, hot2, A.Hs};
+  const ReportEmit EM{A, hotF, hot1, hot2, A.Hs, hotL};
   const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
   const int64_t stride = (int64_t)gridDim.x * ngrp;
   const int64_t nit = (A.N + stride - 1) / stride;
@@ -1520,6 +1553,7 @@ __global__ __launch_bounds__(RR_NT) void k_report_rows(ReportArgs A) {
     const double v = hotF[t];
     const uint32_t c1 = hot1[t], c2 = hot2[t];
     if (v != 0.0) unsafeAtomicAdd(&A.g_conf[t], v);
+    if (A.g_conf_lo) { const double l = hotL[t]; if (l != 0.0) unsafeAtomicAdd(&A.g_conf_lo[t], l); }
     if (c1) unsafeAtomicAdd(&A.g_n1[t], (double)c1);
     if (c2) unsafeAtomicAdd(&A.g_n2[t], (double)c2);
   }
@@ -1529,7 +1563,7 @@ __global__ __launch_bounds__(RR_NT) void k_report_rows(ReportArgs A) {
 template <bool INIT>
 __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
   constexpr int G = 16;
-  const ReportEmit EM{A, nullptr, nullptr, nullptr, 0};  // (no LDS slots here: a handful of rows)
+  const ReportEmit EM{A, nullptr, nullptr, nullptr, 0, nullptr};  // (no LDS slots here: a handful of rows)
   const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
   const int64_t nd = (int64_t)*A.defer_n;
   for (int64_t d = (int64_t)blockIdx.x * ngrp + grp; d < nd; d += (int64_t)gridDim.x * ngrp) {
@@ -1571,12 +1605,13 @@ __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
 // by id -> by column: out[0..K) = conf, out[K..2K) = exclude, out[2K..3K) = average = n1 + n2 / 2 + the wider ties' shares
 __global__ void k_report_finish(int IDN, int K, const int32_t* __restrict__ col_of_id, const double* __restrict__ g_conf,
                                 const double* __restrict__ g_n1, const double* __restrict__ g_n2, const double* __restrict__ g_avgt,
-                                double* __restrict__ out) {
+                                const double* __restrict__ g_conf_lo, const double* __restrict__ g_avgt_lo, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= IDN) return;
   const int j = col_of_id[i];
   if (j < 0) return;
-  out[j] = g_conf[i]; out[K + j] = g_n1[i]; out[2 * (int64_t)K + j] = (g_n1[i] + 0.5 * g_n2[i]) + g_avgt[i];
+  const double cf = g_conf_lo ? g_conf[i] + g_conf_lo[i] : g_conf[i], av = g_avgt_lo ? g_avgt[i] + g_avgt_lo[i] : g_avgt[i];
+  out[j] = cf; out[K + j] = g_n1[i]; out[2 * (int64_t)K + j] = (g_n1[i] + 0.5 * g_n2[i]) + av;
 }
 // popularity ids: id = slot * P + part of the column's first slot in the blocked layout (popular columns come first in
 // every part, so small ids are popular columns); cnat2 by id
@@ -3696,6 +3731,25 @@ int tsem_best_ties(tsem_ctx* h, int which, int64_t cap, int32_t* rows, int32_t* 
   return rc;
 }
 
+// option "reproducible": a second, zeroed buffer for the low pieces of the values a row pass sums (exact_split01);
+// rowpass_lo_end adds it to the sums and frees it
+static int rowpass_lo_begin(tsem_ctx* h, RowPassArgs& A, int64_t n, double** lo) {
+  *lo = nullptr;
+  if (!h->opt_reproducible || n <= 0) return TSEM_OK;
+  TSEM_ALLOC(*lo, n);
+  TSEM_HIP(hipMemsetAsync(*lo, 0, sizeof(double) * n, h->stream));
+  A.colsums_lo = *lo;
+  return TSEM_OK;
+}
+static int rowpass_lo_end(tsem_ctx* h, double* sums, double* lo, int64_t n) {
+  if (!lo) return TSEM_OK;
+  k_add_lo<<<cdiv64(n, 256), 256, 0, h->stream>>>(n, sums, lo);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(lo);
+  return TSEM_OK;
+}
+
 int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks, double* colsums,
                   double* mask) {
   if (!h || !h->d_indptr || !colsums) return TSEM_ERR_ARG;
@@ -3738,6 +3792,8 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
     if (h->N) TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
   }
   A.colsums = d_cs; A.zout = d_mask; A.picks = d_picks;
+  double* d_lo = nullptr;
+  if (int rc = rowpass_lo_begin(h, A, h->K, &d_lo)) return rc;
   if (h->N && h->d_colmap && h->d_col_of_pc && h->P > 0) {
     // hot slots of every part in LDS.  `all` emits one value per stored entry, so it wants as many slots as fit: one
     // 1024-thread workgroup per CU with ~150 KB of accumulators.  The other modes emit at most a few values per ROW
@@ -3762,6 +3818,7 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
     k_rowpass<RP_REASSIGN><<<rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   }
   TSEM_HIP(hipGetLastError());
+  if (int rc = rowpass_lo_end(h, d_cs, d_lo, h->K)) return rc;
   TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
   if (mask && h->nnz) TSEM_HIP(hipMemcpyAsync(mask, d_mask, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
@@ -3801,20 +3858,23 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       R.lut = h->d_lut; R.lut_len = A.lut_len; R.cnat2 = nullptr; R.thresh = thresh; R.nbest = d_nb;
       const bool init = A.pi == nullptr;
       double *d_g = nullptr, *d_c2 = nullptr;
-      TSEM_ALLOC(d_g, 4 * (int64_t)IDN);
-      TSEM_HIP(hipMemsetAsync(d_g, 0, sizeof(double) * 4 * IDN, h->stream));
+      const bool exact = h->opt_reproducible != 0;
+      TSEM_ALLOC(d_g, 6 * (int64_t)IDN);
+      TSEM_HIP(hipMemsetAsync(d_g, 0, sizeof(double) * 6 * IDN, h->stream));
       if (!init) {
         TSEM_ALLOC(d_c2, 2 * (int64_t)IDN);
         k_cnat2_id<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, h->d_col_of_id, A.pi, A.theta, d_c2);
         R.cnat2 = d_c2;
       }
       R.g_conf = d_g; R.g_n1 = d_g + IDN; R.g_n2 = d_g + 2 * (int64_t)IDN; R.g_avgt = d_g + 3 * (int64_t)IDN;
+      if (exact) { R.g_conf_lo = d_g + 4 * (int64_t)IDN; R.g_avgt_lo = d_g + 5 * (int64_t)IDN; }
       // LDS: one workgroup of RR_NT threads per CU (or two, option rowpass_wgs).  The final z wants pi*theta of as many
       // ids as fit (8 B each) next to a few thousand accumulator slots (16 B each); the initial z has no pi*theta.
       const int wgs = h->opt_rowpass_wgs >= 2 && h->opt_report_wgs2 ? 2 : 1;
       const int lds_avail = TS_LDS_MAX / wgs - 2048 - R.lut_len * 8;
-      R.Hs = std::min(IDN, init ? lds_avail / 16 : std::min(3072, lds_avail / 16 / 4));
-      R.HC = init ? 0 : std::max(0, std::min(IDN, (lds_avail - R.Hs * 16) / 8));
+      const int slot_bytes = exact ? 24 : 16;                // conf (f64) + two counters (+ the low pieces)
+      R.Hs = std::min(IDN, init ? lds_avail / slot_bytes : std::min(3072, lds_avail / slot_bytes / 4));
+      R.HC = init ? 0 : std::max(0, std::min(IDN, (lds_avail - R.Hs * slot_bytes) / 8));
       int cap = 256;                                       // G x E
       if (h->opt_report_lanes > 0) {
         cap = (int)h->opt_report_lanes;
@@ -3831,12 +3891,12 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       R.dbg = (int)h->opt_report_dbg;
       R.defer_rows = d_rows; R.defer_n = d_n;               // (d_rows is the tie list later: the slow kernel is done with it by then)
       TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
-      rk<<<h->n_cu * wgs, RR_NT, (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * 16, h->stream>>>(R);
+      rk<<<h->n_cu * wgs, RR_NT, (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * slot_bytes, h->stream>>>(R);
       TSEM_HIP(hipGetLastError());
       if (init) k_report_slow<true><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
       else k_report_slow<false><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
       TSEM_HIP(hipGetLastError());
-      k_report_finish<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, K, h->d_col_of_id, R.g_conf, R.g_n1, R.g_n2, R.g_avgt, d_cs);
+      k_report_finish<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, K, h->d_col_of_id, R.g_conf, R.g_n1, R.g_n2, R.g_avgt, R.g_conf_lo, R.g_avgt_lo, d_cs);
       TSEM_HIP(hipGetLastError());
       TSEM_HIP(hipStreamSynchronize(h->stream));
       (void)hipFree(d_g);
@@ -3846,9 +3906,17 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;
       A.Hs = std::max(0, std::min(h->Kp, (int)((TS_LDS_MAX / wgs - 8192 / wgs - 1024 - A.lut_len * 8) / 8 / h->P / 3)));
       TSEM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      double* d_lo = nullptr;
+      if (int rc = rowpass_lo_begin(h, A, 3 * (int64_t)K, &d_lo)) return rc;
       kern<<<h->n_cu * wgs, 1024, (size_t)(3 * A.P * A.Hs + A.lut_len) * 8, h->stream>>>(A);
+      TSEM_HIP(hipGetLastError());
+      if (int rc = rowpass_lo_end(h, d_cs, d_lo, 3 * (int64_t)K)) return rc;
     } else {
+      double* d_lo = nullptr;
+      if (int rc = rowpass_lo_begin(h, A, 3 * (int64_t)K, &d_lo)) return rc;
       kern<<<rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+      TSEM_HIP(hipGetLastError());
+      if (int rc = rowpass_lo_end(h, d_cs, d_lo, 3 * (int64_t)K)) return rc;
     }
     TSEM_HIP(hipGetLastError());
     size_t tb = 0;
@@ -3924,8 +3992,11 @@ int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const 
   A.method = method; A.thresh = thresh; A.colsums = d_cs; A.picks = d_picks;
   A.rowlist = rows ? d_rows : h->d_tie_rows; A.nlist = n;
   const int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + 15) / 16));
+  double* d_lo = nullptr;
+  if (int rc = rowpass_lo_begin(h, A, h->K, &d_lo)) return rc;
   k_rowpass<RP_REASSIGN><<<grid, 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
+  if (int rc = rowpass_lo_end(h, d_cs, d_lo, h->K)) return rc;
   TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
   (void)hipFree(d_cs);
@@ -3956,8 +4027,11 @@ int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, cons
     if (h->N) TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
   }
   A.colsums = d_out; A.picks = d_picks; A.group = d_grp;
+  double* d_lo = nullptr;
+  if (int rc = rowpass_lo_begin(h, A, n_out, &d_lo)) return rc;
   if (h->N && n_out) k_rowpass<RP_REASSIGN><<<rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
+  if (int rc = rowpass_lo_end(h, d_out, d_lo, n_out)) return rc;
   if (n_out) TSEM_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
   (void)hipFree(d_out); (void)hipFree(d_grp);

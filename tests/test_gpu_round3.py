@@ -323,3 +323,43 @@ def test_reproducible_mode_has_no_order_dependent_fallback(gpu_device):
     assert 'reproducible' in str(ei.value)
     after = tl._eng.get_params()
     assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])   # nothing was committed
+
+
+def test_reproducible_report_sums_are_bitwise_reproducible(gpu_device):
+    """The float-valued report columns (`conf`, `average` of TE_counts.tsv, model.py:455-458) under `reproducible`: every
+    value is cut into two pieces whose sums are exact (exact_split01), in the streaming report kernel, in the generic row
+    pass and in the per-barcode pass alike — two independent contexts give the same bits; against the default mode the
+    sums agree to rounding."""
+    from telescope_amd._lib import Z_PREV, Z_INITIAL
+    rows = 2_000_000
+    groups = [np.arange(0, rows, 7), np.arange(3, rows, 11), np.array([5, 5, 9])]
+    got = {}
+    for mode in ('default', 'a', 'b'):
+        options = () if mode == 'default' else (('reproducible', 1),)
+        tl = _synthetic_tl(rows, 30_000, 24, 'zipf', uniq=0.05, options=options, opts=Opts(max_iter=6, em_epsilon=0.0))
+        tl.em()
+        res = {}
+        for kern in (1, 0):
+            tl._eng.set_option('report_kernel', kern)
+            for which in (Z_PREV, Z_INITIAL):
+                sums, r, c = tl._eng.report_colsums(which, 0.9)
+                res[(kern, which)] = (sums['conf'].copy(), sums['average'].copy(), sums['exclude'].copy(), r.copy(), c.copy())
+        tl._eng.set_option('report_kernel', 1)
+        res['conf_single'] = tl._eng.reassign('conf', 0.9, Z_PREV)[0].copy()
+        res['avg_single'] = tl._eng.reassign('average', 0.9, Z_PREV)[0].copy()
+        res['groups'] = tl.reassign_group_sums('conf', groups, 0.9).copy()
+        got[mode] = res
+        del tl
+    a, b, d = got['a'], got['b'], got['default']
+    for key in a:
+        if isinstance(a[key], tuple):
+            for x, y, z in zip(a[key], b[key], d[key]):
+                assert np.array_equal(x, y), key
+                assert np.allclose(x, z, rtol=1e-11, atol=1e-9), key
+        else:
+            assert np.array_equal(a[key], b[key]), key
+            assert np.allclose(a[key], d[key], rtol=1e-11, atol=1e-9), key
+    # the two kernels compute a row's posteriors with different (fixed) reduction trees: equal to rounding, not bit for bit
+    assert np.allclose(a[(1, Z_PREV)][0], a[(0, Z_PREV)][0], rtol=1e-11, atol=1e-9)
+    assert np.array_equal(a[(1, Z_PREV)][2], a[(0, Z_PREV)][2])
+    assert float(a[(1, Z_PREV)][0].sum()) > 1e5                  # (not vacuous)
