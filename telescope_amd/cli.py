@@ -53,6 +53,8 @@ def build_parser():
     g.add_argument('--skip_em', action='store_true', help='Exits after loading the checkpoint.')
     g = rs.add_argument_group('Device')
     g.add_argument('--device', type=int, default=0, help='GPU index (single-process runs).')
+    g.add_argument('--reproducible', action='store_true',
+                   help='Exact, order-independent sums on the device: the same bits in every run (about 2.4x the time per EM iteration).')
     asg = sub.add_parser('assign', help='Load alignments + annotation, checkpoint, EM, reports')
     g = asg.add_argument_group('Input Options')
     g.add_argument('samfile', help='Path to alignment file (BAM, collated by read name).  Read by a streaming '
@@ -94,6 +96,8 @@ def build_parser():
     g.add_argument('--skip_em', action='store_true', help='Exits after loading alignment and saving checkpoint file.')
     g = asg.add_argument_group('Device')
     g.add_argument('--device', type=int, default=0, help='GPU index (single-process runs).')
+    g.add_argument('--reproducible', action='store_true',
+                   help='Exact, order-independent sums on the device: the same bits in every run (about 2.4x the time per EM iteration).')
     return ap
 
 
@@ -141,7 +145,8 @@ def run_resume(args):
     seed = ts.get_random_seed()
     lg.debug('Random seed: {}'.format(seed))
     np.random.seed(seed)
-    ts_model = TelescopeLikelihood(ts.raw_scores, opts, device=opts.device)
+    ts_model = TelescopeLikelihood(ts.raw_scores, opts, device=opts.device,
+                                   engine_options={'reproducible': 1} if opts.reproducible else None)
     lg.info('Running Expectation-Maximization...')
     stime = time()
     ts_model.em(use_likelihood=opts.use_likelihood, loglev=lg.INFO)
@@ -189,7 +194,8 @@ def run_assign(args):
     seed = ts.get_random_seed()
     lg.debug('Random seed: {}'.format(seed))
     np.random.seed(seed)
-    ts_model = TelescopeLikelihood(ts.raw_scores, opts, device=opts.device)
+    ts_model = TelescopeLikelihood(ts.raw_scores, opts, device=opts.device,
+                                   engine_options={'reproducible': 1} if opts.reproducible else None)
     lg.info('Running Expectation-Maximization...')
     stime = time()
     ts_model.em(use_likelihood=opts.use_likelihood, loglev=lg.INFO)

@@ -2863,7 +2863,8 @@ __device__ __forceinline__ int bin_slot(uint32_t cm, int Kp, int* copies) {
   return (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu);
 }
 __global__ void k_bin_check(int K, const double* __restrict__ red, const uint32_t* __restrict__ colmap, int Kp,
-                            const unsigned long long* __restrict__ colcount, const double* __restrict__ pi, const double* __restrict__ theta,
+                            const unsigned long long* __restrict__ colcount, const uint32_t* __restrict__ ucount,
+                            const double* __restrict__ pi, const double* __restrict__ theta,
                             uint16_t* __restrict__ ebias, uint8_t* __restrict__ ovf, uint32_t* __restrict__ flag) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= K || red[K] > 0.0) return;                       // (a pass that timed out: the sums mean nothing, the update kernel refuses them)
@@ -2875,7 +2876,11 @@ __global__ void k_bin_check(int K, const double* __restrict__ red, const uint32_
   const double S = red[j];
   int eb_new = eb;
   if (over) eb_new = eb + 12;
-  else if (S == 0.0) { if (colcount && colcount[j] > 0 && pi[j] * theta[j] != 0.0 && eb > 120) eb_new = eb - 24; }
+  else if (S == 0.0) {
+    // nothing arrived: too coarse a grid, unless the column has no entry in a row of several (those of single-entry rows feed pi
+    // through pisum0, not through this pass) or pi * theta is zero
+    if (colcount && colcount[j] > (ucount ? ucount[j] : 0u) && pi[j] * theta[j] != 0.0 && eb > 120) eb_new = eb - 24;
+  }
   else {
     // (a high sum a few grid steps large says little about S: move by at most 24 bits and keep 6 bits in hand)
     const int ex4 = (int)((__double2hiint(S) >> 20) & 0x7FF) + 4;
@@ -2940,7 +2945,7 @@ int tsem_em_pass(tsem_ctx* h) {
     for (int attempt = 0;; ++attempt) {
       if (int rc = pass(1, attempt == 0 ? pair : nullptr)) return rc;
       TSEM_HIP(hipMemsetAsync(h->d_binflag, 0, 4, h->stream));
-      k_bin_check<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_red, h->d_colmap, h->Kp, h->d_colcount, h->d_pi, h->d_theta,
+      k_bin_check<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_red, h->d_colmap, h->Kp, h->d_colcount, h->d_ucount, h->d_pi, h->d_theta,
                                                             h->d_ebias, h->d_ovf, h->d_binflag);
       TSEM_HIP(hipGetLastError());
       uint32_t redo = 0;

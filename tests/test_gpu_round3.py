@@ -363,3 +363,39 @@ def test_reproducible_report_sums_are_bitwise_reproducible(gpu_device):
     assert np.allclose(a[(1, Z_PREV)][0], a[(0, Z_PREV)][0], rtol=1e-11, atol=1e-9)
     assert np.array_equal(a[(1, Z_PREV)][2], a[(0, Z_PREV)][2])
     assert float(a[(1, Z_PREV)][0].sum()) > 1e5                  # (not vacuous)
+
+
+def test_reproducible_mode_between_two_ranks(gpu_device):
+    """Row shards on two participants (in-process transport, the shipped chunk loop) with `reproducible`: each rank's sums
+    are exact, the all-reduce adds them in rank order — two executions give the same bits on both ranks, and the golden
+    result."""
+    from telescope_amd.distributed import ThreadGroup, shard_bounds
+    from telescope_amd.likelihood import TelescopeLikelihood
+    c = load_case('mid_zipf_20k')
+    raw = case_matrix(c).tocsr()
+    o = Opts(c)
+    cuts = shard_bounds(raw.shape[0], 2, indptr=raw.indptr)
+    runs = []
+    for execution in range(2):
+        group = ThreadGroup(0, 2)
+
+        def rank_main(rank):
+            comm = group.comm(rank)
+            r0, r1 = cuts[rank], cuts[rank + 1]
+            tl = TelescopeLikelihood(raw[r0:r1], o, device=0, comm=comm,
+                                     engine_options={'row_offset': r0, 'reproducible': 1})
+            assert tl._eng.layout_info()['fused'] == 1 and tl._eng.layout_info()['reproducible'] == 1
+            tl.em()
+            res = (tl.n_iter, tl.lnl, tl.pi.copy(), tl.theta.copy(), tl.reassign_colsums('conf', 0.9, False).copy())
+            comm.close()
+            return res
+        try:
+            runs.append(_run_ranks(2, rank_main))
+        finally:
+            group.close()
+    (a0, a1), (b0, b1) = runs
+    for x in (a1, b0, b1):
+        assert x[0] == a0[0] == int(c['n_iter']) and x[1] == a0[1]
+        assert np.array_equal(x[2], a0[2]) and np.array_equal(x[3], a0[3]) and np.array_equal(x[4], a0[4])
+    assert np.allclose(a0[2], c['pi'], rtol=1e-10, atol=0) and abs(a0[1] - float(c['lnl'])) <= 1e-10 * abs(float(c['lnl']))
+    assert np.allclose(a0[4], c['ra_conf_0_colsum'], rtol=1e-9, atol=1e-12)

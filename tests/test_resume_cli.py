@@ -53,6 +53,28 @@ def test_resume_writes_reference_reports(gpu_device, tmp_path, mode):
             assert sorted(got.splitlines()) == sorted(want.splitlines()), suffix
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['average', 'conf'])
+def test_resume_reproducible_writes_the_same_bytes_twice(gpu_device, tmp_path, mode):
+    """`--reproducible`: the reports with a float-valued count column (model.py:455-458 writes it unrounded) are the
+    same files in two runs, and the reference's."""
+    outs = []
+    for rep in ('a', 'b'):
+        d = tmp_path / rep
+        d.mkdir()
+        cmd = [sys.executable, '-m', 'telescope_amd', 'resume', os.path.join(GOLD, 'resume_checkpoint.npz'),
+               '--outdir', str(d), '--exp_tag', 'run', '--reassign_mode', mode, '--reproducible']
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert 'EM converged after 16 iterations.' in r.stderr and 'Final log-likelihood: 95252.596293.' in r.stderr
+        outs.append({sfx: open(os.path.join(str(d), 'run-' + sfx)).read() for sfx in ('run_stats.tsv', 'TE_counts.tsv')})
+    assert outs[0] == outs[1]
+    for sfx, got in outs[0].items():
+        want = open(os.path.join(GOLD, 'resume_%s-%s' % (mode, sfx))).read()
+        if got != want:
+            assert sorted(got.splitlines()) == sorted(want.splitlines()), sfx
+
+
 def test_loader_reproduces_bundled_matrix():
     """BAM + GTF -> the score matrix the reference's loader builds for its `telescope test` data
     (validated through the README log-likelihood and the golden report, tools/make_golden.py)."""
