@@ -73,6 +73,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-layout', action='store_true',
                     help='skip the second measurement with 2-byte score codes (N=1, default --value-format only)')
+    ap.add_argument('--no-reproducible-leg', action='store_true', help='skip the `reproducible_mode` block (option reproducible on a 10M-row sample)')
     ap.add_argument('--no-precision-sweep', action='store_true',
                     help='skip the fp32-vs-fp64 tolerance sweep of BASELINE config 3 (N=1 only; ~10 s)')
     ap.add_argument('--force-comm', action='store_true',
@@ -401,6 +402,13 @@ def main():
             logging.disable(logging.NOTSET)
         except Exception as e:   # noqa: BLE001 — never let the extra block break the bench line
             out['precision_sweep'] = dict(error=repr(e))
+    if world == 1 and not args.no_reproducible_leg:
+        # option `reproducible` (exact, order-independent sums) on a 10M-row sample of the workload: what it costs
+        # per EM pass and whether two independent contexts agree bit for bit (the default mode is timed beside it)
+        try:
+            out['reproducible_mode'] = reproducible_leg(local, min(10_000_000, args.rows), args, cdf, dist_code)
+        except Exception as e:   # noqa: BLE001
+            out['reproducible_mode'] = dict(error=repr(e))
     _shutdown(comm)
     try:   # RCCL prints its version banner through C stdio: flush it first so the JSON is the LAST line
         import ctypes
@@ -408,6 +416,38 @@ def main():
     except Exception:   # noqa: BLE001
         pass
     print(json.dumps(out), flush=True)
+
+
+def reproducible_leg(device, rows, args, cdf, dist_code, iters=10):
+    import logging
+    from telescope_amd._lib import Engine
+    from telescope_amd.likelihood import TelescopeLikelihood
+    logging.disable(logging.WARNING)
+    res = {}
+    try:
+        for mode in (0, 1, 1):
+            eng = Engine(device)
+            eng.set_option('reproducible', mode)
+            eng.generate(0, rows, args.cols, cdf, args.seed, dist_code, 0.05)
+            tl = TelescopeLikelihood.from_engine(eng, Opts(iters), None)
+            eng.em_chunk(2, 0.0, False)
+            eng.synchronize()
+            t0 = time.perf_counter()
+            eng.em_chunk(iters, 0.0, False)
+            eng.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / iters
+            pi, theta = eng.get_params()
+            info = eng.layout_info()
+            res.setdefault(mode, []).append((ms, pi.copy(), theta.copy(), info['bin_repeats']))
+            eng.close()
+            del tl
+    finally:
+        logging.disable(logging.NOTSET)
+    d, (a, b) = res[0][0], res[1]
+    return dict(sample_rows=rows, iterations=iters + 2, ms_per_step_default=d[0], ms_per_step=min(a[0], b[0]),
+                cost_vs_default=min(a[0], b[0]) / d[0], repeated_passes=int(a[3]),
+                two_runs_bit_identical=bool((a[1] == b[1]).all() and (a[2] == b[2]).all()),
+                pi_max_rel_delta_vs_default=float(abs(a[1] - d[1]).max() / d[1].max()))
 
 
 def _pmc_traffic(total_rows, args, world, value_bytes):

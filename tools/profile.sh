@@ -30,14 +30,14 @@ tools/ubench/lds > $OUT/lds_ubench.log 2>&1
 tools/ubench/stream > $OUT/stream_ubench.log 2>&1
 # per-iteration cost outside the EM kernel, and what the library communicator adds (1 rank: host + launch side only)
 for kt in 0; do for fc in "" "--force-comm"; do for r in 6250000 50000000; do
-  python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-alt-layout --no-precision-sweep --kernel-timing $kt --rows $r $fc 2>/dev/null | tail -1 | python -c "
+  python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-alt-layout --no-precision-sweep --no-reproducible-leg --kernel-timing $kt --rows $r $fc 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('rows $r kernel_timing $kt $fc: %.4f ms per EM iteration' % d['ms_per_step'])"
 done; done; done > $OUT/comm_overhead.txt 2>&1
 for r in 6250000 50000000; do
-  python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-alt-layout --no-precision-sweep --kernel-timing 1 --rows $r 2>/dev/null | tail -1 | python -c "
+  python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-alt-layout --no-precision-sweep --no-reproducible-leg --kernel-timing 1 --rows $r 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('rows $r kernel_timing 1: %.4f ms per EM iteration, EM kernel %.4f ms' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
 done >> $OUT/comm_overhead.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep --kernel-timing 0 --rows 6250000 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep --no-reproducible-leg --kernel-timing 0 --rows 6250000 > /dev/null 2>&1
 python tools/iter_timeline.py $(ls $OUT/tl/*/*_kernel_trace.csv | head -1) 12 2 > $OUT/iter_timeline.txt 2>&1
 tools/sweep_r02.sh > $OUT/sweep.txt 2>&1
 python tools/time_setup.py > $OUT/time_setup.txt 2>&1

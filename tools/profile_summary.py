@@ -66,7 +66,7 @@ def main():
     src, prefix = sys.argv[1], sys.argv[2]
     one = lambda pat: sorted(glob.glob(os.path.join(src, pat)))[0]
     bench = json.load(open(os.path.join(src, 'bench.json')))
-    cmd = 'python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-sweep'
+    cmd = 'python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-sweep --no-reproducible-leg'
     kl, avg = kernel_table(one('trace/*/*_kernel_trace.csv'))
     with open(os.path.join(ROOT, 'profiles', prefix + '_fused_kernel_stats.txt'), 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats -- %s   (default workload; the run times the headline fp64\n'

@@ -1,6 +1,6 @@
 #!/bin/bash
 # many EM iterations back to back per layout / geometry: no watchdog time-out, no fallback, stable time per iteration
-run() { python bench.py --steps $1 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep "${@:2}" 2>/dev/null | tail -1 | python -c "
+run() { python bench.py --steps $1 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep --no-reproducible-leg "${@:2}" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); l=d['config']['layout']
 print('%-44s steps %5d  ms/iteration %.3f  EM kernel ms %.3f  fallbacks %d  tag misses in the last pass %d  geo %d R %d' % ('${*:2}', d['steps'], d['ms_per_step'], d['roofline']['kernel_ms'], l['fallbacks'], l['slow_path'], l['geometry'], l['R']))"; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # geometry A/B at short rows: tools/sweep_geo.sh "<nnz values>" "<geometries>"
-C="--steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep --value-format auto"
+C="--steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep --no-reproducible-leg --value-format auto"
 run() { python bench.py $C "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); l=d['config']['layout']

@@ -1,6 +1,6 @@
 #!/bin/bash
 # order x geometry x format sweep of the fused EM kernel (kernel ms), the table behind the layout rules
-C="--steps 12 --warmup 2 --no-cpu-baseline --no-alt-layout --no-precision-sweep"
+C="--steps 12 --warmup 2 --no-cpu-baseline --no-alt-layout --no-precision-sweep --no-reproducible-leg"
 run() { python bench.py $C "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); l=d['config']['layout']

@@ -1,4 +1,4 @@
-C="--steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep"
+C="--steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep --no-reproducible-leg"
 run() { python bench.py $C "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); l=d['config']['layout']

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the library's own layout choice (value_format auto = score codes, deconflict on, geometry by row length) and the fp64 layout at short
 # rows, three repeats on one box: kernel ms and fraction of the HBM peak per EM pass
-C="--steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep"
+C="--steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep --no-reproducible-leg"
 run() { python bench.py $C "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); l=d['config']['layout']
