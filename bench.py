@@ -177,7 +177,11 @@ def self_launch(args):
     th.start()
     rcs = [None] * n
     deadline = None
+    hard = time.time() + float(os.environ.get('TSEM_BENCH_TIMEOUT', '1500'))   # nothing here may hang the caller for good
     while any(rc is None for rc in rcs):
+        if time.time() > hard and deadline is None:
+            print('bench.py: ranks still running after TSEM_BENCH_TIMEOUT s: stopping them', file=sys.stderr, flush=True)
+            deadline = 0.0
         for r, p in enumerate(procs):
             if rcs[r] is None:
                 rcs[r] = p.poll()

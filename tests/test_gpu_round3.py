@@ -399,3 +399,82 @@ def test_reproducible_mode_between_two_ranks(gpu_device):
         assert np.array_equal(x[2], a0[2]) and np.array_equal(x[3], a0[3]) and np.array_equal(x[4], a0[4])
     assert np.allclose(a0[2], c['pi'], rtol=1e-10, atol=0) and abs(a0[1] - float(c['lnl'])) <= 1e-10 * abs(float(c['lnl']))
     assert np.allclose(a0[4], c['ra_conf_0_colsum'], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_reproducible_mode_on_random_shapes(gpu_device, seed):
+    """The shapes of test_random_shapes_against_oracle (1..5 column parts, one block or many, rows of 1..120 entries,
+    0..60 % single-entry rows, forced block sizes, priors on and off — with both priors 0 columns die and their grids must
+    follow them down) under `reproducible`: two contexts agree bit for bit, and with the oracle to the usual tolerance.  A
+    shape the mode cannot take must be refused at set-up."""
+    import scipy.sparse as sp
+    from oracle.telescope_oracle import OracleModel
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+    rng = np.random.RandomState(7000 + seed)
+    k = int(rng.choice([3, 17, 200, 5000, 9000, 16000, 24000, 33000]))
+    n = int(rng.choice([7, 300, 2500, 12000, 40000]))
+    max_len = int(min(k, rng.choice([2, 5, 30, 120])))
+    uniq = float(rng.choice([0.0, 0.1, 0.6]))
+    lens = np.where(rng.rand(n) < uniq, 1, rng.randint(1, max_len + 1, n))
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    lo, hi = [(139, 212), (1, 5), (100, 1500), (60000, 65535)][int(rng.randint(4))]
+    data = rng.randint(lo, hi + 1, indptr[-1]).astype(np.uint16)
+    raw = sp.csr_matrix((data, indices, indptr), shape=(n, k))
+    options = [('reproducible', 1)]
+    if rng.rand() < 0.3:
+        options.append(('block_rows', int(rng.choice([64, 128, 256]))))
+    o = Opts(max_iter=int(rng.randint(2, 12)), em_epsilon=0.0)
+    o.pi_prior, o.theta_prior = [(0, 200000), (0, 0), (5, 1000)][int(rng.randint(3))]
+    res = []
+    for rep in range(2):
+        eng = _lib.Engine(0)
+        for key, v in options:
+            eng.set_option(key, v)
+        eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), k, score_lut(int(raw.data.max())))
+        try:
+            tl = TelescopeLikelihood.from_engine(eng, o)
+        except _lib.EngineError as e:
+            assert 'reproducible mode needs' in str(e)
+            assert hi > 2047 or eng.layout_info()['fused'] == 0, (seed, n, k, hi)   # the documented limits, nothing else
+            return
+        tl._raw = raw
+        tl.em()
+        res.append((tl.lnl, tl.pi.copy(), tl.theta.copy(), tl.reassign_colsums('conf').copy(), eng.layout_info()))
+    a, b = res
+    ctx = (seed, n, k, max_len, uniq, (lo, hi), options, a[4])
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), ctx
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    om.em(0.0, o.max_iter)
+    assert abs(a[0] - om.lnl) <= RTOL * max(abs(om.lnl), 1e-300), ctx
+    assert np.allclose(a[1], om.pi, rtol=RTOL, atol=1e-300) and np.allclose(a[2], om.theta, rtol=RTOL, atol=1e-300), ctx
+    assert np.allclose(a[3], np.asarray(om.reassign('conf').sum(0)).ravel(), rtol=1e-9, atol=1e-12), ctx
+
+
+def test_reproducible_mode_reports_rows_it_cannot_vouch_for(gpu_device):
+    """A row of more than 256 entries can end in three row-sum atomics (a run across three wavefronts), whose order is
+    the hardware's: tsem_layout_info[21] says 2 instead of 1 then (include/telescope_em.h); the results stay within the
+    usual tolerance of the oracle."""
+    import scipy.sparse as sp
+    from oracle.telescope_oracle import OracleModel
+    from telescope_amd.likelihood import TelescopeLikelihood
+    rng = np.random.RandomState(5)
+    n, k = 3000, 6000
+    lens = rng.randint(2, 20, n)
+    lens[17] = 700
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    raw = sp.csr_matrix((rng.randint(100, 300, indptr[-1]).astype(np.uint16), indices, indptr), shape=(n, k))
+    o = Opts(max_iter=4, em_epsilon=0.0)
+    tl = TelescopeLikelihood(raw, o, device=0, engine_options={'reproducible': 1})
+    assert tl._eng.layout_info()['reproducible'] == 2
+    tl.em()
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    om.em(0.0, o.max_iter)
+    assert abs(tl.lnl - om.lnl) <= RTOL * abs(om.lnl) and np.allclose(tl.pi, om.pi, rtol=RTOL, atol=0)
+    lens[17] = 200
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    raw = sp.csr_matrix((rng.randint(100, 300, indptr[-1]).astype(np.uint16), indices, indptr), shape=(n, k))
+    assert TelescopeLikelihood(raw, o, device=0, engine_options={'reproducible': 1})._eng.layout_info()['reproducible'] == 1
