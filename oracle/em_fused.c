@@ -16,7 +16,8 @@
  *   mstep   724-742  thetasum_j = sum_i z_ij w_i Y_i;  theta = (thetasum + tp) / (W_amb + tp K);
  *                    pi = (pisum0 + thetasum + pp) / (W_tot + pp K),  tp = theta_prior * w_max, pp = pi_prior * w_max
  *   lnl     744-760  sum_ij z_ij log1p(inner_ij), inner built like n but with the NEW pi, theta
- *   loop    762-806  diff = sum |pi_new - pi|; stop at diff < eps or max_iter; lnl of (last z, final pi/theta)
+ *   loop    762-806  diff = sum |pi_new - pi|; stop at diff < eps (or, use_likelihood, |lnl - previous lnl| < eps) or max_iter;
+ *                    lnl of (last z, final pi/theta)
  * Summation order differs from scipy's (row-parallel partial sums), so results agree to rounding, not bitwise.
  */
 #include <math.h>
@@ -31,10 +32,10 @@ static inline double recip0(double v) { double r = 1.0 / v; return isinf(r) ? 0.
 
 /* returns the number of iterations run, or -1 on allocation failure.
  * out: pi[K], theta[K], pi_init[K] (after the first iteration), *lnl, *converged, diffs[max_iter] (may be NULL) */
-int oracle_em_fused(int64_t N, int32_t K, const int64_t* indptr, const int32_t* indices, const uint16_t* raw,
-                    const double* lut, double pi_prior, double theta_prior, double epsilon, int32_t max_iter,
-                    int32_t nthreads, double* pi, double* theta, double* pi_init, double* lnl, int32_t* converged,
-                    double* diffs) {
+int oracle_em_fused2(int64_t N, int32_t K, const int64_t* indptr, const int32_t* indices, const uint16_t* raw,
+                     const double* lut, double pi_prior, double theta_prior, double epsilon, int32_t max_iter,
+                     int32_t use_likelihood, int32_t nthreads, double* pi, double* theta, double* pi_init, double* lnl,
+                     int32_t* converged, double* diffs) {
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
   const int T = omp_get_max_threads();
@@ -96,8 +97,9 @@ int oracle_em_fused(int64_t N, int32_t K, const int64_t* indptr, const int32_t* 
     ++it;
     if (diffs) diffs[it - 1] = diff;
     conv = diff < epsilon;                                            /* model.py:781,792 */
-    if (conv || it >= max_iter) {
-      /* final lnl: z from the parameters BEFORE this M-step, inner from the ones after it (model.py:795-801) */
+    if (use_likelihood || conv || it >= max_iter) {
+      /* lnl: z from the parameters BEFORE this M-step, inner from the ones after it — of every iteration under
+       * use_likelihood (model.py:783-789), else of the last one (model.py:795-801) */
       double l = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : l)
       for (int64_t i = 0; i < N; ++i) {
@@ -113,6 +115,7 @@ int oracle_em_fused(int64_t N, int32_t K, const int64_t* indptr, const int32_t* 
           if (z != 0.0) l += z * log1p(inner);
         }
       }
+      if (use_likelihood) conv = fabs(l - total_lnl) < epsilon;       /* model.py:786-788; self.lnl starts at inf (model.py:676) */
       total_lnl = l;
     }
     memcpy(pi, pin, sizeof(double) * K);
@@ -123,6 +126,14 @@ int oracle_em_fused(int64_t N, int32_t K, const int64_t* indptr, const int32_t* 
   if (converged) *converged = conv;
   free(acc); free(pisum0); free(c); free(pin); free(thn); free(w);
   return it;
+}
+
+int oracle_em_fused(int64_t N, int32_t K, const int64_t* indptr, const int32_t* indices, const uint16_t* raw,
+                    const double* lut, double pi_prior, double theta_prior, double epsilon, int32_t max_iter,
+                    int32_t nthreads, double* pi, double* theta, double* pi_init, double* lnl, int32_t* converged,
+                    double* diffs) {
+  return oracle_em_fused2(N, K, indptr, indices, raw, lut, pi_prior, theta_prior, epsilon, max_iter, 0, nthreads, pi, theta,
+                          pi_init, lnl, converged, diffs);
 }
 
 /* reassign('exclude').sum(0) (model.py:837-842, sparse_plus.py:99-129) with z = estep(pi, theta) computed row by

@@ -22,6 +22,9 @@ def lib():
         L.oracle_em_fused.restype = C.c_int
         L.oracle_em_fused.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, dbl, dbl, dbl, C.c_int32, C.c_int32,
                                       vp, vp, vp, vp, vp, vp]
+        L.oracle_em_fused2.restype = C.c_int
+        L.oracle_em_fused2.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, dbl, dbl, dbl, C.c_int32, C.c_int32, C.c_int32,
+                                       vp, vp, vp, vp, vp, vp]
         L.oracle_exclude_counts.restype = C.c_int
         L.oracle_exclude_counts.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
         _lib = L
@@ -33,10 +36,11 @@ def score_lut(max_score, scale=100.):
     return np.expm1((np.arange(max_score + 1, dtype=np.uint16) * (1. / max_score)) * scale)
 
 
-def em_fused(raw, pi_prior=0, theta_prior=200000, epsilon=1e-7, max_iter=100, nthreads=0):
+def em_fused(raw, pi_prior=0, theta_prior=200000, epsilon=1e-7, max_iter=100, nthreads=0, use_likelihood=False):
     """EM on a scipy CSR of integer raw scores; returns dict(pi, theta, pi_init, lnl, n_iter, converged, diffs)."""
     raw = raw.tocsr()
-    return em_fused_arrays(raw.indptr, raw.indices, raw.data, raw.shape[1], pi_prior, theta_prior, epsilon, max_iter, nthreads)
+    return em_fused_arrays(raw.indptr, raw.indices, raw.data, raw.shape[1], pi_prior, theta_prior, epsilon, max_iter, nthreads,
+                           use_likelihood)
 
 
 def exclude_counts(indptr, indices, data, k, pi, theta, max_score=None):
@@ -53,7 +57,8 @@ def exclude_counts(indptr, indices, data, k, pi, theta, max_score=None):
     return counts
 
 
-def em_fused_arrays(indptr, indices, data, k, pi_prior=0, theta_prior=200000, epsilon=1e-7, max_iter=100, nthreads=0):
+def em_fused_arrays(indptr, indices, data, k, pi_prior=0, theta_prior=200000, epsilon=1e-7, max_iter=100, nthreads=0,
+                    use_likelihood=False):
     """The same on raw CSR arrays (no scipy object, no copies when the dtypes already match)."""
     indptr = np.ascontiguousarray(indptr, dtype=np.int64)
     indices = np.ascontiguousarray(indices, dtype=np.int32)
@@ -64,9 +69,9 @@ def em_fused_arrays(indptr, indices, data, k, pi_prior=0, theta_prior=200000, ep
     lnl, conv = C.c_double(), C.c_int32()
     diffs = np.zeros(max(1, max_iter))
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    it = lib().oracle_em_fused(n, k, p(indptr), p(indices), p(data), p(lut), float(pi_prior), float(theta_prior),
-                               float(epsilon), int(max_iter), int(nthreads), p(pi), p(theta), p(pi_init),
-                               C.addressof(lnl), C.addressof(conv), p(diffs))
+    it = lib().oracle_em_fused2(n, k, p(indptr), p(indices), p(data), p(lut), float(pi_prior), float(theta_prior),
+                                float(epsilon), int(max_iter), 1 if use_likelihood else 0, int(nthreads), p(pi), p(theta),
+                                p(pi_init), C.addressof(lnl), C.addressof(conv), p(diffs))
     if it < 0:
         raise MemoryError('oracle_em_fused')
     return dict(pi=pi, theta=theta, pi_init=pi_init, lnl=lnl.value, n_iter=it, converged=bool(conv.value), diffs=diffs[:it])

@@ -135,12 +135,13 @@ def test_c_restatement_matches_reference_goldens(name):
     reference: same iteration count, lnl / pi / theta to rounding."""
     from oracle.em_fused import em_fused
     c = load_case(name)
-    if bool(c['use_likelihood']):
-        pytest.skip('the C restatement implements the default convergence test (model.py:792)')
-    r = em_fused(case_matrix(c), float(c['pi_prior']), float(c['theta_prior']), float(c['em_epsilon']), int(c['max_iter']))
+    ul = bool(c['use_likelihood'])
+    r = em_fused(case_matrix(c), float(c['pi_prior']), float(c['theta_prior']), float(c['em_epsilon']), int(c['max_iter']),
+                 use_likelihood=ul)
     assert r['n_iter'] == int(c['n_iter']) and r['converged'] == bool(c['converged'])
     assert abs(r['lnl'] - float(c['lnl'])) <= 1e-10 * abs(float(c['lnl']))
     assert np.allclose(r['pi'], c['pi'], rtol=1e-10, atol=0) and np.allclose(r['theta'], c['theta'], rtol=1e-10, atol=0)
     assert np.allclose(r['pi_init'], c['pi_init'], rtol=1e-10, atol=0)
-    r1 = em_fused(case_matrix(c), float(c['pi_prior']), float(c['theta_prior']), float(c['em_epsilon']), int(c['max_iter']), nthreads=1)
+    r1 = em_fused(case_matrix(c), float(c['pi_prior']), float(c['theta_prior']), float(c['em_epsilon']), int(c['max_iter']), nthreads=1,
+                  use_likelihood=ul)
     assert np.allclose(r1['pi'], r['pi'], rtol=1e-12, atol=0) and r1['n_iter'] == r['n_iter']
