@@ -330,11 +330,19 @@ __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, 
 // entries of each ambiguous row per column part, packed 8 x 16 bit in two words (fused layout, P <= 8); the popularity
 // ids of the report pass are written on the way (the column map is gathered here anyway).  G lanes per row, sixteen
 // consecutive entries per lane (round 2: 16 lanes per row, one entry per lane and step: 8.3 ms at 2e9 entries).
-template <int G>
-__global__ __launch_bounds__(256) void k_row_partcounts(int64_t N_amb, const int32_t* __restrict__ amb_row,
-    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap,
+// LM: the column map (4 B per column) in LDS, one 1024-thread workgroup per CU — 2e9 gathers of a 120 KB table through the vector
+// cache (about one address per clock and CU) were most of this kernel's 8.1 ms at 2e9 entries; LDS serves 16+ lanes per clock.
+template <int G, bool LM>
+__global__ __launch_bounds__(LM ? 1024 : 256) void k_row_partcounts(int64_t N_amb, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap_g, int K,
     unsigned long long* __restrict__ out /* [N_amb][2] */, uint16_t* __restrict__ rid /* popularity ids (k_report_rows) or null */, int P) {
   constexpr int E = 16;
+  extern __shared__ uint32_t pc_cm[];                      // LM: [K]
+  if (LM) {
+    for (int t = threadIdx.x; t < K; t += blockDim.x) pc_cm[t] = colmap_g[t];
+    __syncthreads();
+  }
+  const uint32_t* const colmap = LM ? pc_cm : colmap_g;
   const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
   for (int64_t a = (int64_t)blockIdx.x * ngrp + grp; a < N_amb; a += (int64_t)gridDim.x * ngrp) {
     const int64_t i = amb_row[a];
@@ -528,6 +536,12 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
 // reduced in registers / across lanes instead of one LDS atomic per entry (tsem_fused.h, phase 1).
 // The padding at the end of a sub-block repeats the last row with value 0.
 constexpr int FILL_MAX_RP = 1152 * 4;                      // row slots x parts of a block the row-order fill can take
+// Round 3 (second pass over this kernel, 13.9 ms at 2e9 entries): it was bound by the LATENCY of three dependent loads
+// per row (row slot -> row pointers -> entries, then one more round trip per 16 entries of the row) with 16 rows in
+// flight per workgroup.  Now the row pointers of the whole block go to LDS in one parallel sweep, and a 16-lane group
+// loads the first 64 ids and scores of its NEXT row before it places the current one (unconditional loads: the arrays
+// carry TS_ENTRY_PAD entries of padding), so a group waits for memory about once per row instead of four times.
+__host__ __device__ inline size_t fill_lds_bytes(int R, int P) { return (size_t)(((R * P + 1) & ~1) * 4) + (size_t)R * 12; }
 __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
     const double* __restrict__ lut, const uint32_t* __restrict__ colmap, const int64_t* __restrict__ sb_off,
@@ -535,11 +549,21 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
     const int64_t* __restrict__ bstart, const unsigned long long* __restrict__ pc,
     const uint16_t* __restrict__ rid /* popularity ids (slot * P + part) instead of the column-map gather, or null */,
     uint32_t magicP /* ceil(2^32 / P) */, int nsplit /* ids below this may be split columns */, const uint8_t* __restrict__ lgtab) {
-  __shared__ uint32_t cnt[FILL_MAX_RP];                    // [row slot][part]: counts, then write cursors
+  extern __shared__ __attribute__((aligned(16))) unsigned char fl_lds[];
+  uint32_t* const cnt = reinterpret_cast<uint32_t*>(fl_lds);                   // [row slot][part]: counts, then write cursors
+  int64_t* const rstart = reinterpret_cast<int64_t*>(cnt + ((R * P + 1) & ~1));   // [row slot] first entry of the row in the CSR
+  int32_t* const rlen = reinterpret_cast<int32_t*>(rstart + R);                // [row slot] its length (0: empty slot)
   __shared__ uint32_t total[8], lastrow[8];
+  __shared__ int64_t sbase[8];
   const int64_t b = blockIdx.x;
   const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
   for (int t = threadIdx.x; t < R * P; t += blockDim.x) cnt[t] = 0;
+  for (int lr = threadIdx.x; lr < R; lr += blockDim.x) {
+    const int64_t i = amb_row[b * R + lr];
+    const int64_t s0 = i >= 0 ? indptr[i] : 0;
+    rstart[lr] = s0; rlen[lr] = i >= 0 ? (int32_t)(indptr[i + 1] - s0) : 0;
+  }
+  if (threadIdx.x < P) sbase[threadIdx.x] = sb_off[b * P + threadIdx.x];
   __syncthreads();
   if (pc) {                                                // the per-row part counts are already known
     const int64_t a0 = bstart[b], n = bstart[b + 1] - a0;
@@ -549,9 +573,8 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
     }
   } else {
     for (int lr = sub; lr < R; lr += subs) {
-      const int64_t i = amb_row[b * R + lr];
-      if (i < 0) continue;
-      for (int64_t k = indptr[i] + lane; k < indptr[i + 1]; k += RS_SUB) atomicAdd(&cnt[lr * P + (colmap[indices[k]] >> 16)], 1u);
+      const int64_t s0 = rstart[lr];
+      for (int k = lane; k < rlen[lr]; k += RS_SUB) atomicAdd(&cnt[lr * P + (colmap[indices[s0 + k]] >> 16)], 1u);
     }
   }
   __syncthreads();
@@ -572,44 +595,70 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
   // kernel's time), and the layout is the same from run to run.
   const int sgbase = (threadIdx.x & 63) / RS_SUB * RS_SUB;
   const uint32_t below = (1u << lane) - 1u;
-  for (int lr = sub; lr < R; lr += subs) {
-    const int64_t i = amb_row[b * R + lr];
-    if (i < 0) continue;
-    uint32_t run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int64_t s = indptr[i], e = indptr[i + 1];
-    for (int64_t k0 = s; k0 < e; k0 += RS_SUB) {          // (all 16 lanes stay in the loop: the ballots need them)
-      const int64_t k = k0 + lane;
-      const bool valid = k < e;
-      uint32_t cm = 0u;
-      if (rid) {                                           // (round 3) the ids k_row_partcounts wrote: a coalesced 2-byte read instead of a gather
-        const uint32_t id = valid ? (uint32_t)rid[k] : 0u;
-        const uint32_t slot = P == 1 ? id : __umulhi(id, magicP);   // id / P, exact for 16-bit ids and 2 <= P <= 8 (ceil(2^32 / 1) does not fit 32 bits)
-        const uint32_t lg = (int)id < nsplit ? (uint32_t)lgtab[id] : 0u;
-        cm = ((id - slot * (uint32_t)P) << 16) | (lg << 13) | slot;
-      } else {
-        cm = valid ? colmap[indices[k]] : 0u;
-      }
-      const uint32_t p = valid ? cm >> 16 : 0xFFFFu;
-      uint32_t t = 0;
+  // one step of 16 entries: column-map word cm of this lane's entry (0xFFFF.... part for lanes past the row's end), its score
+  auto place = [&](int lr, uint32_t (&run)[8], bool valid, uint32_t cm, uint32_t code) {
+    const uint32_t p = valid ? cm >> 16 : 0xFFFFu;
+    uint32_t t = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (q < P) {
-          const uint32_t m = (uint32_t)(__ballot(p == (uint32_t)q) >> sgbase) & 0xFFFFu;
-          if (p == (uint32_t)q) t = run[q] + __popc(m & below);
-          run[q] += __popc(m);
-        }
+    for (int q = 0; q < 8; ++q) {
+      if (q < P) {
+        const uint32_t m = (uint32_t)(__ballot(p == (uint32_t)q) >> sgbase) & 0xFFFFu;
+        if (p == (uint32_t)q) t = run[q] + __popc(m & below);
+        run[q] += __popc(m);
       }
-      if (valid) {
-        t += cnt[lr * P + p];
-        const int64_t pos = sb_off[b * P + p] + t;
-        if (pcode) pcode[pos] = raw[k];
-        else pval[pos] = lut[raw[k]];
-        prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
+    }
+    if (valid) {
+      t += cnt[lr * P + p];
+      const int64_t pos = sbase[p] + t;
+      if (pcode) pcode[pos] = (uint16_t)code;
+      else pval[pos] = lut[code];
+      prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
+    }
+  };
+  auto cm_of_id = [&](uint32_t id) -> uint32_t {           // the ids k_row_partcounts wrote: a coalesced 2-byte read instead of a gather
+    const uint32_t slot = P == 1 ? id : __umulhi(id, magicP);   // id / P, exact for 16-bit ids and 2 <= P <= 8 (ceil(2^32 / 1) does not fit 32 bits)
+    const uint32_t lg = (int)id < nsplit ? (uint32_t)lgtab[id] : 0u;
+    return ((id - slot * (uint32_t)P) << 16) | (lg << 13) | slot;
+  };
+  if (rid) {
+    constexpr int PF = 4;                                  // steps of a row loaded ahead (64 entries)
+    uint32_t nid[PF], nrw[PF];
+    auto load_row = [&](int lr) {
+      const int64_t s0 = rstart[lr < R ? lr : R - 1];
+#pragma unroll
+      for (int j = 0; j < PF; ++j) { nid[j] = rid[s0 + 16 * j + lane]; nrw[j] = raw[s0 + 16 * j + lane]; }
+    };
+    load_row(sub);
+    for (int lr = sub; lr < R; lr += subs) {
+      uint32_t cid[PF], crw[PF];
+#pragma unroll
+      for (int j = 0; j < PF; ++j) { cid[j] = nid[j]; crw[j] = nrw[j]; }
+      load_row(lr + subs);                                 // (past the block's last row: the last row again, unused)
+      const int len = rlen[lr];
+      const int64_t s0 = rstart[lr];
+      uint32_t run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < PF; ++j)
+        if (16 * j < len) place(lr, run, 16 * j + lane < len, cm_of_id(cid[j]), crw[j]);   // (uniform over the 16 lanes)
+      for (int k0 = 16 * PF; k0 < len; k0 += RS_SUB) {      // the rest of a long row
+        const bool valid = k0 + lane < len;
+        const uint32_t id = valid ? (uint32_t)rid[s0 + k0 + lane] : 0u;
+        place(lr, run, valid, cm_of_id(id), valid ? (uint32_t)raw[s0 + k0 + lane] : 0u);
+      }
+    }
+  } else {
+    for (int lr = sub; lr < R; lr += subs) {
+      const int len = rlen[lr];
+      const int64_t s0 = rstart[lr];
+      uint32_t run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k0 = 0; k0 < len; k0 += RS_SUB) {           // (all 16 lanes stay in the loop: the ballots need them)
+        const bool valid = k0 + lane < len;
+        place(lr, run, valid, valid ? colmap[indices[s0 + k0 + lane]] : 0u, valid ? (uint32_t)raw[s0 + k0 + lane] : 0u);
       }
     }
   }
   for (int p = 0; p < P; ++p) {                            // padding: value 0 (buffers are zero-filled), row = last row
-    const int64_t base = sb_off[b * P + p], end = sb_off[b * P + p + 1];
+    const int64_t base = sbase[p], end = sb_off[b * P + p + 1];
     for (int64_t pos = base + total[p] + threadIdx.x; pos < end; pos += blockDim.x) prc[pos] = lastrow[p] << 16;
   }
 }
@@ -2440,9 +2489,17 @@ static int build_layout(tsem_ctx* h) {
       for (int q = 1; q < 6; ++q)
         if ((double)h->len_gt[q] <= 0.005 * (double)h->N) { capc = 8 << q; break; }
       const int G = capc <= 16 ? 1 : capc <= 32 ? 2 : capc <= 64 ? 4 : capc <= 128 ? 8 : 16;
-      const unsigned grid = (unsigned)std::min<int64_t>(65535, (na + 256 / G - 1) / (256 / G));
-      auto pk = G == 1 ? k_row_partcounts<1> : G == 2 ? k_row_partcounts<2> : G == 4 ? k_row_partcounts<4> : G == 8 ? k_row_partcounts<8> : k_row_partcounts<16>;
-      pk<<<grid, 256, 0, h->stream>>>(na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, d_pc, h->d_rid16, P);
+      if ((size_t)K * 4 <= (size_t)TS_LDS_MAX - 2048 && na >= 65536) {   // the column map fits LDS (K <= 40k) and the matrix is worth a 120 KB preload per CU
+        auto pk = G == 1 ? k_row_partcounts<1, true> : G == 2 ? k_row_partcounts<2, true> : G == 4 ? k_row_partcounts<4, true>
+                : G == 8 ? k_row_partcounts<8, true> : k_row_partcounts<16, true>;
+        TSEM_HIP(hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        pk<<<h->n_cu, 1024, (size_t)K * 4, h->stream>>>(na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, K, d_pc, h->d_rid16, P);
+      } else {
+        const unsigned grid = (unsigned)std::min<int64_t>(65535, (na + 256 / G - 1) / (256 / G));
+        auto pk = G == 1 ? k_row_partcounts<1, false> : G == 2 ? k_row_partcounts<2, false> : G == 4 ? k_row_partcounts<4, false>
+                : G == 8 ? k_row_partcounts<8, false> : k_row_partcounts<16, false>;
+        pk<<<grid, 256, 0, h->stream>>>(na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, K, d_pc, h->d_rid16, P);
+      }
     }
     TSEM_HIP(hipGetLastError());
     rid_amb_done = true;
@@ -2585,7 +2642,7 @@ static int build_layout(tsem_ctx* h) {
       }
     }
     const uint32_t magicP = (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P);
-    k_sb_fill_sorted<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
+    k_sb_fill_sorted<<<(unsigned)nb, 256, fill_lds_bytes(R, P), h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
                                                          d_pc ? d_bs : nullptr, d_pc, rid_fill, magicP, nsplit, d_lgtab);
     TSEM_HIP(hipGetLastError());
