@@ -191,6 +191,10 @@ __global__ void k_gen_rows(int64_t row_begin, int64_t n, int32_t K, uint64_t see
 // 2^26 pieces is exact in fp64, k_pisum_finish adds the levels in a fixed order.  A 53-bit Q has pieces on 3-4 levels.
 constexpr int PIS_LEVELS = 9, PIS_W = 26;
 constexpr int RS_SUB = 16;
+// G lanes per row, sixteen consecutive scores per lane (two 16-byte loads), G from the mean row length: the round-2 shape
+// (16 lanes per row, one 2-byte load per lane and step) read the scores at 1 TB/s: 3.8 ms at 2e9 entries.
+typedef unsigned int rs_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+template <int G>
 __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __restrict__ indptr,
     const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
     const double* __restrict__ lut, uint16_t* __restrict__ row_code, uint8_t* __restrict__ row_class,
@@ -199,24 +203,35 @@ __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __re
     uint32_t* __restrict__ ucount /* [K] unique rows with a positive score per column; [K] = 1 if any stored score is 0 */,
     int K, unsigned long long* __restrict__ len_gt /* [6] rows longer than 8, 16, 32, 64, 128, 256 entries */) {
   __shared__ double scratch[16];
-  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB;
-  const int subs = blockDim.x / RS_SUB;
+  constexpr int E = 16;
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
   double wt = 0.0, wa = 0.0;
   int mymax = 0;
   unsigned lg[6] = {0, 0, 0, 0, 0, 0};
-  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
-    int64_t s = indptr[row], e = indptr[row + 1];
+  for (int64_t row = (int64_t)blockIdx.x * ngrp + grp; row < N; row += (int64_t)gridDim.x * ngrp) {
+    const int64_t s = indptr[row];
+    const int len = (int)(indptr[row + 1] - s);
     int m = 0;
     bool zero = false;
-    if (lane == 0) {
+    if (gl == 0) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) lg[q] += (e - s) > (8 << q) ? 1u : 0u;
+      for (int q = 0; q < 6; ++q) lg[q] += len > (8 << q) ? 1u : 0u;
     }
-    for (int64_t k = s + lane; k < e; k += RS_SUB) { const int r = (int)raw[k]; m = max(m, r); zero |= r == 0; }
-    m = sg_max_i<RS_SUB>(m);
+    for (int k0 = E * gl; k0 < len; k0 += E * G) {           // (the array carries TS_ENTRY_PAD entries of padding)
+      rs_u32x4_a2 cd[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) cd[q] = *reinterpret_cast<const rs_u32x4_a2*>(raw + s + k0 + 8 * q);
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const uint32_t w = cd[j / 8][(j / 2) & 3];
+        const int r = (int)((j & 1) ? w >> 16 : w & 0xFFFFu);
+        if (k0 + j < len) { m = max(m, r); zero |= r == 0; }
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, G));
     if (zero) ucount[K] = 1u;                              // (a stored score of 0: the shortcuts of tsem_reassign do not apply)
-    int64_t len = e - s;
-    if (lane == 0) {
+    if (gl == 0) {
       double w = (len > 0) ? lut[m] : 0.0;
       wt += w;
       if (len > 1) wa += w;
@@ -229,8 +244,8 @@ __global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __re
         for (int lv = 0; lv < PIS_LEVELS && r != 0.0; ++lv) {
           const int eb = pis_e0 - PIS_W * lv;               // pieces of this level: |piece| <= 2^(eb-1023), multiples of 2^(eb-1023-PIS_W)
           if (eb + 52 - PIS_W < 1) break;                   // (below the normal range: nothing of a finite score table gets here)
-          const double m = __hiloint2double((int)(((uint32_t)(eb + 52 - PIS_W) << 20) | 0x80000u), 0);
-          const double piece = (r + m) - m;
+          const double mm = __hiloint2double((int)(((uint32_t)(eb + 52 - PIS_W) << 20) | 0x80000u), 0);
+          const double piece = (r + mm) - mm;
           if (piece != 0.0) unsafeAtomicAdd(&pis_lv[(size_t)lv * K + col], piece);
           r -= piece;
         }
@@ -2333,9 +2348,13 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   unsigned long long* d_lg = nullptr;
   TSEM_ALLOC(d_lg, 8);
   TSEM_HIP(hipMemsetAsync(d_lg, 0, 64, h->stream));
-  if (N)
-    k_rowstats<<<grid, 256, 0, h->stream>>>(N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, d_code, d_cls,
-                                           d_wpart, h->d_maxcode, d_pis_lv, pis_e2 + 1023, h->d_ucount, K, d_lg);
+  if (N) {
+    const double mean_len = (double)h->nnz / (double)N;    // lanes per row x 16 entries >= ~1.5 mean row lengths
+    const int G = mean_len * 1.5 <= 16 ? 1 : mean_len * 1.5 <= 32 ? 2 : mean_len * 1.5 <= 64 ? 4 : mean_len * 1.5 <= 128 ? 8 : 16;
+    auto rk = G == 1 ? k_rowstats<1> : G == 2 ? k_rowstats<2> : G == 4 ? k_rowstats<4> : G == 8 ? k_rowstats<8> : k_rowstats<16>;
+    rk<<<grid, 256, 0, h->stream>>>(N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, d_code, d_cls,
+                                    d_wpart, h->d_maxcode, d_pis_lv, pis_e2 + 1023, h->d_ucount, K, d_lg);
+  }
   k_pisum_finish<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, d_pis_lv, h->d_pisum0);
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipMemcpyAsync(h->len_gt, d_lg, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
