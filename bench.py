@@ -76,6 +76,10 @@ def parse():
     ap.add_argument('--no-reproducible-leg', action='store_true', help='skip the `reproducible_mode` block (option reproducible on a 10M-row sample)')
     ap.add_argument('--no-precision-sweep', action='store_true',
                     help='skip the fp32-vs-fp64 tolerance sweep of BASELINE config 3 (N=1 only; ~10 s)')
+    ap.add_argument('--one-device', action='store_true',
+                    help='DRY RUN of --gpus N on a box with fewer GPUs: every rank uses device 0, torch.distributed gloo, the reduce '
+                         'buffer staged through the host (RCCL refuses two ranks on one device).  Exercises the launcher, the row '
+                         'shards, the set-up and per-iteration collectives and the result line; its throughput means nothing')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the multi-rank code path (RCCL group, per-iteration all-reduce) even at world size 1')
     return ap.parse_args()
@@ -222,8 +226,11 @@ def main():
     from telescope_amd.likelihood import TelescopeLikelihood
 
     # the engine first: without a usable GPU every rank fails HERE, loudly ("no CPU fallback"), not in the launcher
-    eng = Engine(int(os.environ.get('LOCAL_RANK', '0')))
-    comm = init_from_env('nccl', force=args.force_comm) if (world > 1 or args.force_comm) else None
+    if args.one_device:
+        os.environ['TSEM_ONE_DEVICE'] = '1'
+        os.environ['TSEM_GLOO_HOST_STAGED'] = '1'
+    eng = Engine(0 if args.one_device else int(os.environ.get('LOCAL_RANK', '0')))
+    comm = init_from_env('gloo' if args.one_device else 'nccl', force=args.force_comm) if (world > 1 or args.force_comm) else None
     rank = comm.rank if comm else 0
     local = comm.device if comm else 0
     total_rows = args.rows * (world if args.scaling == 'weak' else 1)
@@ -297,6 +304,12 @@ def main():
         _shutdown(comm)
         return
 
+    # the parameters every rank now holds, folded to three numbers: the same for every N at strong scaling (the rows are generated
+    # from their GLOBAL index, so N ranks hold the same matrix) — what a run at N > 1 can be checked against
+    pi_now, theta_now = eng.get_params()
+    wts = np.arange(1, args.cols + 1, dtype=np.float64) / args.cols
+    check = dict(iterations=args.warmup + args.steps, pi_sum=float(pi_now.sum()), pi_weighted=float(np.dot(pi_now, wts)),
+                 theta_weighted=float(np.dot(theta_now, wts)))
     info = eng.layout_info()
     traffic = _pmc_traffic(total_rows, args, world, info.get('value_bytes', 8)) if info.get('fused') else None
     k_ms = ks['em_ms'] / max(1, ks['em_launches'])
@@ -308,6 +321,7 @@ def main():
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
         'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'nnz_per_sec': nnz_total * args.steps / elapsed,
+        'check': check,
         'config': {
             'workload': 'synthetic %dM fragments x %dk loci, ~%g nnz/row, %s columns, fp64 arithmetic, '
                         'pi_prior=0 theta_prior=200000, em_epsilon=0 (fixed iterations)'
@@ -316,7 +330,7 @@ def main():
             'parallelism': (('row-sharded x%d, 1 in-library RCCL all-reduce(K+2 f64)/iter' % world) if comm.in_library else
                             ('row-sharded x%d, FALL-BACK transport: torch.distributed all-reduce(K+1 f64) + host round trip per iter' % world))
             if comm is not None else 'single GPU',
-            'transport': comm.describe() if comm is not None else None,
+            'transport': (comm.describe() + (' — ONE-DEVICE DRY RUN, host-staged' if args.one_device else '')) if comm is not None else None,
             'launcher': 'self (bench.py started the ranks)' if os.environ.get('TSEM_BENCH_SELF_LAUNCHED') else
                         ('torchrun / external' if world > 1 else 'single process'),
             'em_kernel': args.em_kernel, 'layout': info,

@@ -222,11 +222,21 @@ class Comm(object):
             self.in_library = True
             return
         from ._lib import Engine
-        if isinstance(engine, Engine) and self.backend != 'nccl':
-            raise RuntimeError('a HIP engine needs the nccl (RCCL) backend: its reduce buffer lives in HBM and the %s '
-                               'backend reduces host tensors' % self.backend)
         t = self._torch
         self.in_library = False
+        self._staged = False
+        if isinstance(engine, Engine) and self.backend != 'nccl':
+            # A HIP engine's reduce buffer lives in HBM and this backend reduces host tensors.  Refused — except for the
+            # DRY RUN of a multi-process job on a box with fewer GPUs than ranks (TSEM_GLOO_HOST_STAGED=1, bench.py
+            # --one-device): several ranks share a device, which RCCL does not allow, so the buffer takes a round trip
+            # through the host and gloo per iteration.  Same numbers, same host logic; not a product transport.
+            if os.environ.get('TSEM_GLOO_HOST_STAGED', '0') != '1':
+                raise RuntimeError('a HIP engine needs the nccl (RCCL) backend: its reduce buffer lives in HBM and the %s '
+                                   'backend reduces host tensors' % self.backend)
+            self._staged = True
+            self._red = t.zeros(n_cols + 2, dtype=t.float64, device=t.device('cuda', self.device))
+            engine.bind_reduce_buffer(self._red.data_ptr(), n_cols + 2)
+            return
         self._red = t.zeros(n_cols + 2, dtype=t.float64, device=self.tdev)
         engine.bind_reduce_buffer(self._red.data_ptr(), n_cols + 2)
 
@@ -235,6 +245,13 @@ class Comm(object):
             engine.comm_allreduce(offset, count)
             return
         red = self._red if count is None else self._red[offset:offset + count]
+        if getattr(self, '_staged', False):                   # dry run: HBM -> host -> gloo -> HBM
+            engine.synchronize()
+            h = red.cpu()
+            self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self.group)
+            red.copy_(h)
+            self._torch.cuda.synchronize()
+            return
         # the engine's kernels run on ITS stream, torch's collective on torch's current stream: order them through the
         # host (this transport makes a host round trip per iteration anyway)
         if self.backend == 'nccl':
@@ -261,7 +278,7 @@ def init_from_env(backend=None, force=False):
     import torch.distributed as dist
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = 0 if os.environ.get('TSEM_ONE_DEVICE', '0') == '1' else int(os.environ.get('LOCAL_RANK', 0))
     if backend == 'nccl':
         torch.cuda.set_device(local)
     if not dist.is_initialized():

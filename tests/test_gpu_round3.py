@@ -6,6 +6,7 @@
 * full-size oracle parity for BASELINE configs 2 and 3, a run that converges below max_iter on >= 1M rows;
 * the order-deterministic final iteration.
 """
+import os
 import threading
 
 import numpy as np
@@ -478,3 +479,45 @@ def test_reproducible_mode_reports_rows_it_cannot_vouch_for(gpu_device):
     indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
     raw = sp.csr_matrix((rng.randint(100, 300, indptr[-1]).astype(np.uint16), indices, indptr), shape=(n, k))
     assert TelescopeLikelihood(raw, o, device=0, engine_options={'reproducible': 1})._eng.layout_info()['reproducible'] == 1
+
+
+_BENCH_COMMON = ['--rows', '3000000', '--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--no-alt-layout', '--no-precision-sweep',
+                 '--no-reproducible-leg', '--uniq-frac', '0.05']
+_BENCH_LINES = {}
+
+
+def _bench_line(key, prefix, extra):
+    import json
+    import subprocess
+    if key not in _BENCH_LINES:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run(prefix + [os.path.join(root, 'bench.py')] + extra + _BENCH_COMMON, cwd=root, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        _BENCH_LINES[key] = json.loads(r.stdout.strip().splitlines()[-1])
+    return _BENCH_LINES[key]
+
+
+@pytest.mark.parametrize('launcher', ['self', 'torchrun'])
+def test_bench_two_ranks_dry_run_on_one_gpu(gpu_device, launcher):
+    """`python bench.py --gpus 2 --one-device` (bench.py starts the ranks) and the driver's form `python -m
+    torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 --one-device`: two rank processes that share GPU 0 (gloo, the
+    reduce buffer staged through the host — RCCL refuses two ranks on one device): row shards generated from the global row index,
+    the set-up collectives, one all-reduce per iteration, MAX of the elapsed times, rank 0's result line.  Its `check` block (the
+    parameters after warm-up + steps folded to three numbers) must equal the single-process run's."""
+    import socket
+    import sys as _sys
+    one = _bench_line('one', [_sys.executable], ['--gpus', '1'])
+    if launcher == 'self':
+        two = _bench_line('self', [_sys.executable], ['--gpus', '2', '--one-device'])
+    else:
+        sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+        two = _bench_line('torchrun', [_sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                                       '--master-addr', '127.0.0.1', '--master-port', str(port)], ['--gpus', '2', '--one-device'])
+    assert two['n_gpus'] == 2 and one['n_gpus'] == 1 and two['config']['nnz'] == one['config']['nnz']
+    assert 'DRY RUN' in two['config']['transport']
+    assert ('self' in two['config']['launcher']) == (launcher == 'self')
+    assert two['check']['iterations'] == one['check']['iterations'] == 8
+    for key in ('pi_sum', 'pi_weighted', 'theta_weighted'):
+        assert abs(two['check'][key] - one['check'][key]) <= 1e-11 * abs(one['check'][key]), key
+    assert two['value'] > 0 and two['ms_per_step'] > 0
