@@ -127,6 +127,34 @@ def configure_logging(opts):
     lg.basicConfig(level=level, format=fmt, datefmt='%Y-%m-%d %H:%M:%S', stream=opts.logfile, force=True)
 
 
+def build_model(raw_scores, opts):
+    """The likelihood model — on one GPU, or, when the process is one rank of a `torch.distributed.run` launch (WORLD_SIZE > 1:
+    `python -m torch.distributed.run --nproc-per-node N -m telescope_amd resume ...`), on this rank's contiguous share of the
+    fragments (balanced by stored entries): pi, theta and every report sum are all-reduced over the ranks (RCCL), rank 0 alone
+    draws the random picks of `choose` and writes the reports.  Every rank reads the same input files."""
+    from .likelihood import TelescopeLikelihood
+    eo = {'reproducible': 1} if opts.reproducible else {}
+    if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return TelescopeLikelihood(raw_scores, opts, device=opts.device, engine_options=eo or None), None
+    from .distributed import init_from_env, shard_bounds
+    comm = init_from_env()
+    raw = raw_scores.tocsr()
+    r0, r1 = shard_bounds(raw.shape[0], comm.world, comm.rank, indptr=raw.indptr)
+    if comm.rank != 0:
+        lg.getLogger().setLevel(max(lg.getLogger().level, lg.WARNING))      # one copy of the progress lines
+    lg.info('Row-sharded over %d ranks (%s); this rank: fragments %d..%d' % (comm.world, comm.describe(), r0, r1))
+    eo['row_offset'] = r0
+    return TelescopeLikelihood(raw[r0:r1], opts, comm=comm, engine_options=eo), comm
+
+
+def finish(comm):
+    if comm is not None:
+        import torch.distributed as dist
+        comm.barrier()
+        comm.close()
+        dist.destroy_process_group()
+
+
 def run_resume(args):
     """telescope_resume.py:183-232."""
     from .likelihood import TelescopeLikelihood
@@ -145,15 +173,16 @@ def run_resume(args):
     seed = ts.get_random_seed()
     lg.debug('Random seed: {}'.format(seed))
     np.random.seed(seed)
-    ts_model = TelescopeLikelihood(ts.raw_scores, opts, device=opts.device,
-                                   engine_options={'reproducible': 1} if opts.reproducible else None)
+    ts_model, comm = build_model(ts.raw_scores, opts)
     lg.info('Running Expectation-Maximization...')
     stime = time()
     ts_model.em(use_likelihood=opts.use_likelihood, loglev=lg.INFO)
     lg.info('EM completed in %s' % format_minutes(time() - stime))
     lg.info('Generating Report...')
     os.makedirs(opts.outdir, exist_ok=True)
-    ts.output_report(ts_model, opts.outfile_path('run_stats.tsv'), opts.outfile_path('TE_counts.tsv'))
+    ts.output_report(ts_model, opts.outfile_path('run_stats.tsv'), opts.outfile_path('TE_counts.tsv'),
+                     write=comm is None or comm.rank == 0)
+    finish(comm)
     lg.info('telescope resume complete (%s)' % format_minutes(time() - total_time))
     return 0
 
@@ -186,7 +215,8 @@ def run_assign(args):
         lg.info('telescope assign complete (%s)' % format_minutes(time() - total_time))
         return 0
     os.makedirs(opts.outdir, exist_ok=True)
-    ts.save(opts.outfile_path('checkpoint'))
+    if int(os.environ.get('RANK', '0')) == 0:                # (every rank of a sharded launch loads the same files; one writes)
+        ts.save(opts.outfile_path('checkpoint'))
     if opts.skip_em:
         lg.info('Skipping EM...')
         lg.info('telescope assign complete (%s)' % format_minutes(time() - total_time))
@@ -194,14 +224,15 @@ def run_assign(args):
     seed = ts.get_random_seed()
     lg.debug('Random seed: {}'.format(seed))
     np.random.seed(seed)
-    ts_model = TelescopeLikelihood(ts.raw_scores, opts, device=opts.device,
-                                   engine_options={'reproducible': 1} if opts.reproducible else None)
+    ts_model, comm = build_model(ts.raw_scores, opts)
     lg.info('Running Expectation-Maximization...')
     stime = time()
     ts_model.em(use_likelihood=opts.use_likelihood, loglev=lg.INFO)
     lg.info('EM completed in %s' % format_minutes(time() - stime))
     lg.info('Generating Report...')
-    ts.output_report(ts_model, opts.outfile_path('run_stats.tsv'), opts.outfile_path('TE_counts.tsv'))
+    ts.output_report(ts_model, opts.outfile_path('run_stats.tsv'), opts.outfile_path('TE_counts.tsv'),
+                     write=comm is None or comm.rank == 0)
+    finish(comm)
     lg.info('telescope assign complete (%s)' % format_minutes(time() - total_time))
     return 0
 

@@ -277,7 +277,7 @@ def init_from_env(backend=None, force=False):
     import torch
     import torch.distributed as dist
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('TSEM_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     local = 0 if os.environ.get('TSEM_ONE_DEVICE', '0') == '1' else int(os.environ.get('LOCAL_RANK', 0))
     if backend == 'nccl':
         torch.cuda.set_device(local)

@@ -115,7 +115,7 @@ class Telescope(object):
         say('\n')
 
     # ---- reports (model.py:420-477) -----------------------------------------------
-    def output_report(self, tl, stats_filename, counts_filename):
+    def output_report(self, tl, stats_filename, counts_filename, write=True):
         """Same columns, evaluation order (the RNG is consumed by init_best_random before the
         final mode), sort, rounding and file layout as the reference — including the header row
         glued onto the RunInfo comment line (model.py:470-471 writes no newline)."""
@@ -140,6 +140,8 @@ class Telescope(object):
                                       index=['final_conf', 'final_prop', 'init_best_avg', 'init_prop']))
         counts = pd.DataFrame(OrderedDict([('transcript', names), ('count', colsum(mode, prob))]))
         counts.sort_values('transcript', inplace=True)
+        if not write:                                        # a rank other than 0 of a row-sharded run: it took part in the sums
+            return
         comment = ['## RunInfo'] + ['{}:{}'.format(k, v) for k, v in self.run_info.items()]
         with open(stats_filename, 'w') as fh:
             fh.write('\t'.join(comment))

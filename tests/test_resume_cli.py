@@ -75,6 +75,30 @@ def test_resume_reproducible_writes_the_same_bytes_twice(gpu_device, tmp_path, m
             assert sorted(got.splitlines()) == sorted(want.splitlines()), sfx
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['choose', 'conf'])
+def test_resume_row_sharded_over_two_rank_processes(gpu_device, tmp_path, mode):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m telescope_amd resume ...`: every rank loads the checkpoint, takes
+    its share of the fragments, the sums are all-reduced, rank 0 draws the picks of `choose` and writes the reference's
+    reports.  On the one-GPU box the two ranks share device 0 (the dry-run transport of telescope_amd.distributed: gloo, the
+    reduce buffer staged through the host); with one GPU per rank the same command runs on RCCL."""
+    import socket
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, TSEM_ONE_DEVICE='1', TSEM_GLOO_HOST_STAGED='1', TSEM_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), '-m', 'telescope_amd', 'resume', os.path.join(GOLD, 'resume_checkpoint.npz'),
+           '--outdir', str(tmp_path), '--exp_tag', 'run', '--reassign_mode', mode]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stderr.count('EM converged after 16 iterations.') == 1            # one copy of the progress lines
+    assert 'Final log-likelihood: 95252.596293.' in r.stderr and 'Row-sharded over 2 ranks' in r.stderr
+    for suffix in ('run_stats.tsv', 'TE_counts.tsv'):
+        got = open(os.path.join(str(tmp_path), 'run-' + suffix)).read()
+        want = open(os.path.join(GOLD, 'resume_%s-%s' % (mode, suffix))).read()
+        if got != want:   # rows of equal final_prop may come in any order (unstable sort, model.py:449)
+            assert sorted(got.splitlines()) == sorted(want.splitlines()), suffix
+
+
 def test_loader_reproduces_bundled_matrix():
     """BAM + GTF -> the score matrix the reference's loader builds for its `telescope test` data
     (validated through the README log-likelihood and the golden report, tools/make_golden.py)."""
