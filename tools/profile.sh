@@ -8,7 +8,7 @@ TAG=${1:-r}
 OUT=gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-sweep --kernel-timing 1"
+B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-sweep --no-reproducible-leg --kernel-timing 1"
 STAGES=${STAGES:-"trace pmc lds rest"}
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 if has trace; then
