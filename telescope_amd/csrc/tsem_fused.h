@@ -330,7 +330,12 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
         }
         double2 w = make_double2(1.0, 1.0);
         if (MODE != 1) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
-        // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730)
+        // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730).  (The exchange wave computes 4-6 of these IEEE
+        // divisions per lane and step, on the critical path of a short-row step.  v_rcp_f64 + two fma-corrected Newton steps
+        // instead: -3 % at 10 entries per row, -1.5 % at 40 with score codes when written without any special-case handling;
+        // made safe for zero / denormal / huge sums — a wave-uniform choice between the sequences, or frexp / ldexp around the
+        // short one — the gain is within the repeat spread, and it is not a correctly rounded quotient: not taken.
+        // profiles/r03_exchange_bounds.txt section 7.)
         *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(recip0(ys0) * w.x, recip0(ys1) * w.y);
         if (!OWNREG) *reinterpret_cast<double2*>(&y[(k & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
       }
