@@ -298,6 +298,8 @@ int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
 int64_t tsem_debug_subblock(tsem_ctx* h, int64_t block, int32_t part, uint32_t* out, int64_t cap);
 /* y[i] = the device log1p the lnl passes use (finite x >= 0), for accuracy tests against libm */
 int  tsem_debug_log1p(int device, int32_t n, const double* x, double* y);
+/* the same for the table-driven log1p of the fused lnl pass (64-entry table in LDS, ~1e-16 absolute error per evaluation) */
+int  tsem_debug_log1p_tab(int device, int32_t n, const double* x, double* y);
 
 #ifdef __cplusplus
 }

@@ -140,6 +140,7 @@ def lib():
     L.tsem_layout_info.argtypes = [vp, vp]
     L.tsem_debug_fused_prof.argtypes = [vp, vp]
     L.tsem_debug_log1p.argtypes = [C.c_int, C.c_int32, vp, vp]
+    L.tsem_debug_log1p_tab.argtypes = [C.c_int, C.c_int32, vp, vp]
     L.tsem_debug_subblock.argtypes = [vp, C.c_int64, C.c_int32, vp, C.c_int64]
     for name in exported_symbols():
         fn = getattr(L, name)
@@ -556,10 +557,10 @@ class LibComm(object):
     __del__ = close
 
 
-def debug_log1p(x, device=0):
+def debug_log1p(x, device=0, table=False):
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.empty_like(x)
-    rc = lib().tsem_debug_log1p(device, len(x), ptr(x), ptr(y))
+    rc = (lib().tsem_debug_log1p_tab if table else lib().tsem_debug_log1p)(device, len(x), ptr(x), ptr(y))
     if rc != OK:
         raise EngineError('tsem_debug_log1p failed (%d)' % rc)
     return y

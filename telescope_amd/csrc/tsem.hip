@@ -1943,7 +1943,7 @@ static bool fz_wants_codes(const tsem_ctx* h) {
 }
 static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
   return (size_t)(2 * h->Kp + (fz_yr(h->geo) + 2) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0) +
-         (h->opt_reproducible ? (size_t)h->Kp * 2 + 16 : 0);   // (+ the slots' exponent table)
+         std::max<size_t>(h->opt_reproducible ? (size_t)h->Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16);   // (+ the slots' exponent table | the lnl pass's log table)
 }
 
 static void free_layout(tsem_ctx* h) {
@@ -2298,7 +2298,7 @@ static int choose_geometry(tsem_ctx* h) {
       if (h->opt_geo >= 0 && P <= 4) h->geo = (h->opt_geo == 2 || h->opt_geo == 3) ? (int)h->opt_geo : 0;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
-      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - 2 * Kp * 8 - lut_bytes - (h->opt_reproducible ? Kp * 2 + 16 : 0)) / ((fz_yr(h->geo) + 2) * 8));
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - 2 * Kp * 8 - lut_bytes - std::max(h->opt_reproducible ? Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16)) / ((fz_yr(h->geo) + 2) * 8));
       rmax = std::min(rmax, FILL_MAX_RP / P);                // (k_sb_fill_sorted keeps R x P counters in LDS)
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
@@ -4350,6 +4350,30 @@ int tsem_debug_log1p(int device, int32_t n, const double* x, double* y) {
   return e == hipSuccess ? TSEM_OK : TSEM_ERR_HIP;
 }
 
+__global__ void k_log1p_tab_probe(int n, const double* x, double* y) {
+  __shared__ double2 tab[FZ_LOGTAB];
+  if (threadIdx.x < FZ_LOGTAB) {
+    const double ci = 1.0 + (double)threadIdx.x * (1.0 / FZ_LOGTAB);
+    tab[threadIdx.x] = make_double2(1.0 / ci, ts_log1p_pos((double)threadIdx.x * (1.0 / FZ_LOGTAB)));
+  }
+  __syncthreads();
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = fz_log1p_tab(x[i], tab);
+}
+/* the table-driven log1p of the FUSED lnl pass (fz_log1p_tab) on caller-supplied x >= 0 (accuracy test hook) */
+int tsem_debug_log1p_tab(int device, int32_t n, const double* x, double* y) {
+  if (!x || !y || n < 0) return TSEM_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return TSEM_ERR_HIP;
+  double *dx = nullptr, *dy = nullptr;
+  if (hipMalloc((void**)&dx, 8 * (size_t)std::max(1, n)) != hipSuccess || hipMalloc((void**)&dy, 8 * (size_t)std::max(1, n)) != hipSuccess)
+    return TSEM_ERR_NOMEM;
+  (void)hipMemcpy(dx, x, 8 * (size_t)n, hipMemcpyHostToDevice);
+  if (n) k_log1p_tab_probe<<<(n + 255) / 256, 256>>>(n, dx, dy);
+  hipError_t e = hipMemcpy(y, dy, 8 * (size_t)n, hipMemcpyDeviceToHost);
+  (void)hipFree(dx); (void)hipFree(dy);
+  return e == hipSuccess ? TSEM_OK : TSEM_ERR_HIP;
+}
+
 /* debug: the packed (local row << 16 | local column) words of sub-block (block, part); returns their number */
 int64_t tsem_debug_subblock(tsem_ctx* h, int64_t block, int32_t part, uint32_t* out, int64_t cap) {
   if (!h || !h->d_prc || !h->d_sb_off || block < 0 || block >= h->nb || part < 0 || part >= h->P) return TSEM_ERR_ARG;
@@ -4368,7 +4392,8 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[12] = h->last_slow_path; info[13] = h->max_subblock; info[14] = h->fmt_code ? 2 : 8; info[15] = h->n_hot_cols;
   info[16] = h->use_fused ? (int64_t)fz_lds_bytes(h, fz_fmt(h) != 0) : 0;   // dynamic LDS per workgroup of the fused kernel
   info[17] = h->sorted_layout ? 1 : 0; info[18] = h->geo; info[19] = h->n_fallbacks;
-  info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->len_gt[5] ? 2 : 1) : 0;     // 2: some row has more than 256 entries, see telescope_em.h info[22] = 0; info[23] = 0;
+  info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->len_gt[5] ? 2 : 1) : 0;     // 2: some row has more than 256 entries, see telescope_em.h
+  info[22] = 0; info[23] = 0;
   return TSEM_OK;
 }
 

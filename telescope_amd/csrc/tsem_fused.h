@@ -192,6 +192,29 @@ __device__ __forceinline__ void fz_row_sums(double* yb, bool idle, uint32_t r0, 
   }
 }
 
+// log1p(x), x >= 0 finite, for the fused lnl pass (2e9 evaluations per pass: ts_log1p_pos was 3.7 of its 7.3 ms): 1 + x = 2^k m,
+// m = c_i (1 + r) with c_i = 1 + i / 64 from the top six mantissa bits, (1 / c_i, log c_i) from a 64-entry table in LDS (built
+// at kernel start with the accurate routine), log1p(r) by its series to r^9 (r < 2^-6), the rounding of 1 + x put back like
+// fdlibm does.  Entry 0 is (1, 0), so small x keep their relative accuracy; elsewhere the error is ~1e-16 ABSOLUTE per
+// evaluation (1 / c_i is rounded), which is what a sum of z * log1p needs.  Max relative error measured against log1p: see
+// test_fast_log1p_of_the_fused_lnl_pass.
+constexpr int FZ_LOGTAB = 64;
+__device__ __forceinline__ double fz_log1p_tab(double x, const double2* __restrict__ tab) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double u = 1.0 + x;
+  const int hu = __double2hiint(u);
+  const int k = (hu >> 20) - 1023;
+  const double cerr = (k > 0 ? 1.0 - (u - x) : x - (u - 1.0)) * __builtin_amdgcn_rcp(u);   // (1 + x) - u, relative to u
+  const double2 t = tab[(hu >> 14) & (FZ_LOGTAB - 1)];
+  const double m = __hiloint2double((hu & 0x000FFFFF) | 0x3FF00000, __double2loint(u));    // [1, 2)
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(r, 1.0 / 9.0, -1.0 / 8.0);
+  p = fma(r, p, 1.0 / 7.0); p = fma(r, p, -1.0 / 6.0); p = fma(r, p, 1.0 / 5.0); p = fma(r, p, -0.25);
+  p = fma(r, p, 1.0 / 3.0); p = fma(r, p, -0.5); p = fma(r, p, 1.0);
+  const double dk = (double)k;
+  return fma(dk, ln2_hi, t.y + fma(r, p, fma(dk, ln2_lo, cerr)));
+}
+
 struct FzRegs {            // 4 entries per thread: 12 VGPRs (FMT 1: 6 until phase 1 turns the codes into numerators)
   uint4 rc;
   double2 v0, v1;
@@ -514,6 +537,12 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   if (FMT != 0)
     for (int t = tid; t < A.lut_len; t += FZ_NT) lutS[t] = A.lut[t];
   uint16_t* const eS = reinterpret_cast<uint16_t*>(lutS + A.lut_len);   // MODE 2: [Kp] the slots' exponent bounds
+  // MODE 1: [FZ_LOGTAB] (1 / c_i, log c_i) for fz_log1p_tab, in the same place (the two modes never share a launch)
+  double2* const logtab = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(lutS + A.lut_len) + 15) & ~(uintptr_t)15);
+  if (MODE == 1 && tid < FZ_LOGTAB) {
+    const double ci = 1.0 + (double)tid * (1.0 / FZ_LOGTAB);
+    logtab[tid] = make_double2(1.0 / ci, ts_log1p_pos((double)tid * (1.0 / FZ_LOGTAB)));
+  }
   if (MODE == 2)
     for (int t = tid; t < Kp; t += FZ_NT) eS[t] = A.ebias[p * Kp + t];
   const int64_t nsteps = nblk + FZ_LAG + 1;               // last scatter is block nblk-1 at step nblk+3
@@ -602,7 +631,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       if (lnl) {                                          // z = (Q c_prev) * recip0(rowsum);  acc[] holds c_cur
         auto term = [&](double q, uint32_t rc) {
           const double z = (q * c[rc & 0xFFFF]) * sb[rc >> 16];
-          if (z != 0.0) lsum += z * ts_log1p_pos(q * acc[rc & 0xFFFF]);
+          if (z != 0.0) lsum += z * fz_log1p_tab(q * acc[rc & 0xFFFF], logtab);
         };
         if (FMT == 1) {
           term(lutS[rr.cd.x & 0xFFFFu], rr.rc.x); term(lutS[rr.cd.x >> 16], rr.rc.y);

@@ -395,6 +395,26 @@ def test_device_log1p_matches_libm(gpu_device):
     assert np.all(np.isfinite(y)) and err.max() <= 2.0, (err.max(), x[err.argmax()])
 
 
+def test_fast_log1p_of_the_fused_lnl_pass(gpu_device):
+    """fz_log1p_tab (64-entry table + series): what a sum of z * log1p(x) needs is ABSOLUTE accuracy — <= 4e-16 here, i.e.
+    a few ulp of values around 1 — and relative accuracy where log1p is small (first table entry is exact: <= 4 ulp below
+    x = 1/64)."""
+    from telescope_amd import _lib
+    rng = np.random.RandomState(2)
+    x = np.concatenate([10.0 ** rng.uniform(-320, 300, 200000), 10.0 ** rng.uniform(-3, 3, 300000), rng.uniform(0, 3, 200000),
+                        1.0 + np.arange(64) / 64.0 - 1.0, np.nextafter(1.0 + np.arange(1, 64) / 64.0, 0) - 1.0,
+                        [0.0, 5e-324, 2.0 ** -28, 2.0 ** -53, 2.0 ** -52, 1.0, 2.0 ** 0.5 - 1, 2.0 ** 53, 1e43, 1.7e308]])
+    y = _lib.debug_log1p(x, table=True)
+    ref = np.log1p(x)
+    assert np.all(np.isfinite(y))
+    abs_err = np.abs(y - ref)
+    rel_ulp = abs_err / np.maximum(np.spacing(ref), 5e-324)
+    assert (abs_err / np.maximum(1.0, np.abs(ref))).max() <= 4e-16, (abs_err.max(), x[abs_err.argmax()])
+    assert rel_ulp.max() <= 64.0, (rel_ulp.max(), x[rel_ulp.argmax()])
+    small = x < 1.0 / 64
+    assert rel_ulp[small].max() <= 4.0, (rel_ulp[small].max(), x[small][rel_ulp[small].argmax()])
+
+
 def _random_csr(rng, n, k, max_len, lo, hi, hot_frac=0.0):
     lens = rng.randint(2, max_len, n)
     indptr = np.concatenate([[0], np.cumsum(lens)])
