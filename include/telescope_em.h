@@ -89,7 +89,10 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *                  sum may depend on timing.  Needs the fused kernel and a score table of <= 2048 entries; column sums are
  *                  within (entries of the column) x 2^-41 of exact, typically one fp64 rounding.  The float-valued sums of
  *                  tsem_reassign / _rows / _groups / tsem_report_colsums (conf, average) are accumulated exactly as well
- *                  (two atomics per value).  Default 0.
+ *                  (two atomics per value).  1: both pieces in ONE pass over THREE tables per part when they fit the LDS (score
+ *                  codes, at most 4800 columns per part with at most 8 parts — i.e. K <= 19k with teams of 4, K <= 38k with
+ *                  long rows) — ~1.65x the default mode's time per iteration instead of ~2.5x; 2: always the two-pass form
+ *                  (tsem_layout_info[22] says which one runs).  Default 0.
  *   "em_precision" 1: the EM pass in fp32 arithmetic (row sums, posteriors and column sums in fp32) — a
  *                  DIAGNOSTIC for the fp32-vs-fp64 tolerance sweep of BASELINE config 3, not a product path
  *   "fused_dbg", "fused_prof", "chunk_blocks"     timing experiments */

@@ -54,7 +54,7 @@ def build_parser():
     g = rs.add_argument_group('Device')
     g.add_argument('--device', type=int, default=0, help='GPU index (single-process runs).')
     g.add_argument('--reproducible', action='store_true',
-                   help='Exact, order-independent sums on the device: the same bits in every run (about 2.4x the time per EM iteration).')
+                   help='Exact, order-independent sums on the device: the same bits in every run (1.6-2.5x the time per EM iteration).')
     asg = sub.add_parser('assign', help='Load alignments + annotation, checkpoint, EM, reports')
     g = asg.add_argument_group('Input Options')
     g.add_argument('samfile', help='Path to alignment file (BAM, collated by read name).  Read by a streaming '
@@ -97,7 +97,7 @@ def build_parser():
     g = asg.add_argument_group('Device')
     g.add_argument('--device', type=int, default=0, help='GPU index (single-process runs).')
     g.add_argument('--reproducible', action='store_true',
-                   help='Exact, order-independent sums on the device: the same bits in every run (about 2.4x the time per EM iteration).')
+                   help='Exact, order-independent sums on the device: the same bits in every run (1.6-2.5x the time per EM iteration).')
     return ap
 
 

@@ -1901,10 +1901,11 @@ static int ensure_device(tsem_ctx* h) {
 
 typedef void (*fz_fn)(FusedArgs);
 template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
-  if (mode == 2) {                                         // exact (binned) column sums: needs the score table in LDS (formats 1, 2)
+  if (mode >= 2) {                                         // exact (binned) column sums: needs the score table in LDS (formats 1, 2)
 #ifdef TSEM_NO_REPRO
     return nullptr;
 #else
+    if (mode == 3) return fmt == 1 ? k_em_fused<P, 3, 1, GEO> : nullptr;   // both pieces in one pass: score codes only
     if (fmt == 1) return k_em_fused<P, 2, 1, GEO>;
     if (fmt == 2) return k_em_fused<P, 2, 2, GEO>;
     return nullptr;
@@ -1942,14 +1943,14 @@ static bool fz_wants_codes(const tsem_ctx* h) {
   return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048;
 }
 static size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
-  return (size_t)(2 * h->Kp + (fz_yr(h->geo) + 2) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0) +
+  return (size_t)((h->exact_single ? 3 : 2) * h->Kp + (fz_yr(h->geo) + 2) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0) +
          std::max<size_t>(h->opt_reproducible ? (size_t)h->Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16);   // (+ the slots' exponent table | the lnl pass's log table)
 }
 
 static void free_layout(tsem_ctx* h) {
   dfree(h->d_ebias); dfree(h->d_ovf); dfree(h->d_red_hi); dfree(h->d_binflag); dfree(h->d_ehist);
   dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_rid16); dfree(h->d_col_of_id); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_pcode); dfree(h->d_prc);
-  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fz_aux); h->fz_clean = false; dfree(h->d_fpartial); dfree(h->d_amb_w); dfree(h->d_sb_q32);
+  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fz_aux); h->fz_clean = false; dfree(h->d_fpartial); dfree(h->d_fpartial2); dfree(h->d_amb_w); dfree(h->d_sb_q32);
   h->fused_launched = false;
 }
 static void free_matrix(tsem_ctx* h) {
@@ -2255,7 +2256,20 @@ static int choose_geometry(tsem_ctx* h) {
   const int64_t na = h->N_amb, nu = h->N_uni;
   {
     // column parts (tables of one part must fit LDS) and rows per block
-    int P = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP - 1) / TS_MAX_KP;
+    // option "reproducible" = 1: both pieces of the exact sums in ONE pass if three tables per part fit the LDS with at most 8
+    // parts (score codes; 26 B of LDS per column); else — or with "reproducible" = 2 — two passes over two tables
+    h->exact_single = false;
+    if (h->opt_reproducible == 1 && h->em_kernel != TSEM_EMK_TWOPASS && h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048) {
+      const int p3 = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP3 - 64 - 1) / (TS_MAX_KP3 - 64);
+      // teams of 5-8 have ONE geometry (384 row slots): worth it only when the rows are long enough to fill their register
+      // tiles (20M x 30k: 100 per row 9.4 -> 6.3 ms per iteration, 18 per row 2.4 -> 3.3; K = 15k, teams of 4: 3.9 -> 2.6 at
+      // 40 per row, 1.9 -> 1.4 at 18; profiles/r03_reproducible.txt)
+      const double ml = na > 0 ? (double)(h->nnz - nu) / (double)na : 0.0;
+      const bool long_enough = p3 <= 4 || h->opt_P > 0 || ml * fz_rmax(1) >= 1.05 * fz_cap(1) * p3;
+      if (p3 >= 1 && p3 <= FZ_MAX_P && (K + p3 - 1) / p3 + 64 <= TS_MAX_KP3 && long_enough) h->exact_single = true;
+    }
+    const int max_kp = h->exact_single ? TS_MAX_KP3 - 64 : TS_MAX_KP;
+    int P = h->opt_P > 0 ? (int)h->opt_P : (K + max_kp - 1) / max_kp;
     if (P < 1) P = 1;
     if (h->opt_P <= 0 && h->em_kernel != TSEM_EMK_TWOPASS && P < FZ_MAX_P && na > 0) {
       // Teams never span XCDs, so floor(cpx / P) * P of an XCD's cpx CUs work: 28 of 32 for teams of 7.
@@ -2272,7 +2286,7 @@ static int choose_geometry(tsem_ctx* h) {
     int Kp = (K + P - 1) / P;
     if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
     // spare accumulator slots per part for very popular columns (build_layout splits them)
-    h->hot_extra = h->opt_hot_split ? std::min(64, TS_MAX_KP - Kp) : 0;
+    h->hot_extra = h->opt_hot_split ? std::min(64, (h->exact_single ? TS_MAX_KP3 : TS_MAX_KP) - Kp) : 0;
     Kp += h->hot_extra;
     h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
     h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
@@ -2298,7 +2312,7 @@ static int choose_geometry(tsem_ctx* h) {
       if (h->opt_geo >= 0 && P <= 4) h->geo = (h->opt_geo == 2 || h->opt_geo == 3) ? (int)h->opt_geo : 0;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
-      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - 2 * Kp * 8 - lut_bytes - std::max(h->opt_reproducible ? Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16)) / ((fz_yr(h->geo) + 2) * 8));
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - (h->exact_single ? 3 : 2) * Kp * 8 - lut_bytes - std::max(h->opt_reproducible ? Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16)) / ((fz_yr(h->geo) + 2) * 8));
       rmax = std::min(rmax, FILL_MAX_RP / P);                // (k_sb_fill_sorted keeps R x P counters in LDS)
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
@@ -2713,7 +2727,9 @@ static int build_layout(tsem_ctx* h) {
         TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h), h->geo),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
       if (h->opt_reproducible) {
-        fz_fn f2 = fz_kernel(P, 2, fz_fmt(h), h->geo);
+        if (h->exact_single && !fz_kernel(P, 3, fz_fmt(h), h->geo)) h->exact_single = false;   // (not score codes after all: fz_lds_bytes then counts two tables again)
+        if (h->exact_single) TSEM_ALLOC(h->d_fpartial2, (int64_t)h->fz_teams * h->Kpad);
+        fz_fn f2 = fz_kernel(P, h->exact_single ? 3 : 2, fz_fmt(h), h->geo);
         if (!f2) TSEM_FAIL(TSEM_ERR_ARG, "reproducible mode needs the fused kernel with a score table of at most 2048 entries");
         TSEM_HIP(hipFuncSetAttribute((const void*)f2, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
         TSEM_ALLOC(h->d_ebias, h->Kpad); TSEM_ALLOC(h->d_ovf, h->Kpad); TSEM_ALLOC(h->d_red_hi, K + 2); TSEM_ALLOC(h->d_binflag, 4);
@@ -2888,13 +2904,13 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
   A.sync = h->d_xflags;
   A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.dbg = (int)h->opt_dbg;
   A.ctl = h->d_ctl;
-  A.ebias = h->d_ebias; A.bin = bin; A.ovf = h->d_ovf;
+  A.ebias = h->d_ebias; A.bin = bin; A.ovf = h->d_ovf; A.partial2 = h->d_fpartial2;
 
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
   const size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
   if (lnl && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
   fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h), h->geo);
-  if (!fn) TSEM_FAIL(TSEM_ERR_ARG, mode == 2 ? "reproducible mode needs the fused kernel with a score table of at most 2048 entries"
+  if (!fn) TSEM_FAIL(TSEM_ERR_ARG, mode >= 2 ? "reproducible mode needs the fused kernel with a score table of at most 2048 entries"
                                                : "fused kernel supports at most 8 column parts");
   if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
   fn<<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A);
@@ -3008,15 +3024,23 @@ int tsem_em_pass(tsem_ctx* h) {
       TSEM_HIP(hipStreamSynchronize(h->stream));
       if (st) { h->em_launches += 1; return TSEM_OK; }
     }
-    auto pass = [&](int bin, hipEvent_t* ev) -> int {
-      if (int rc = launch_fused(h, 2, ev, bin)) return rc;
-      k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+    auto reduce = [&](const double* partial) -> int {
+      k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
                                                               h->d_xflags, h->P, h->d_ctl,
                                                               h->P > 1 ? reinterpret_cast<unsigned long long*>(h->d_xchg) : nullptr,
                                                               h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
       // (k_colreduce cleared the exchange ring; the sync words are cleared by the memset of the next launch)
       TSEM_HIP(hipGetLastError());
       return TSEM_OK;
+    };
+    // exact_single: ONE launch leaves the team partials of both pieces (d_fpartial: high, d_fpartial2: low)
+    auto pass = [&](int bin, hipEvent_t* ev) -> int {
+      if (h->exact_single) {
+        if (bin == 1) { if (int rc = launch_fused(h, 3, ev, 0)) return rc; }
+        return reduce(bin == 1 ? h->d_fpartial : h->d_fpartial2);
+      }
+      if (int rc = launch_fused(h, 2, ev, bin)) return rc;
+      return reduce(h->d_fpartial);
     };
     for (int attempt = 0;; ++attempt) {
       if (int rc = pass(1, attempt == 0 ? pair : nullptr)) return rc;
@@ -4401,7 +4425,8 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[16] = h->use_fused ? (int64_t)fz_lds_bytes(h, fz_fmt(h) != 0) : 0;   // dynamic LDS per workgroup of the fused kernel
   info[17] = h->sorted_layout ? 1 : 0; info[18] = h->geo; info[19] = h->n_fallbacks;
   info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->len_gt[5] ? 2 : 1) : 0;     // 2: some row has more than 256 entries, see telescope_em.h
-  info[22] = 0; info[23] = 0;
+  info[22] = h->exact_single ? 1 : 0;                      // reproducible: both pieces in one pass
+  info[23] = 0;
   return TSEM_OK;
 }
 

@@ -48,6 +48,7 @@ __host__ __device__ inline uint64_t ts_hash3(uint64_t seed, uint64_t row, uint64
 // LDS budget for the per-part tables (c and acc, 8 B each per column).
 constexpr int TS_LDS_TABLE_BYTES = 120 * 1024;
 constexpr int TS_MAX_KP = TS_LDS_TABLE_BYTES / 16;   // 7680 columns per part
+constexpr int TS_MAX_KP3 = 4800;                     // ... when a part keeps THREE tables in LDS (option "reproducible", one pass: 26 B per column)
 constexpr int TS_LDS_MAX = 160 * 1024;
 constexpr int TS_ENTRY_PAD = 320;   // entries of padding behind indices[] / raw[] (k_report_rows reads 16-entry lanes past a row's end)
 constexpr int TS_STRANDS = 16;   // strand-transposed entry order inside a sub-block
@@ -120,6 +121,8 @@ struct tsem_ctx {
   uint16_t* d_ebias = nullptr;      // [Kpad] per slot: biased exponent of the bound 2^E of its contributions
   uint8_t* d_ovf = nullptr;         // [Kpad] a contribution reached its slot's bound in the last pass
   double* d_red_hi = nullptr;       // [K+2] column sums of the high pieces
+  bool exact_single = false;        // reproducible: both pieces in ONE pass (three tables per part fit the LDS with <= 8 parts)
+  double* d_fpartial2 = nullptr;    // [fz_teams][Kpad] the low pieces' team partials of that pass
   int16_t* d_ehist = nullptr;       // [2K] per column: exponent (+4) of its last sum, and by how many bits it fell in the last iteration
   uint32_t* d_binflag = nullptr;    // [1] some column wants the pass repeated with another exponent
   int64_t n_bin_repeats = 0;        // passes repeated because an exponent had to move

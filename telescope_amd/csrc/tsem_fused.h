@@ -100,6 +100,7 @@ struct FusedArgs {
   // and the order in which the hardware serves the atomics stops mattering
   const uint16_t* ebias;  // [P*Kp] biased exponent eb of the slot's bound 2^E (every contribution of the slot is < 2^E)
   int bin;                // 1: the high piece (multiples of 2^(E-30)), 2: the low piece (the remainder in multiples of 2^(E-60))
+  double* partial2;       // MODE 3 (both pieces in ONE pass, a second accumulator table in LDS): the low pieces' team partials
   uint8_t* ovf;           // [P*Kp] set to 1 when a contribution reached its slot's bound (the host raises E and repeats the pass)
   int dbg;              // bit0: skip partner loads (timing experiments only; wrong results)
                         // bit5 / bit6: behave like a hand-off time-out in the EM / lnl pass (tests of the recovery path)
@@ -462,7 +463,8 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   const int Kp = A.Kp, R = A.R;
   double* c = reinterpret_cast<double*>(smem);
   double* acc = c + Kp;
-  double* y = acc + Kp;                            // y[FZ_YR][R]  partial row sums (ring)
+  double* const acc2 = acc + Kp;                   // MODE 3: the low pieces' accumulators [Kp]
+  double* y = acc + (MODE == 3 ? 2 : 1) * Kp;      // y[FZ_YR][R]  partial row sums (ring)
   double* s = y + FZ_YR * R;                       // s[2][R]      w_i / rowsum_i   (ring)
   int* ibox = reinterpret_cast<int*>(s + 2 * R);   // [0]=ticket [1..8]=xcd counts
   const int tid = threadIdx.x;
@@ -491,6 +493,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     for (int x = 0; x < 8; ++x) ibox[1 + x] = (int)fz_ld_u32(&sync[x]);
   }
   for (int t = tid; t < Kp; t += FZ_NT) acc[t] = 0.0;   // (lnl mode: overwritten with ctab2 below)
+  if (MODE == 3) for (int t = tid; t < Kp; t += FZ_NT) acc2[t] = 0.0;
   for (int t = tid; t < FZ_YR * R; t += FZ_NT) y[t] = 0.0;
   for (int t = tid; t < 2 * R; t += FZ_NT) s[t] = 0.0;
   __syncthreads();
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     const double ci = 1.0 + (double)tid * (1.0 / FZ_LOGTAB);
     logtab[tid] = make_double2(1.0 / ci, ts_log1p_pos((double)tid * (1.0 / FZ_LOGTAB)));
   }
-  if (MODE == 2)
+  if (MODE >= 2)
     for (int t = tid; t < Kp; t += FZ_NT) eS[t] = A.ebias[p * Kp + t];
   const int64_t nsteps = nblk + FZ_LAG + 1;               // last scatter is block nblk-1 at step nblk+3
   // prologue: offsets of blocks 0..4 straight into LDS
@@ -745,22 +748,32 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
         const uint32_t j0 = idle2 ? dj : (a0 & 0xFFFFu), j1 = idle2 ? dj : (a1 & 0xFFFFu);
         const uint32_t j2 = idle2 ? dj : (a2 & 0xFFFFu), j3 = idle2 ? dj : (a3 & 0xFFFFu);
 #endif
-        if (MODE == 2) {
+        if (MODE >= 2) {
           // Exact accumulation (Demmel-Nguyen style pre-rounding on a per-slot grid): v = hi + lo + rest with hi a multiple of
-          // 2^(E-30) and lo a multiple of 2^(E-60); the sums of the hi pieces (and, in the second pass, of the lo pieces) of up to
-          // 2^23 contributions below 2^E are exact in fp64, hence the same whatever order the LDS serves the atomics in.
-          auto piece = [&](double v, uint32_t j, bool live) -> double {
+          // 2^(E-30) and lo a multiple of 2^(E-60); the sums of the hi pieces (and of the lo pieces) of up to 2^23 contributions
+          // below 2^E are exact in fp64, hence the same whatever order the LDS serves the atomics in.  MODE 2: one piece per
+          // pass (A.bin), one accumulator table.  MODE 3: both pieces in this pass, two tables (when three tables fit the LDS).
+          auto pieces = [&](double v, uint32_t j, bool live, double& hi, double& lo) {
             const uint32_t eb = live ? (uint32_t)eS[j] : 1023u;
             if (live && (uint32_t)(__double2hiint(v) >> 20) >= eb) A.ovf[p * Kp + j] = 1;    // v >= 2^E: the bound was too low
             const double m1 = __hiloint2double((int)(((eb + 22u) << 20) | 0x80000u), 0);    // 1.5 * 2^(E+22): ulp = 2^(E-30)
-            const double hi = (v + m1) - m1;
-            if (A.bin == 1) return hi;
+            hi = (v + m1) - m1;
             const double m2 = __hiloint2double((int)(((eb - 8u) << 20) | 0x80000u), 0);     // 1.5 * 2^(E-8):  ulp = 2^(E-60)
-            return ((v - hi) + m2) - m2;
+            lo = ((v - hi) + m2) - m2;
           };
-          const double p0 = piece(rs.v0.x * s0, j0, !idle2), p1 = piece(rs.v0.y * s1, j1, !idle2);
-          const double p2 = piece(rs.v1.x * s2, j2, !idle2), p3 = piece(rs.v1.y * s3, j3, !idle2);
-          lds_add(&acc[j0], p0); lds_add(&acc[j1], p1); lds_add(&acc[j2], p2); lds_add(&acc[j3], p3);
+          double h0, h1, h2, h3, l0, l1, l2, l3;
+          pieces(rs.v0.x * s0, j0, !idle2, h0, l0); pieces(rs.v0.y * s1, j1, !idle2, h1, l1);
+          pieces(rs.v1.x * s2, j2, !idle2, h2, l2); pieces(rs.v1.y * s3, j3, !idle2, h3, l3);
+          if (MODE == 3) {
+            // (idle lanes: both zeros go to the lane's dummy slot of acc[] — acc2 + dj would point past the dummy slots)
+            double* const b2 = idle2 ? acc : acc2;
+            lds_add(&acc[j0], h0); lds_add(&acc[j1], h1); lds_add(&acc[j2], h2); lds_add(&acc[j3], h3);
+            lds_add(&b2[j0], l0); lds_add(&b2[j1], l1); lds_add(&b2[j2], l2); lds_add(&b2[j3], l3);
+          } else {
+            const bool first = A.bin == 1;
+            lds_add(&acc[j0], first ? h0 : l0); lds_add(&acc[j1], first ? h1 : l1);
+            lds_add(&acc[j2], first ? h2 : l2); lds_add(&acc[j3], first ? h3 : l3);
+          }
         } else {
         lds_add(&acc[j0], rs.v0.x * s0);
         lds_add(&acc[j1], rs.v0.y * s1);
@@ -776,7 +789,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       load_blk(rs, oqa, oqb, i + FZ_DL);
       if (pr) A.prof[i * FZ_PROF_SLOTS + 2] = clock64();
       if (A.prof && team == 0 && p == 0 && tid == FZ_DT - 64 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 8] = clock64();
-      __builtin_amdgcn_s_waitcnt(0xC47F);                 // lgkmcnt(4): everything but the four scatters above has completed
+      __builtin_amdgcn_s_waitcnt(MODE == 3 ? 0xC87F : 0xC47F);   // lgkmcnt(4): everything but the four (MODE 3: eight) scatters above has completed
       oqa = __builtin_amdgcn_readfirstlane(on0); oqb = __builtin_amdgcn_readfirstlane(on1);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -833,4 +846,8 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
 #endif
   double* out = A.partial + (int64_t)team * (P * Kp) + p * Kp;
   for (int t = tid; t < Kp; t += FZ_NT) out[t] = acc[t];
+  if (MODE == 3) {
+    double* out2 = A.partial2 + (int64_t)team * (P * Kp) + p * Kp;
+    for (int t = tid; t < Kp; t += FZ_NT) out2[t] = acc2[t];
+  }
 }

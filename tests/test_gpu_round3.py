@@ -521,3 +521,35 @@ def test_bench_two_ranks_dry_run_on_one_gpu(gpu_device, launcher):
     for key in ('pi_sum', 'pi_weighted', 'theta_weighted'):
         assert abs(two['check'][key] - one['check'][key]) <= 1e-11 * abs(one['check'][key]), key
     assert two['value'] > 0 and two['ms_per_step'] > 0
+
+
+def test_reproducible_one_pass_and_two_pass_forms(gpu_device):
+    """`reproducible` = 1 takes the ONE-pass form (three tables per part in LDS: both pieces of every contribution in one
+    launch) where it fits — K = 15k with teams of 4 — and = 2 forces the two-pass form; each is bitwise reproducible, both agree
+    with the C oracle like the default mode, and with long rows K = 30k takes the one-pass form with teams of 7-8."""
+    from oracle import em_fused as oc
+    res = {}
+    for form in (1, 2):
+        runs = []
+        for rep in range(2):
+            tl = _synthetic_tl(1_500_000, 15_000, 24, 'zipf', uniq=0.05, options=(('reproducible', form),),
+                               opts=Opts(max_iter=12, em_epsilon=0.0))
+            info = tl._eng.layout_info()
+            assert info['exact_single'] == (1 if form == 1 else 0) and info['reproducible'] == 1
+            tl.em()
+            runs.append((tl.lnl, tl.pi.copy(), tl.theta.copy()))
+            if form == 1 and rep == 0:
+                ip, ix, rw = tl._eng.export_csr()
+                ref = oc.em_fused_arrays(ip, ix, rw, 15_000, 0, 200000, 0.0, 12)
+        assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+        res[form] = runs[0]
+    for form in (1, 2):
+        assert abs(res[form][0] - ref['lnl']) <= RTOL * abs(ref['lnl'])
+        assert np.allclose(res[form][1], ref['pi'], rtol=RTOL, atol=0) and np.allclose(res[form][2], ref['theta'], rtol=RTOL, atol=0)
+    tl = _synthetic_tl(300_000, 30_000, 100, 'zipf', uniq=0.05, options=(('reproducible', 1),), opts=Opts(max_iter=4, em_epsilon=0.0))
+    info = tl._eng.layout_info()
+    assert info['exact_single'] == 1 and info['P'] >= 7
+    tl.em()
+    ip, ix, rw = tl._eng.export_csr()
+    ref = oc.em_fused_arrays(ip, ix, rw, 30_000, 0, 200000, 0.0, 4)
+    assert abs(tl.lnl - ref['lnl']) <= RTOL * abs(ref['lnl']) and np.allclose(tl.pi, ref['pi'], rtol=RTOL, atol=0)
