@@ -456,7 +456,7 @@ def reproducible_leg(device, rows, args, cdf, dist_code, iters=10):
             ms = (time.perf_counter() - t0) * 1e3 / iters
             pi, theta = eng.get_params()
             info = eng.layout_info()
-            res.setdefault(mode, []).append((ms, pi.copy(), theta.copy(), info['bin_repeats']))
+            res.setdefault(mode, []).append((ms, pi.copy(), theta.copy(), info['bin_repeats'], info.get('exact_single', 0)))
             eng.close()
             del tl
     finally:
@@ -464,6 +464,7 @@ def reproducible_leg(device, rows, args, cdf, dist_code, iters=10):
     d, (a, b) = res[0][0], res[1]
     return dict(sample_rows=rows, iterations=iters + 2, ms_per_step_default=d[0], ms_per_step=min(a[0], b[0]),
                 cost_vs_default=min(a[0], b[0]) / d[0], repeated_passes=int(a[3]),
+                form='one pass, three tables per part' if a[4] else 'two passes (three tables per part do not fit / rows too short for teams of 5-8)',
                 two_runs_bit_identical=bool((a[1] == b[1]).all() and (a[2] == b[2]).all()),
                 pi_max_rel_delta_vs_default=float(abs(a[1] - d[1]).max() / d[1].max()))
 
