@@ -1459,9 +1459,11 @@ struct ReportEmit {                                        // where a row's valu
   }
 };
 
-constexpr int RR_NT = 512;                                 // threads per workgroup (E = 16 needs ~150 VGPRs: 512 threads leave 256)
+// threads per workgroup: the pass over the final z needs ~92 VGPRs (pi*theta gathers in flight) and spills under the 128 of a 1024-thread
+// workgroup (15.6 vs 5.3 ms); the pass over the initial z needs 68 and gains from 16 waves per CU instead of 8 (7.8 -> 6.9 ms with its tie list)
+constexpr int rr_nt(bool init) { return init ? 1024 : 512; }
 template <int G, int E, bool INIT>
-__global__ __launch_bounds__(RR_NT) void k_report_rows(ReportArgs A) {
+__global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
   static_assert(E == 8 || E == 16, "entries per lane");
   extern __shared__ double rr_lds[];   // [lut_len] score table | [HC] pi*theta | [Hs] conf (f64) | [Hs] single winners | [Hs] two-way ties (u32)
   double* const lutS = rr_lds;
@@ -3973,7 +3975,7 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       }
       R.g_conf = d_g; R.g_n1 = d_g + IDN; R.g_n2 = d_g + 2 * (int64_t)IDN; R.g_avgt = d_g + 3 * (int64_t)IDN;
       if (exact) { R.g_conf_lo = d_g + 4 * (int64_t)IDN; R.g_avgt_lo = d_g + 5 * (int64_t)IDN; }
-      // LDS: one workgroup of RR_NT threads per CU (or two, option rowpass_wgs).  The final z wants pi*theta of as many
+      // LDS: one workgroup of rr_nt() threads per CU (or two, option rowpass_wgs).  The final z wants pi*theta of as many
       // ids as fit (8 B each) next to a few thousand accumulator slots (16 B each); the initial z has no pi*theta.
       const int wgs = h->opt_rowpass_wgs >= 2 && h->opt_report_wgs2 ? 2 : 1;
       const int lds_avail = TS_LDS_MAX / wgs - 2048 - R.lut_len * 8;
@@ -3996,7 +3998,7 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       R.dbg = (int)h->opt_report_dbg;
       R.defer_rows = d_rows; R.defer_n = d_n;               // (d_rows is the tie list later: the slow kernel is done with it by then)
       TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
-      rk<<<h->n_cu * wgs, RR_NT, (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * slot_bytes, h->stream>>>(R);
+      rk<<<h->n_cu * wgs, rr_nt(init), (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * slot_bytes, h->stream>>>(R);
       TSEM_HIP(hipGetLastError());
       if (init) k_report_slow<true><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
       else k_report_slow<false><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
