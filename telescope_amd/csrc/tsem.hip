@@ -2267,7 +2267,9 @@ static int choose_geometry(tsem_ctx* h) {
       // tiles (20M x 30k: 100 per row 9.4 -> 6.3 ms per iteration, 18 per row 2.4 -> 3.3; K = 15k, teams of 4: 3.9 -> 2.6 at
       // 40 per row, 1.9 -> 1.4 at 18; profiles/r03_reproducible.txt)
       const double ml = na > 0 ? (double)(h->nnz - nu) / (double)na : 0.0;
-      const bool long_enough = p3 <= 4 || h->opt_P > 0 || ml * fz_rmax(1) >= 1.05 * fz_cap(1) * p3;
+      // (one pass costs ~1.25 default passes on a full tile, two passes cost 2: worth it down to tiles ~2/3 full — K = 30k, 40 per
+      //  row, teams of 7: 3.58 against 3.79 ms per iteration)
+      const bool long_enough = p3 <= 4 || h->opt_P > 0 || ml * fz_rmax(1) >= 0.62 * 1.05 * fz_cap(1) * p3;
       if (p3 >= 1 && p3 <= FZ_MAX_P && (K + p3 - 1) / p3 + 64 <= TS_MAX_KP3 && long_enough) h->exact_single = true;
     }
     const int max_kp = h->exact_single ? TS_MAX_KP3 - 64 : TS_MAX_KP;
