@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
 // a thread's four consecutive entries and its neighbours' mostly share a row and the row sums can be
 // reduced in registers / across lanes instead of one LDS atomic per entry (tsem_fused.h, phase 1).
 // The padding at the end of a sub-block repeats the last row with value 0.
-constexpr int FILL_MAX_RP = 1152 * 4;                      // row slots x parts of a block the row-order fill can take
+constexpr int FILL_MAX_RP = 768 * 8;                       // row slots x parts of a block the row-order fill can take (1152 x 4, 768 x 8)
 // Round 3 (second pass over this kernel, 13.9 ms at 2e9 entries): it was bound by the LATENCY of three dependent loads
 // per row (row slot -> row pointers -> entries, then one more round trip per 16 entries of the row) with 16 rows in
 // flight per workgroup.  Now the row pointers of the whole block go to LDS in one parallel sweep, and a 16-lane group
@@ -1918,7 +1918,7 @@ template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
   return mode ? k_em_fused<P, 1, 0, GEO> : k_em_fused<P, 0, 0, GEO>;
 }
 template <int P> static fz_fn fz_pick(int mode, int fmt, int geo) {
-  if constexpr (P > 4) return fz_pick2<P, 1>(mode, fmt);   // teams of 5-8: one geometry
+  if constexpr (P > 4) return geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 1>(mode, fmt);   // teams of 5-8: 384 or 768 row slots
   else return geo == 3 ? fz_pick2<P, 3>(mode, fmt) : (geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 0>(mode, fmt));
 }
 static int fz_fmt(const tsem_ctx* h) { return h->fmt_code ? 1 : (h->fmt_wcode ? 2 : 0); }
@@ -2269,7 +2269,7 @@ static int choose_geometry(tsem_ctx* h) {
       const double ml = na > 0 ? (double)(h->nnz - nu) / (double)na : 0.0;
       // (one pass costs ~1.25 default passes on a full tile, two passes cost 2: worth it down to tiles ~2/3 full — K = 30k, 40 per
       //  row, teams of 7: 3.58 against 3.79 ms per iteration)
-      const bool long_enough = p3 <= 4 || h->opt_P > 0 || ml * fz_rmax(1) >= 0.62 * 1.05 * fz_cap(1) * p3;
+      const bool long_enough = p3 <= 4 || h->opt_P > 0 || ml * fz_rmax(2) >= 0.62 * 1.05 * fz_cap(1) * p3;
       if (p3 >= 1 && p3 <= FZ_MAX_P && (K + p3 - 1) / p3 + 64 <= TS_MAX_KP3 && long_enough) h->exact_single = true;
     }
     const int max_kp = h->exact_single ? TS_MAX_KP3 - 64 : TS_MAX_KP;
@@ -2284,7 +2284,7 @@ static int choose_geometry(tsem_ctx* h) {
       auto util = [&](int p) { return (double)(cpx / p * p) / cpx; };
       const double mean_len = (double)(h->nnz - nu) / (double)na;
       for (int p2 = P + 1; p2 <= FZ_MAX_P; ++p2)
-        if (util(p2) >= util(P) + 0.10 && mean_len * fz_rmax(1) >= 1.05 * fz_cap(1) * p2) { P = p2; break; }
+        if (util(p2) >= util(P) + 0.10 && mean_len * fz_rmax(2) >= 1.05 * fz_cap(1) * p2) { P = p2; break; }
     }
     if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
     int Kp = (K + P - 1) / P;
@@ -2308,12 +2308,16 @@ static int choose_geometry(tsem_ctx* h) {
       // (profiles/r02_sweep_short.txt, 50M rows, both entry formats: the third exchange wave pays once the tile
       // needs more than ~1.25x the 512 row slots of geometry 0 — 20 entries per row: codes 2.21 -> 1.98 ms, fp64
       // 2.63 -> 2.57; 28 per row: codes 2.55 -> 2.66, fp64 equal)
-      h->geo = P > 4 ? 1 : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > 1.25 * fz_rmax(0)) ? 2 : 0);
+      // teams of 5-8 (round 3): 768 row slots (geometry 2: two row pairs per exchange lane, (P - 1) x 2 partner values in its
+      // registers: 118-124 VGPRs, no spill) when 384 cannot fill the register tiles
+      h->geo = P > 4 ? ((1.07 * fz_cap(1) * P / std::max(2.0, mean_len) > 1.25 * fz_rmax(1)) ? 2 : 1)
+                     : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > 1.25 * fz_rmax(0)) ? 2 : 0);
       // rows so short that 768 of them cannot fill the tile either: geometry 3 (32 B of LDS per row slot instead of 48)
       // (profiles/r03_sweep_short.txt: 8 / 10 / 12 entries per row 1.27 / 1.31 / 1.39 -> 1.18 / 1.23 / 1.34 ms, 14 equal, 16 and more slower:
       //  the exchange of a step grows with its row slots)
-      if (h->geo == 2 && 1.07 * fz_cap(2) * P / std::max(2.0, mean_len) > 1.4 * fz_rmax(2)) h->geo = 3;
+      if (P <= 4 && h->geo == 2 && 1.07 * fz_cap(2) * P / std::max(2.0, mean_len) > 1.4 * fz_rmax(2)) h->geo = 3;
       if (h->opt_geo >= 0 && P <= 4) h->geo = (h->opt_geo == 2 || h->opt_geo == 3) ? (int)h->opt_geo : 0;
+      if (h->opt_geo >= 0 && P > 4) h->geo = h->opt_geo == 2 ? 2 : 1;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
       int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - (h->exact_single ? 3 : 2) * Kp * 8 - lut_bytes - std::max(h->opt_reproducible ? Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16)) / ((fz_yr(h->geo) + 2) * 8));

@@ -42,7 +42,8 @@ constexpr int FZ_NT = 1024;            // threads per workgroup
 // block to fill the register tile.
 //   0 : 2 exchange waves x 2 row pairs per lane (R <= 512), 14 data waves   teams of 1-4
 //   1 : 3 exchange waves x 1 row pair  per lane (R <= 384), 13 data waves   teams of 5-8
-//   2 : 3 exchange waves x 2 row pairs per lane (R <= 768), 13 data waves   teams of 1-4, short rows
+//   2 : 3 exchange waves x 2 row pairs per lane (R <= 768), 13 data waves   teams of 1-4, short rows; teams of 5-8 whose rows cannot
+//       fill the tiles with 384 row slots (round 3: (P - 1) x 2 partner values per exchange lane, 118-126 VGPRs, no spill)
 //   3 : 3 exchange waves x 3 row pairs per lane (R <= 1152), 13 data waves  teams of 1-4, rows too short to fill the tile with
 //       768 of them (round 3).  The row slots are what limits such a block: 48 B of LDS each (y ring 4 deep + s ring 2 deep)
 //       next to 121 KB of tables.  Here the exchange wave reads a block's partial sums ONCE, at the publish, keeps its own

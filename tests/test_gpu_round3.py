@@ -553,3 +553,23 @@ def test_reproducible_one_pass_and_two_pass_forms(gpu_device):
     ip, ix, rw = tl._eng.export_csr()
     ref = oc.em_fused_arrays(ip, ix, rw, 30_000, 0, 200000, 0.0, 4)
     assert abs(tl.lnl - ref['lnl']) <= RTOL * abs(ref['lnl']) and np.allclose(tl.pi, ref['pi'], rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize('cols,d,fmt', [(40_000, 20, 0), (50_000, 36, 0), (33_000, 12, 1), (61_000, 24, 0)])
+def test_teams_of_5_to_8_with_768_row_slots(gpu_device, cols, d, fmt):
+    """K in (30k, 61k] needs teams of 5-8; when their rows are too short to fill the register tiles with 384 row slots they now
+    take the 768-slot geometry (two row pairs per exchange lane): against the C oracle, and against the 384-slot geometry."""
+    from oracle import em_fused as oc
+    tl = _synthetic_tl(400_000, cols, d, 'zipf', uniq=0.05, options=(('value_format', fmt),), opts=Opts(max_iter=5, em_epsilon=0.0))
+    info = tl._eng.layout_info()
+    assert info['fused'] == 1 and info['P'] >= 5 and info['geometry'] == 2 and info['R'] > 384, info
+    tl.em()
+    ip, ix, rw = tl._eng.export_csr()
+    ref = oc.em_fused_arrays(ip, ix, rw, cols, 0, 200000, 0.0, 5)
+    assert abs(tl.lnl - ref['lnl']) <= RTOL * abs(ref['lnl'])
+    assert np.allclose(tl.pi, ref['pi'], rtol=RTOL, atol=0) and np.allclose(tl.theta, ref['theta'], rtol=RTOL, atol=0)
+    t1 = _synthetic_tl(400_000, cols, d, 'zipf', uniq=0.05, options=(('value_format', fmt), ('geometry', 1)), opts=Opts(max_iter=5, em_epsilon=0.0))
+    assert t1._eng.layout_info()['geometry'] == 1 and t1._eng.layout_info()['R'] <= 384
+    t1.em()
+    assert abs(t1.lnl - tl.lnl) <= 1e-11 * abs(tl.lnl) and np.allclose(t1.pi, tl.pi, rtol=1e-10, atol=0)
+    assert np.array_equal(t1.reassign_colsums('exclude'), tl.reassign_colsums('exclude'))
