@@ -239,7 +239,10 @@ def main():
     cdf = synthetic.poisson_cdf_u32(args.nnz_row)
 
     eng.set_option('row_offset', r0)
-    eng.set_option('em_kernel', {'auto': EMK_AUTO, 'twopass': EMK_TWOPASS, 'fused': EMK_FUSED}[args.em_kernel])
+    # (--one-device: the persistent fused kernel needs all its workgroups resident at once, which two processes sharing a GPU cannot
+    #  promise each other — the hand-off watchdog would catch it and fall back; the dry run is about the plumbing, so it starts there)
+    eng.set_option('em_kernel', EMK_TWOPASS if args.one_device and args.em_kernel == 'auto' else
+                   {'auto': EMK_AUTO, 'twopass': EMK_TWOPASS, 'fused': EMK_FUSED}[args.em_kernel])
     eng.set_option('value_format', {'auto': 0, 'f64': 1, 'code16': 2}[args.value_format])
     if args.block_rows:
         eng.set_option('block_rows', args.block_rows)
@@ -272,10 +275,21 @@ def main():
         if comm is not None and not comm.in_library:
             # fall-back transport (the library communicator could not be created, distributed.py): what em() then runs —
             # one torch.distributed all-reduce of the engine's reduce buffer and one host round trip per iteration
-            for _ in range(n):
+            from telescope_amd._lib import EngineError, ERR_TIMEOUT
+            timeouts = 0
+            done = 0
+            while done < n:
                 eng.em_pass()
                 comm.allreduce_device(eng, 0, args.cols + 1)
-                eng.em_update()
+                try:
+                    eng.em_update()
+                except EngineError as exc:      # some rank's persistent kernel timed out: nobody committed (slot K of the sums);
+                    timeouts += 1               # that rank switches to the two-pass kernels, every rank redoes the iteration
+                    if exc.code != ERR_TIMEOUT or timeouts > 3:
+                        raise
+                    eng.recover_timeout()
+                    continue
+                done += 1
             return
         eng.em_chunk(n, 0.0, False)
 

@@ -26,22 +26,40 @@ class EngineError(RuntimeError):
     code = 0
 
 
-def build_library(force=False, verbose=False):
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = [SRC, os.path.join(HERE, 'csrc', 'tsem_common.h'),
-            os.path.join(HERE, 'csrc', 'tsem_fused.h'),
-            os.path.join(ROOT, 'include', 'telescope_em.h')]
-    deps = [d for d in deps if os.path.exists(d)]
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
-        return LIB_PATH
-    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-munsafe-fp-atomics', '-I' + os.path.join(ROOT, 'include'),
-           '-I' + os.path.join(HERE, 'csrc'), '-o', LIB_PATH, SRC, '-ldl', '-lpthread']   # (RCCL is resolved at run time)
+FZ_UNITS = ('tsem_fz_p1', 'tsem_fz_p2', 'tsem_fz_p3', 'tsem_fz_p4', 'tsem_fz_p56', 'tsem_fz_p78')
+
+
+def build_library(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU).  Seven translation units — tsem.hip and the
+    six that instantiate the fused kernel for one or two team sizes each (most of the build time) — are compiled in parallel and
+    linked into one shared object."""
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(HERE, 'csrc')
+    units = [SRC] + [os.path.join(csrc, u + '.hip') for u in FZ_UNITS]
+    deps = units + [os.path.join(csrc, h) for h in ('tsem_common.h', 'tsem_fused.h', 'tsem_device.h', 'tsem_fused_inst.h')] + \
+        [os.path.join(ROOT, 'include', 'telescope_em.h')]
+    target = out or LIB_PATH
+    if (not force and os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)):
+        return target
+    objdir = os.path.join(csrc, '_obj' + ('' if out is None else '_' + os.path.basename(out)))
+    os.makedirs(objdir, exist_ok=True)
+    common = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
+              '-I' + os.path.join(ROOT, 'include'), '-I' + csrc] + list(extra_flags)
+
+    def compile_unit(src):
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '.o')
+        cmd = common + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+    with ThreadPoolExecutor(max_workers=len(units)) as ex:
+        objs = list(ex.map(compile_unit, units))
+    link = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', target] + objs + ['-ldl', '-lpthread']   # (RCCL is resolved at run time)
     if verbose:
-        print(' '.join(cmd))
-    subprocess.run(cmd, check=True)
-    return LIB_PATH
+        print(' '.join(link), flush=True)
+    subprocess.run(link, check=True)
+    return target
 
 
 _lib = None

@@ -38,43 +38,7 @@ static std::string g_create_err;
 // ============================================================================
 // small device helpers
 // ============================================================================
-// log1p(x) for finite x >= 0 (the lnl passes evaluate it once per stored entry: 2*10^9 times per
-// pass at config 4, where the library routine's generality made the pass compute-bound).  The
-// classic argument reduction 1+x = 2^k (1+f), sqrt(2)/2 < 1+f < sqrt(2), log(1+f) = f - f^2/2 +
-// s (f^2/2 + R(s^2)), s = f/(2+f), with the rounding of 1+x corrected by c/u (W. Kahan / fdlibm's
-// published log1p; minimax coefficients Lp1..Lp7 from there).  Error < 1 ulp on the range used.
-__device__ __forceinline__ double ts_log1p_pos(double x) {
-  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
-               Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
-               Lp7 = 1.479819860511658591e-01;
-  if (x < 3.725290298461914e-09) return fma(-0.5 * x, x, x);         // x < 2^-28: x - x^2/2 is exact to rounding
-  const double u = 1.0 + x;
-  int hu = __double2hiint(u);
-  int k = (hu >> 20) - 1023;
-  // rounding error of 1 + x, relative to u (only matters while k is small; it underflows harmlessly later)
-  const double c = (k > 0 ? 1.0 - (u - x) : x - (u - 1.0)) * __builtin_amdgcn_rcp(u);
-  hu &= 0x000fffff;
-  if (hu < 0x6a09e) { hu |= 0x3ff00000; } else { k += 1; hu |= 0x3fe00000; }   // 1+f in [sqrt(2)/2, sqrt(2))
-  const double f = __hiloint2double(hu, __double2loint(u)) - 1.0;
-  const double hfsq = 0.5 * f * f;
-  const double d = 2.0 + f;                                            // in (1.7, 2.42): plain Newton reciprocal
-  double r = __builtin_amdgcn_rcp(d);
-  r = fma(fma(-d, r, 1.0), r, r);
-  r = fma(fma(-d, r, 1.0), r, r);
-  double s = f * r;
-  s = fma(fma(-d, s, f), r, s);
-  const double z = s * s;
-  const double R = z * fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, Lp7, Lp6), Lp5), Lp4), Lp3), Lp2), Lp1);
-  const double dk = (double)k;
-  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + (dk * ln2_lo + c))) - f);
-}
-
-__device__ __forceinline__ double recip0(double v) {
-  // sparse_plus.py:16-22 — 1/v with inf -> 0
-  double r = 1.0 / v;
-  return isinf(r) ? 0.0 : r;
-}
+#include "tsem_device.h"
 
 template <int W>
 __device__ __forceinline__ double sg_sum(double v) {
@@ -116,9 +80,6 @@ __device__ __forceinline__ double block_sum(double v, double* scratch /* >= 16 d
   return t;
 }
 
-__device__ __forceinline__ void lds_add(double* p, double v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 // ============================================================================
 // synthetic generator (bit-exact twin of telescope_amd/synthetic.py)
@@ -1901,39 +1862,25 @@ static int ensure_device(tsem_ctx* h) {
   return TSEM_OK;
 }
 
+// The fused kernel's instantiations (team size x mode x entry format x geometry: ~200 kernels, most of the library's build time)
+// live in six translation units compiled in parallel (tsem_fz_p1.hip ... tsem_fz_p78.hip, tsem_fused_inst.h); each exports one
+// look-up function.  The host launches through the pointer.
 typedef void (*fz_fn)(FusedArgs);
-template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
-  if (mode >= 2) {                                         // exact (binned) column sums: needs the score table in LDS (formats 1, 2)
-#ifdef TSEM_NO_REPRO
-    return nullptr;
-#else
-    if (mode == 3) return fmt == 1 ? k_em_fused<P, 3, 1, GEO> : nullptr;   // both pieces in one pass: score codes only
-    if (fmt == 1) return k_em_fused<P, 2, 1, GEO>;
-    if (fmt == 2) return k_em_fused<P, 2, 2, GEO>;
-    return nullptr;
-#endif
-  }
-  if (fmt == 1) return mode ? k_em_fused<P, 1, 1, GEO> : k_em_fused<P, 0, 1, GEO>;
-  if (fmt == 2) return mode ? k_em_fused<P, 1, 2, GEO> : k_em_fused<P, 0, 2, GEO>;
-  return mode ? k_em_fused<P, 1, 0, GEO> : k_em_fused<P, 0, 0, GEO>;
-}
-template <int P> static fz_fn fz_pick(int mode, int fmt, int geo) {
-  if constexpr (P > 4) return geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 1>(mode, fmt);   // teams of 5-8: 384 or 768 row slots
-  else return geo == 3 ? fz_pick2<P, 3>(mode, fmt) : (geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 0>(mode, fmt));
-}
+fz_fn tsem_fz_kernel_p1(int P, int mode, int fmt, int geo);
+fz_fn tsem_fz_kernel_p2(int P, int mode, int fmt, int geo);
+fz_fn tsem_fz_kernel_p3(int P, int mode, int fmt, int geo);
+fz_fn tsem_fz_kernel_p4(int P, int mode, int fmt, int geo);
+fz_fn tsem_fz_kernel_p56(int P, int mode, int fmt, int geo);
+fz_fn tsem_fz_kernel_p78(int P, int mode, int fmt, int geo);
 static int fz_fmt(const tsem_ctx* h) { return h->fmt_code ? 1 : (h->fmt_wcode ? 2 : 0); }
 static fz_fn fz_kernel(int P, int mode, int fmt, int geo) {
-#ifdef TSEM_FAST_BUILD                                     // kernel experiments (tools/ab.sh): teams of 4 only, 1/8 of the build time
-  return P == 4 ? fz_pick<4>(mode, fmt, geo) : nullptr;
-#else
   switch (P) {
-    case 1: return fz_pick<1>(mode, fmt, geo); case 2: return fz_pick<2>(mode, fmt, geo);
-    case 3: return fz_pick<3>(mode, fmt, geo); case 4: return fz_pick<4>(mode, fmt, geo);
-    case 5: return fz_pick<5>(mode, fmt, geo); case 6: return fz_pick<6>(mode, fmt, geo);
-    case 7: return fz_pick<7>(mode, fmt, geo); case 8: return fz_pick<8>(mode, fmt, geo);
+    case 1: return tsem_fz_kernel_p1(P, mode, fmt, geo); case 2: return tsem_fz_kernel_p2(P, mode, fmt, geo);
+    case 3: return tsem_fz_kernel_p3(P, mode, fmt, geo); case 4: return tsem_fz_kernel_p4(P, mode, fmt, geo);
+    case 5: case 6: return tsem_fz_kernel_p56(P, mode, fmt, geo);
+    case 7: case 8: return tsem_fz_kernel_p78(P, mode, fmt, geo);
     default: return nullptr;
   }
-#endif
 }
 
 // code16 entry format: only with the fused kernel, and only while the score table is small enough to

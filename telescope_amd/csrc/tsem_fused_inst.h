@@ -1,0 +1,27 @@
+// Instantiation of the fused kernel for the team sizes one translation unit is responsible for (included by tsem_fz_*.hip only).
+#pragma once
+#include <cstdint>
+#include "tsem_common.h"
+#include "tsem_device.h"
+#include "tsem_fused.h"
+
+typedef void (*fz_fn)(FusedArgs);
+template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
+  if (mode >= 2) {                                         // exact (binned) column sums: needs the score table in LDS (formats 1, 2)
+#ifdef TSEM_NO_REPRO
+    return nullptr;
+#else
+    if (mode == 3) return fmt == 1 ? k_em_fused<P, 3, 1, GEO> : nullptr;   // both pieces in one pass: score codes only
+    if (fmt == 1) return k_em_fused<P, 2, 1, GEO>;
+    if (fmt == 2) return k_em_fused<P, 2, 2, GEO>;
+    return nullptr;
+#endif
+  }
+  if (fmt == 1) return mode ? k_em_fused<P, 1, 1, GEO> : k_em_fused<P, 0, 1, GEO>;
+  if (fmt == 2) return mode ? k_em_fused<P, 1, 2, GEO> : k_em_fused<P, 0, 2, GEO>;
+  return mode ? k_em_fused<P, 1, 0, GEO> : k_em_fused<P, 0, 0, GEO>;
+}
+template <int P> static fz_fn fz_pick(int mode, int fmt, int geo) {
+  if constexpr (P > 4) return geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 1>(mode, fmt);   // teams of 5-8: 384 or 768 row slots
+  else return geo == 3 ? fz_pick2<P, 3>(mode, fmt) : (geo == 2 ? fz_pick2<P, 2>(mode, fmt) : fz_pick2<P, 0>(mode, fmt));
+}
