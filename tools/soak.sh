@@ -10,3 +10,7 @@ run 5000 --value-format auto --nnz-row 10
 run 5000 --value-format auto --nnz-row 20
 run 3000 --value-format auto --rows 20000000 --cols 50000 --nnz-row 100
 run 8000 --value-format auto --rows 6250000
+# teams of 7-8 with the 768-slot geometry (end of round 3)
+run 4000 --value-format auto --rows 20000000 --cols 50000 --nnz-row 20
+run 4000 --value-format auto --rows 20000000 --cols 50000 --nnz-row 40
+run 3000 --value-format f64 --rows 20000000 --cols 45000 --nnz-row 30
