@@ -6,6 +6,7 @@ host.
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -86,10 +87,13 @@ def lib():
             'g.build()"`. There is no CPU fallback.' % LIB_PATH)
     # torch ships its own libamdhip64; if it is going to be used in this process (multi-GPU
     # plumbing), it must be loaded BEFORE ours so both share one HIP runtime.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # A single-process command-line run never touches torch: TSEM_NO_TORCH=1 (set by telescope_amd/cli.py when it is not a rank
+    # of a torch.distributed launch) saves the 1.5-2 s of `import torch` there.
+    if 'torch' in sys.modules or os.environ.get('TSEM_NO_TORCH', '0') != '1':
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     L.tsem_create.argtypes = [C.POINTER(vp), C.c_int]

@@ -135,6 +135,7 @@ def build_model(raw_scores, opts):
     from .likelihood import TelescopeLikelihood
     eo = {'reproducible': 1} if opts.reproducible else {}
     if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        os.environ.setdefault('TSEM_NO_TORCH', '1')            # (a single-process run needs no torch: its import is most of a small run)
         return TelescopeLikelihood(raw_scores, opts, device=opts.device, engine_options=eo or None), None
     from .distributed import init_from_env, shard_bounds
     comm = init_from_env()
