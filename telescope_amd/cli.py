@@ -145,7 +145,7 @@ def build_model(raw_scores, opts):
         lg.getLogger().setLevel(max(lg.getLogger().level, lg.WARNING))      # one copy of the progress lines
     lg.info('Row-sharded over %d ranks (%s); this rank: fragments %d..%d' % (comm.world, comm.describe(), r0, r1))
     eo['row_offset'] = r0
-    if os.environ.get('TSEM_ONE_DEVICE', '0') == '1':
+    if os.environ.get('TSEM_ONE_DEVICE', '0') == '1' and not opts.reproducible:   # (the reproducible mode has only the fused kernel)
         # dry run of several ranks on ONE GPU: the persistent fused kernel needs all its workgroups resident at once, which two
         # processes sharing a device cannot promise each other (the hand-off watchdog would catch it and fall back): start there
         eo['em_kernel'] = 1

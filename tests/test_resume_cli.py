@@ -76,8 +76,8 @@ def test_resume_reproducible_writes_the_same_bytes_twice(gpu_device, tmp_path, m
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['choose', 'conf'])
-def test_resume_row_sharded_over_two_rank_processes(gpu_device, tmp_path, mode):
+@pytest.mark.parametrize('mode,extra', [('choose', []), ('conf', [])])
+def test_resume_row_sharded_over_two_rank_processes(gpu_device, tmp_path, mode, extra):
     """`python -m torch.distributed.run --nproc-per-node 2 -m telescope_amd resume ...`: every rank loads the checkpoint, takes
     its share of the fragments, the sums are all-reduced, rank 0 draws the picks of `choose` and writes the reference's
     reports.  On the one-GPU box the two ranks share device 0 (the dry-run transport of telescope_amd.distributed: gloo, the
@@ -87,7 +87,7 @@ def test_resume_row_sharded_over_two_rank_processes(gpu_device, tmp_path, mode):
     env = dict(os.environ, TSEM_ONE_DEVICE='1', TSEM_GLOO_HOST_STAGED='1', TSEM_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), '-m', 'telescope_amd', 'resume', os.path.join(GOLD, 'resume_checkpoint.npz'),
-           '--outdir', str(tmp_path), '--exp_tag', 'run', '--reassign_mode', mode]
+           '--outdir', str(tmp_path), '--exp_tag', 'run', '--reassign_mode', mode] + extra
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stderr.count('EM converged after 16 iterations.') == 1            # one copy of the progress lines
