@@ -154,3 +154,19 @@ def test_shard_bounds():
     cuts = shard_bounds(100, 2, indptr=indptr)
     assert cuts[0] == 0 and cuts[-1] == 100 and 2 <= cuts[1] <= 4      # balanced by nnz, not rows
     assert shard_bounds(3, 8)[-1] == 3 and len(shard_bounds(3, 8)) == 9  # more ranks than rows
+
+
+def test_single_process_cli_runs_do_not_import_torch():
+    """`import torch` is most of the wall clock of a small `telescope resume`; the loader skips it when the command line is not a
+    rank of a torch.distributed launch (TSEM_NO_TORCH=1, telescope_amd/cli.py) and keeps it otherwise (torch's HIP runtime must be
+    the one both share when torch is going to be used)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); from telescope_amd import _lib; _lib.lib(); "
+            "print('torch' in sys.modules)" % root)
+    for env_val, want in (('1', 'False'), ('0', 'True')):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, TSEM_NO_TORCH=env_val))
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert r.stdout.strip().splitlines()[-1] == want, (env_val, r.stdout)
