@@ -1857,6 +1857,19 @@ static int bin_reset(tsem_ctx* h) {
 
 static inline int cdiv64(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// TSEM_TRACE=1: host wall clock of the set-up phases on stderr (each lap synchronises the stream; a diagnostic, not a product path)
+struct PhaseTimer {
+  bool on; hipStream_t s; std::chrono::steady_clock::time_point t;
+  explicit PhaseTimer(hipStream_t st) : on(getenv("TSEM_TRACE") != nullptr), s(st), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* name) {
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tsem] %-34s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
 static int ensure_device(tsem_ctx* h) {
   TSEM_HIP(hipSetDevice(h->device));
   return TSEM_OK;
@@ -2404,6 +2417,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
 // layout: column partition by popularity, blocked COO of ambiguous rows
 // ---------------------------------------------------------------------------
 static int build_layout(tsem_ctx* h) {
+  PhaseTimer pt(h->stream);
   const int K = h->K;
   const int64_t na = h->N_amb;
   free_layout(h);
@@ -2448,6 +2462,7 @@ static int build_layout(tsem_ctx* h) {
     col_of_pc[p * Kp + cursor[p]] = j;                     // the first slot owns the column; the others stay -1
     cursor[p] += 1 << lg;
   }
+  pt.lap("layout: column map (host)");
   TSEM_ALLOC(h->d_colmap, K);
   TSEM_ALLOC(h->d_col_of_pc, h->Kpad);
   TSEM_HIP(hipMemcpy(h->d_colmap, colmap.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice));
@@ -2462,6 +2477,7 @@ static int build_layout(tsem_ctx* h) {
     TSEM_HIP(hipMemcpy(h->d_col_of_id, col_of_id.data(), sizeof(int32_t) * h->Kpad, hipMemcpyHostToDevice));
     TSEM_ALLOC(h->d_rid16, h->nnz + TS_ENTRY_PAD);
   }
+  pt.lap("layout: maps to the device, rid16 alloc");
   // 3. row blocks.  Two-pass layout: R rows each.  Fused layout: as many consecutive rows as the
   //    register tile takes (no part may exceed FZ_CAP entries, at most R rows) — rows per block vary,
   //    every block still owns R row SLOTS (holes at the end), so all kernels keep b*R+lr indexing.
@@ -2547,6 +2563,7 @@ static int build_layout(tsem_ctx* h) {
     else TSEM_HIP(hipMemsetAsync(h->d_amb_wcode, 0, sizeof(uint16_t) * h->N_amb_pad, h->stream));
     TSEM_HIP(hipGetLastError());
   }
+  pt.lap("layout: part counts, blocks, slots");
   // 4. sub-block sizes -> offsets
   std::vector<int64_t> sb(nb * P + 1, 0);
   if (nb) {
@@ -2592,6 +2609,7 @@ static int build_layout(tsem_ctx* h) {
   if (h->opt_reproducible && !(h->use_fused && (h->fmt_code || h->fmt_wcode)))
     TSEM_FAIL(TSEM_ERR_ARG, "reproducible mode needs the fused kernel (at most 8 column parts, every row within the register tile) and a score "
                             "table of at most 2048 entries");
+  pt.lap("layout: sub-block offsets");
   TSEM_ALLOC(h->d_prc, off);
   TSEM_HIP(hipMemsetAsync(h->d_prc, 0, sizeof(uint32_t) * std::max<int64_t>(1, off), h->stream));
   if (h->fmt_code) {
@@ -2601,6 +2619,7 @@ static int build_layout(tsem_ctx* h) {
     TSEM_ALLOC(h->d_pval, off);
     TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
   }
+  pt.lap("layout: entry buffers (alloc + zero)");
   // Row order (row sums reduced in registers, a tenth of the LDS atomics) for every fused layout.  Score codes: 40
   // entries per row at P = 4 4.44 -> 3.59 ms, 20 per row 2.30 -> 1.92, 10 per row 1.65 -> 1.40.  fp64 entries
   // were indifferent to it while the exchange wave stalled behind the memory pipe (round 1: 4.62 against 4.57 ms);
@@ -2657,6 +2676,7 @@ static int build_layout(tsem_ctx* h) {
   TSEM_HIP(hipStreamSynchronize(h->stream));
   (void)hipFree(d_bs);
   if (d_pc) (void)hipFree(d_pc);
+  pt.lap("layout: fill + conflict-aware order");
   if (!h->use_fused) TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad);   // partial row sums of the two-pass kernels
   // launch geometry
   const size_t lds1 = (size_t)(Kp + R) * 8, lds2 = (size_t)(2 * Kp + R) * 8;
@@ -2697,6 +2717,7 @@ static int build_layout(tsem_ctx* h) {
   TSEM_HIP(hipFuncSetAttribute((const void*)k_phase2_em<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
   TSEM_HIP(hipFuncSetAttribute((const void*)k_phase2_lnl<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
   TSEM_HIP(hipStreamSynchronize(h->stream));
+  pt.lap("layout: launch buffers, attributes");
   return TSEM_OK;
 }
 
@@ -2704,6 +2725,7 @@ int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, cons
                    const uint64_t* col_hash, double pi_prior, double theta_prior) {
   if (!h || !h->have_rowstats || !stats3 || !pisum0 || !col_count || !col_hash) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
+  PhaseTimer pt0(h->stream);
   const int K = h->K;
   h->col_count.assign(col_count, col_count + K);
   {  // exact twin columns -> representative = smallest column index of the class
@@ -2737,7 +2759,9 @@ int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, cons
     }
     TSEM_HIP(hipMemcpy(h->d_pisum0, ps.data(), sizeof(double) * K, hipMemcpyHostToDevice));
   }
+  pt0.lap("set_model: twins, pisum0 (host)");
   if (int rc = build_layout(h)) return rc;
+  pt0.lap("set_model: build_layout total");
   TSEM_ALLOC(h->d_pi, K); TSEM_ALLOC(h->d_theta, K); TSEM_ALLOC(h->d_pi_prev, K); TSEM_ALLOC(h->d_theta_prev, K);
   TSEM_ALLOC(h->d_tmp_pi, K); TSEM_ALLOC(h->d_tmp_theta, K);
   TSEM_ALLOC(h->d_ctab, h->Kpad); TSEM_ALLOC(h->d_ctab_prev, h->Kpad);
