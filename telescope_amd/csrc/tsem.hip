@@ -2729,13 +2729,16 @@ int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, cons
   const int K = h->K;
   h->col_count.assign(col_count, col_count + K);
   {  // exact twin columns -> representative = smallest column index of the class
-    std::vector<int> ord(K);
-    std::iota(ord.begin(), ord.end(), 0);
-    std::sort(ord.begin(), ord.end(), [&](int a, int b) {
-      if (col_count[a] != col_count[b]) return col_count[a] < col_count[b];
-      if (col_hash[a] != col_hash[b]) return col_hash[a] < col_hash[b];
-      return a < b;
+    struct Sig { uint64_t count, hash; int col; };            // (sorted in place)
+    std::vector<Sig> sg((size_t)K);
+    for (int j = 0; j < K; ++j) sg[j] = Sig{col_count[j], col_hash[j], j};
+    std::sort(sg.begin(), sg.end(), [](const Sig& a, const Sig& b) {
+      if (a.count != b.count) return a.count < b.count;
+      if (a.hash != b.hash) return a.hash < b.hash;
+      return a.col < b.col;
     });
+    std::vector<int> ord(K);
+    for (int j = 0; j < K; ++j) ord[j] = sg[j].col;
     std::vector<int32_t> rep(K);
     h->n_twin_cols = 0;
     for (int i = 0; i < K;) {
