@@ -15,7 +15,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 # TSEM_LIB: kernel experiments (A/B builds of the same source); the product always uses the in-tree build
 LIB_PATH = os.environ.get('TSEM_LIB') or os.path.join(HERE, 'libtelescope_em.so')
-SRC = os.path.join(HERE, 'csrc', 'tsem.hip')
 
 OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_TIMEOUT = 0, -1, -2, -3, -4
 RA_CODE = {'exclude': 0, 'choose': 1, 'average': 2, 'conf': 3, 'unique': 4, 'all': 5}
@@ -27,17 +26,19 @@ class EngineError(RuntimeError):
     code = 0
 
 
+# host / ABI, set-up, EM support, report / row passes, collectives, CSR primitives (telescope_amd/csrc/tsem_internal.h)
+LIB_UNITS = ('tsem_host', 'tsem_setup', 'tsem_em', 'tsem_report', 'tsem_comm', 'tsem_csr')
 FZ_UNITS = ('tsem_fz_p1', 'tsem_fz_p2', 'tsem_fz_p3', 'tsem_fz_p4', 'tsem_fz_p56', 'tsem_fz_p78')
 
 
 def build_library(force=False, verbose=False, extra_flags=(), out=None):
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU).  Seven translation units — tsem.hip and the
-    six that instantiate the fused kernel for one or two team sizes each (most of the build time) — are compiled in parallel and
-    linked into one shared object."""
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU).  Twelve translation units — the six of
+    LIB_UNITS and the six that instantiate the fused kernel for one or two team sizes each (most of the build time) — are compiled
+    in parallel and linked into one shared object."""
     from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(HERE, 'csrc')
-    units = [SRC] + [os.path.join(csrc, u + '.hip') for u in FZ_UNITS]
-    deps = units + [os.path.join(csrc, h) for h in ('tsem_common.h', 'tsem_fused.h', 'tsem_device.h', 'tsem_fused_inst.h')] + \
+    units = [os.path.join(csrc, u + '.hip') for u in LIB_UNITS + FZ_UNITS]
+    deps = units + [os.path.join(csrc, h) for h in ('tsem_common.h', 'tsem_internal.h', 'tsem_fused.h', 'tsem_device.h', 'tsem_fused_inst.h')] + \
         [os.path.join(ROOT, 'include', 'telescope_em.h')]
     target = out or LIB_PATH
     if (not force and os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)):

@@ -1,0 +1,891 @@
+// libtelescope_em.so, EM unit: one EM iteration = fused pass (tsem_fused.h; or the two-pass kernels) -> k_colreduce ->
+// [all-reduce] -> k_update (model.py:718-742, 781), the log-likelihood passes (model.py:744-760), option "reproducible",
+// the fp32 diagnostic pass, and the chunked device-side loop of em() (model.py:762-806).
+#include "tsem_internal.h"
+
+// ============================================================================
+// EM hot loop — two-pass form (phase 1: partial row sums; phase 2: scatter)
+// ============================================================================
+// WG = (part p, stripe g).  LDS: ctab[Kp] | y[R]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_phase1(int P, int Kp, int R, int64_t b0, int64_t nb, int G, int64_t N_amb_pad,
+    const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
+    const double* __restrict__ ctab, double* __restrict__ ypart, const uint32_t* __restrict__ ctl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the run has stopped (tsem_em_chunk)
+  double* c = reinterpret_cast<double*>(smem);
+  double* y = c + Kp;
+  const int p = blockIdx.x % P, g = blockIdx.x / P;
+  for (int t = threadIdx.x; t < Kp; t += NT) c[t] = ctab[p * Kp + t];
+  for (int t = threadIdx.x; t < R; t += NT) y[t] = 0.0;
+  __syncthreads();
+  for (int64_t b = b0 + g; b < nb; b += G) {
+    const int64_t q0 = sb_off[b * P + p] >> 2, q1 = sb_off[b * P + p + 1] >> 2;
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += NT) {
+      uint4 rc = reinterpret_cast<const uint4*>(prc)[q];
+      double2 v0 = reinterpret_cast<const double2*>(pval)[2 * q];
+      double2 v1 = reinterpret_cast<const double2*>(pval)[2 * q + 1];
+      lds_add(&y[rc.x >> 16], v0.x * c[rc.x & 0xFFFF]);
+      lds_add(&y[rc.y >> 16], v0.y * c[rc.y & 0xFFFF]);
+      lds_add(&y[rc.z >> 16], v1.x * c[rc.z & 0xFFFF]);
+      lds_add(&y[rc.w >> 16], v1.y * c[rc.w & 0xFFFF]);
+    }
+    __syncthreads();
+    double* out = ypart + (int64_t)p * N_amb_pad + b * R;
+    for (int t = threadIdx.x; t < R; t += NT) { out[t] = y[t]; y[t] = 0.0; }
+    __syncthreads();
+  }
+}
+
+// LDS: ctab[Kp] | acc[Kp] | s[R].  thetasum partials -> partial[g][p*Kp + l]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_phase2_em(int P, int Kp, int R, int64_t b0, int64_t nb, int G, int accumulate, int64_t N_amb_pad,
+    const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
+    const double* __restrict__ ctab, const double* __restrict__ ypart, const uint16_t* __restrict__ wcode,
+    const double* __restrict__ lut, double* __restrict__ partial, const uint32_t* __restrict__ ctl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  double* c = reinterpret_cast<double*>(smem);
+  double* acc = c + Kp;
+  double* s = acc + Kp;
+  const int p = blockIdx.x % P, g = blockIdx.x / P;
+  {
+    const double* prev = partial + (int64_t)g * (P * Kp) + p * Kp;
+    for (int t = threadIdx.x; t < Kp; t += NT) { c[t] = ctab[p * Kp + t]; acc[t] = accumulate ? prev[t] : 0.0; }
+  }
+  for (int64_t b = b0 + g; b < nb; b += G) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < R; t += NT) {
+      int64_t a = b * R + t;
+      double ys = 0.0;
+      for (int pp = 0; pp < P; ++pp) ys += ypart[(int64_t)pp * N_amb_pad + a];
+      // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730)
+      s[t] = recip0(ys) * lut[wcode[a]];
+    }
+    __syncthreads();
+    const int64_t q0 = sb_off[b * P + p] >> 2, q1 = sb_off[b * P + p + 1] >> 2;
+    for (int64_t q = q0 + threadIdx.x; q < q1; q += NT) {
+      uint4 rc = reinterpret_cast<const uint4*>(prc)[q];
+      double2 v0 = reinterpret_cast<const double2*>(pval)[2 * q];
+      double2 v1 = reinterpret_cast<const double2*>(pval)[2 * q + 1];
+      lds_add(&acc[rc.x & 0xFFFF], (v0.x * c[rc.x & 0xFFFF]) * s[rc.x >> 16]);
+      lds_add(&acc[rc.y & 0xFFFF], (v0.y * c[rc.y & 0xFFFF]) * s[rc.y >> 16]);
+      lds_add(&acc[rc.z & 0xFFFF], (v1.x * c[rc.z & 0xFFFF]) * s[rc.z >> 16]);
+      lds_add(&acc[rc.w & 0xFFFF], (v1.y * c[rc.w & 0xFFFF]) * s[rc.w >> 16]);
+    }
+  }
+  __syncthreads();
+  double* out = partial + (int64_t)g * (P * Kp) + p * Kp;
+  for (int t = threadIdx.x; t < Kp; t += NT) out[t] = acc[t];
+}
+
+// lnl over ambiguous rows: sum z(prev) * log1p(Q * c_cur)   (model.py:755-758)
+// LDS: c_old[Kp] | c_new[Kp] | r[R]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_phase2_lnl(int P, int Kp, int R, int64_t nb, int G, int64_t N_amb_pad,
+    const int64_t* __restrict__ sb_off, const double* __restrict__ pval, const uint32_t* __restrict__ prc,
+    const double* __restrict__ ctab_old, const double* __restrict__ ctab_new, const double* __restrict__ ypart,
+    double* __restrict__ lnl_part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double scratch[16];
+  double* co = reinterpret_cast<double*>(smem);
+  double* cn = co + Kp;
+  double* r = cn + Kp;
+  const int p = blockIdx.x % P, g = blockIdx.x / P;
+  for (int t = threadIdx.x; t < Kp; t += NT) { co[t] = ctab_old[p * Kp + t]; cn[t] = ctab_new[p * Kp + t]; }
+  double acc = 0.0;
+  for (int64_t b = g; b < nb; b += G) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < R; t += NT) {
+      int64_t a = b * R + t;
+      double ys = 0.0;
+      for (int pp = 0; pp < P; ++pp) ys += ypart[(int64_t)pp * N_amb_pad + a];
+      r[t] = recip0(ys);
+    }
+    __syncthreads();
+    const int64_t e0 = sb_off[b * P + p], e1 = sb_off[b * P + p + 1];
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += NT) {
+      uint32_t rc = prc[e];
+      double v = pval[e];
+      double z = (v * co[rc & 0xFFFF]) * r[rc >> 16];
+      if (z != 0.0) acc += z * ts_log1p_pos(v * cn[rc & 0xFFFF]);
+    }
+  }
+  double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) lnl_part[blockIdx.x] = t;
+}
+
+// lnl over unique rows: z = n * recip0(n), n = Q*pi_prev; inner = Q*pi_cur
+__global__ __launch_bounds__(256) void k_lnl_unique(int64_t N_uni, const int32_t* __restrict__ ucol,
+    const uint16_t* __restrict__ ucode, const double* __restrict__ lut, const double* __restrict__ pi_old,
+    const double* __restrict__ pi_new, double* __restrict__ lnl_part) {
+  __shared__ double scratch[16];
+  double acc = 0.0;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < N_uni; u += (int64_t)gridDim.x * blockDim.x) {
+    int col = ucol[u];
+    double q = lut[ucode[u]];
+    double n = q * pi_old[col];
+    if (n != 0.0) {
+      double z = n * recip0(n);
+      if (z != 0.0) acc += z * ts_log1p_pos(q * pi_new[col]);
+    }
+  }
+  double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) lnl_part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ a, int na, const double* __restrict__ b,
+                                                   int nbb, double* __restrict__ out) {
+  __shared__ double scratch[16];
+  double acc = 0.0;
+  for (int t = threadIdx.x; t < na; t += blockDim.x) acc += a[t];
+  for (int t = threadIdx.x; t < nbb; t += blockDim.x) acc += b[t];
+  double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// red[col] = sum_g partial[g][pc]   (fixed order -> deterministic given partials).  A block handles 64
+// slots x 4 interleaved slices of the team axis, so the strided reads of one slot overlap instead of
+// forming a chain of G dependent loads.  `sync` (fused kernel): only the teams that formed wrote
+// their slice — G = sum over XCDs of floor(tickets / P).
+// red[K] = 1 when this rank's fused pass raised its watchdog error word (the flag is summed with the column
+// sums by the all-reduce, so every rank's update kernel sees that SOME rank failed), red[K+1] = 0.
+__global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double* __restrict__ partial,
+                            const int32_t* __restrict__ col_of_pc, const uint32_t* __restrict__ colmap,
+                            double* __restrict__ red, int K, const uint32_t* __restrict__ sync, int P,
+                            const uint32_t* __restrict__ ctl, unsigned long long* __restrict__ fz_xchg, int64_t fz_xchg_n) {
+  // the fused kernel's exchange ring must be zero at its next launch: cleared here, by the ~950 blocks of the
+  // kernel that follows every fused pass (no launch of its own, no fence: the next fused launch is a kernel boundary away)
+  if (fz_xchg) {
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    u64x2_t* const x2 = reinterpret_cast<u64x2_t*>(fz_xchg);                  // (hipMalloc alignment; the ring holds an even number of words)
+    const u64x2_t zz = {0ull, 0ull};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < fz_xchg_n / 2; i += (int64_t)gridDim.x * blockDim.x)
+      x2[i] = zz;
+  }
+  // 32 slots x 8 interleaved slices of the team axis per block: 8 independent loads per thread in flight (the
+  // kernel is latency-bound: 64 teams x 30k slots = 15 MB; 13.6 us with 4 slices of 16 loads, r01 profile)
+  constexpr int NS = 8, NC = 32;
+  __shared__ double part[NS][NC];
+  if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the run has stopped
+  if (sync) {
+    int t = 0;
+    for (int x = 0; x < 8; ++x) t += (int)(sync[x] / (uint32_t)P);
+    G = min(G, t);
+  }
+  const int pcl = threadIdx.x % NC, slice = threadIdx.x / NC;
+  const int pc = blockIdx.x * NC + pcl;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { red[K] = (sync && sync[9]) ? 1.0 : 0.0; red[K + 1] = 0.0; }
+  const int col = pc < Kpad ? col_of_pc[pc] : -1;        // -1: padding, or a secondary slot of a split column
+  double s = 0.0;
+  if (col >= 0) {
+    const int copies = 1 << ((colmap[col] >> 13) & 7u);
+    if (copies == 1) {
+#pragma unroll 8
+      for (int g = slice; g < G; g += NS) s += partial[(int64_t)g * Kpad + pc];
+    } else {
+      for (int g = slice; g < G; g += NS)
+        for (int c = 0; c < copies; ++c) s += partial[(int64_t)g * Kpad + pc + c];
+    }
+  }
+  part[slice][pcl] = s;
+  __syncthreads();
+  if (slice == 0 && col >= 0)                            // fixed order -> deterministic given the partials
+    red[col] = ((part[0][pcl] + part[1][pcl]) + (part[2][pcl] + part[3][pcl])) + ((part[4][pcl] + part[5][pcl]) + (part[6][pcl] + part[7][pcl]));
+}
+
+__global__ void k_keep_err(const uint32_t* sync, uint32_t* errlog) { errlog[0] |= sync[9]; errlog[1] = sync[10]; }
+
+// Loop control of tsem_em_chunk, evaluated on the device so that the host need not synchronise every
+// iteration: ctl[0] = stop flag (0 run, 1 converged, 2 a rank's EM pass timed out), ctl[1] = iterations
+// committed since the host last cleared it.
+struct UpdCtl {
+  uint32_t* ctl;          // null: legacy stepwise use (always commit unless the error flag is up)
+  double eps;             // converged = diff_est < eps (model.py:792) unless use_lnl
+  int use_lnl;            // convergence is decided by k_lnl_check instead (model.py:785-789)
+  double* pi_first;       // non-null: also store the new parameters here (pi_init / theta_init, model.py:776-778)
+  double* theta_first;
+};
+
+// M-step closed forms (model.py:733-740) + per-block partials of diff_est (model.py:781)
+__global__ __launch_bounds__(256) void k_update(UpdCtl C, int K, const double* __restrict__ red,
+    const double* __restrict__ pisum0, double theta_pw, double theta_den, double pi_pw, double pi_den,
+    double* __restrict__ pi, double* __restrict__ theta, double* __restrict__ pi_prev,
+    double* __restrict__ theta_prev, const uint32_t* __restrict__ colmap, int Kp,
+    double* __restrict__ ctab, double* __restrict__ ctab_prev, const int32_t* __restrict__ twin_rep,
+    double* __restrict__ diff_part, double* __restrict__ diff_out, uint32_t* __restrict__ done,
+    uint32_t* __restrict__ fz_sync, uint32_t* __restrict__ fz_errlog, unsigned long long* __restrict__ fz_xchg, int64_t fz_xchg_n) {
+  __shared__ double scratch[16];
+  __shared__ bool last;
+  // the fused kernel's sync words and exchange ring must be zero at its next launch: do it here (this
+  // kernel runs once per EM pass, after the pass) instead of three memsets in front of every launch
+  if (fz_sync) {
+    (void)fz_xchg; (void)fz_xchg_n;                        // (the ring itself is cleared by k_colreduce)
+    if (blockIdx.x == 0 && threadIdx.x < 16) {            // FZ_SYNC_WORDS
+      if (threadIdx.x == 9) atomicOr(&fz_errlog[0], fz_sync[9]);          // keep the error word / miss counter for the host
+      if (threadIdx.x == 10) fz_errlog[1] = fz_sync[10];
+      fz_sync[threadIdx.x] = 0u;
+    }
+  }
+  if (C.ctl && __hip_atomic_load(C.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the run has stopped: nothing to commit
+  // some rank's fused pass timed out (flag summed by the all-reduce): the column sums are incomplete, so NO
+  // rank commits; the last block raises stop = 2 and the host redoes the iteration (tsem_em_chunk)
+  const bool failed = red[K] > 0.0;
+  double d = 0.0;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K && !failed; j += gridDim.x * blockDim.x) {
+    // exact twin columns share one accumulation (see k_colsig) as long as their
+    // sums agree to rounding, i.e. their parameters are still symmetric
+    const int jr = twin_rep[j];
+    double ts = red[j];
+    if (jr != j) {
+      double tr = red[jr];
+      if (fabs(ts - tr) <= 1e-12 * fmax(fabs(ts), fabs(tr))) ts = tr;
+    }
+    double th = (ts + theta_pw) / theta_den;
+    double ps = pisum0[j] + ts;
+    double ph = (ps + pi_pw) / pi_den;
+    double po = pi[j], to = theta[j];
+    d += fabs(ph - po);
+    pi_prev[j] = po; theta_prev[j] = to;
+    pi[j] = ph; theta[j] = th;
+    if (C.pi_first) { C.pi_first[j] = ph; C.theta_first[j] = th; }
+    const uint32_t cm = colmap[j];
+    const int pc = (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu), copies = 1 << ((cm >> 13) & 7u);
+    const double cold = ctab[pc], cnew = ph * th;
+    for (int c = 0; c < copies; ++c) { ctab_prev[pc + c] = cold; ctab[pc + c] = cnew; }
+  }
+  double t = block_sum(d, scratch);
+  if (threadIdx.x == 0) {
+    diff_part[blockIdx.x] = t;
+    __threadfence();
+    last = atomicAdd(done, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last) {                                              // fixed order -> deterministic
+    __threadfence();
+    double v = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) v += __hip_atomic_load(&diff_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double tt = block_sum(v, scratch);
+    if (threadIdx.x == 0) {
+      *done = 0u;
+      if (failed) {
+        if (C.ctl) C.ctl[0] = 2u;
+        *diff_out = -1.0;                                  // (legacy stepwise hosts: negative = not committed)
+      } else {
+        *diff_out = tt;
+        if (C.ctl) {
+          C.ctl[1] += 1u;
+          if (!C.use_lnl && tt < C.eps) C.ctl[0] = 1u;     // model.py:792
+        }
+      }
+    }
+  }
+}
+
+// use_likelihood convergence test (model.py:785-789): lred[0] = all-reduced log-likelihood of the iteration just
+// committed, lred[1] > 0 when some rank's lnl pass timed out.
+__global__ void k_lnl_check(uint32_t* ctl, double* ctld, const double* __restrict__ lred, double eps,
+                            double* __restrict__ lnl_out) {
+  if (ctl[0]) return;
+  if (lred[1] > 0.0) { ctl[0] = 3u; return; }
+  const double l = lred[0];
+  *lnl_out = l;
+  if (fabs(l - ctld[0]) < eps) ctl[0] = 1u;
+  ctld[0] = l;
+}
+// lnl partial + error flag of this rank into the two lnl reduce slots
+__global__ void k_lnl_slots(const double* __restrict__ red_lnl, const uint32_t* __restrict__ sync, double* __restrict__ lred) {
+  lred[0] = *red_lnl;
+  lred[1] = (sync && sync[9]) ? 1.0 : 0.0;
+}
+
+static_assert(FZ_SYNC_WORDS == 16, "k_update clears 16 sync words");
+
+// ---- reduced-precision EM pass (BASELINE config 3: the fp32 leg of the tolerance sweep) -------------
+// A DIAGNOSTIC, not a product path: the E-step products, the row sums, the posteriors and the column sums are all
+// fp32.  Q = expm1(100 s / max) reaches 2.7e43 > FLT_MAX, so the score table is scaled by 2^-64
+// (exact) before rounding to fp32, and pi*theta by 1 / max_j(pi*theta) (z is invariant under both); products
+// that still underflow are lost — which is what the sweep is there to measure.  One 16-lane group per row of the
+// canonical CSR, fp32 global atomics for the column sums.
+constexpr int F32_SHIFT = 64;
+__global__ void k_cmax(int K, const double* __restrict__ pi, const double* __restrict__ theta, unsigned long long* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double v = j < K ? pi[j] * theta[j] : 0.0;
+  v = sg_max<64>(v);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(v));   // non-negative doubles order like integers
+}
+__global__ void k_make_c32(int K, const double* __restrict__ pi, const double* __restrict__ theta,
+                           const unsigned long long* __restrict__ cmax, float* __restrict__ c32) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  const double m = __longlong_as_double((long long)*cmax);
+  c32[j] = (float)((pi[j] * theta[j]) / (m > 0.0 ? m : 1.0));
+}
+__global__ void k_lut32(int n, const double* __restrict__ lut, float* __restrict__ lut32) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lut32[i] = (float)ldexp(lut[i], -F32_SHIFT);
+}
+__global__ __launch_bounds__(256) void k_em_rows_f32(int64_t N, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const uint16_t* __restrict__ raw, const float* __restrict__ lut32, const float* __restrict__ c32, float* __restrict__ colsums) {
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
+    const int64_t s = indptr[row], e = indptr[row + 1];
+    if (e - s < 2) continue;                               // unique rows feed pi through pisum0 only (model.py:699)
+    float y = 0.f, w = 0.f;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) { const float q = lut32[raw[k]]; y += q * c32[indices[k]]; w = fmaxf(w, q); }
+#pragma unroll
+    for (int o = RP_SUB / 2; o > 0; o >>= 1) { y += __shfl_xor(y, o, RP_SUB); w = fmaxf(w, __shfl_xor(w, o, RP_SUB)); }
+    float r = 1.f / y;
+    if (isinf(r)) r = 0.f;                                 // recip0, sparse_plus.py:16-22
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      const float v = ((lut32[raw[k]] * c32[indices[k]]) * r) * w;
+      if (v != 0.f) unsafeAtomicAdd(&colsums[indices[k]], v);
+    }
+  }
+}
+__global__ void k_red_from_f32(int K, const float* __restrict__ colsums, double* __restrict__ red) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < K) red[j] = ldexp((double)colsums[j], F32_SHIFT);
+  if (j == 0) { red[K] = 0.0; red[K + 1] = 0.0; }
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// EM pass / update / lnl
+// ---------------------------------------------------------------------------
+static int launch_phase1(tsem_ctx* h, const double* ctab, int64_t b0 = 0, int64_t b1 = -1, bool em = false) {
+  if (h->nb == 0) return TSEM_OK;
+  if (b1 < 0) b1 = h->nb;
+  const size_t lds1 = (size_t)(h->Kp + h->R) * 8;
+  k_phase1<512><<<h->G1 * h->P, 512, lds1, h->stream>>>(h->P, h->Kp, h->R, b0, b1, h->G1, h->N_amb_pad, h->d_sb_off,
+                                                        h->d_pval, h->d_prc, ctab, h->d_ypart, em ? h->d_ctl : nullptr);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+static int begin_timing(tsem_ctx* h, hipEvent_t** pair) {
+  *pair = nullptr;
+  // option "kernel_timing" = n: HIP events around every n-th EM pass (0 = never, default 1).  An event pair costs
+  // the stream several microseconds per iteration (profiles/r02_comm_overhead.txt): the Python host switches it
+  // off for em(), bench.py samples every 4th launch of the timed region.
+  if (h->opt_timing <= 0 || (h->em_launches % h->opt_timing) != 0) return TSEM_OK;
+  if (h->ev_used + 2 > 8192) return TSEM_OK;
+  while (h->ev.size() < h->ev_used + 2) {
+    hipEvent_t e;
+    TSEM_HIP(hipEventCreate(&e));
+    h->ev.push_back(e);
+  }
+  *pair = &h->ev[h->ev_used];
+  h->ev_used += 2;
+  h->em_timed += 1;
+  TSEM_HIP(hipEventRecord((*pair)[0], h->stream));
+  return TSEM_OK;
+}
+
+// One launch of the persistent fused kernel.  mode 0: EM pass (column sums of w*z into d_fpartial);
+// mode 1: log-likelihood of the ambiguous rows (one partial per workgroup into d_lnl_part).
+static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
+  if (!h->fz_clean) {                                      // (k_update leaves them zero after every EM pass)
+    if (h->fused_launched && h->d_fz_aux)                  // keep the error word of a launch nobody cleaned up after
+      k_keep_err<<<1, 1, 0, h->stream>>>(h->d_xflags, h->d_fz_aux + 2);
+    TSEM_HIP(hipMemsetAsync(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS, h->stream));
+    if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * FZ_XS * h->P * h->R, h->stream));
+  }
+  h->fz_clean = false;
+  if (mode == 1) TSEM_HIP(hipMemsetAsync(h->d_lnl_part, 0, sizeof(double) * (size_t)h->fz_grid, h->stream));   // teams that do not form write nothing
+  FusedArgs A;
+  A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
+  A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc;
+  const bool lnl = mode == 1;                               // mode 2 is an EM pass (exact column sums), not the lnl pass
+  A.ctab = lnl ? h->d_ctab_prev : h->d_ctab; A.ctab2 = h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = lnl ? 1 : 0;
+  A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg; A.sorted = h->sorted_layout ? 1 : 0;
+  A.sync = h->d_xflags;
+  A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.dbg = (int)h->opt_dbg;
+  A.ctl = h->d_ctl;
+  A.ebias = h->d_ebias; A.bin = bin; A.ovf = h->d_ovf; A.partial2 = h->d_fpartial2;
+
+  A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
+  const size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
+  if (lnl && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
+  fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h), h->geo);
+  if (!fn) TSEM_FAIL(TSEM_ERR_ARG, mode >= 2 ? "reproducible mode needs the fused kernel with a score table of at most 2048 entries"
+                                               : "fused kernel supports at most 8 column parts");
+  if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
+  fn<<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  h->fused_launched = true;
+  return TSEM_OK;
+}
+
+int tsem_rowpass_grid(tsem_ctx* h);
+// the fp32 diagnostic pass (option "em_precision" = 1): same outputs as tsem_em_pass, fp32 arithmetic
+static int em_pass_f32(tsem_ctx* h) {
+  const int K = h->K;
+  if (!h->d_c32) {
+    TSEM_ALLOC(h->d_c32, K); TSEM_ALLOC(h->d_cs32, K); TSEM_ALLOC(h->d_lut32, h->lut_len);
+    k_lut32<<<cdiv64(h->lut_len, 256), 256, 0, h->stream>>>(h->lut_len, h->d_lut, h->d_lut32);
+  }
+  unsigned long long* cmax = reinterpret_cast<unsigned long long*>(h->d_lnl_part + 12000);
+  TSEM_HIP(hipMemsetAsync(cmax, 0, 8, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_cs32, 0, sizeof(float) * K, h->stream));
+  k_cmax<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, cmax);
+  k_make_c32<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, cmax, h->d_c32);
+  if (h->N) k_em_rows_f32<<<tsem_rowpass_grid(h), 256, 0, h->stream>>>(h->N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut32, h->d_c32, h->d_cs32);
+  k_red_from_f32<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_cs32, h->d_red);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+// option "reproducible".  Every contribution to a column sum is cut into a high and a low piece on a per-slot grid (tsem_fused.h,
+// phase 2), one pass each; sums of such pieces are exact in fp64, so they do not depend on the order of the LDS atomics.  The grid
+// hangs on the slot's bound 2^E (ebias = E + 1023): pieces are multiples of 2^(E-30) and 2^(E-60).  All decisions below are functions
+// of exact sums, hence identical in every run.
+//   k_bin_check, after the high pass: a contribution reached the bound -> raise it;  the high sum lies more than BIN_SLACK bits
+//     under what the bound was chosen for (or is zero although the column has entries and a non-zero pi * theta) -> lower it.  Either
+//     way the high pass is repeated (one pass lost, the low pass has not run yet).
+//   k_bin_finish, after the low pass: S = high + low, and the bound of the NEXT iteration = 16 x the sum this column is expected to
+//     have then: columns that fall by d bits per iteration (linear EM convergence) or by d, 2d, 4d, ... bits (a column dying under a
+//     zero prior) are followed, so that later iterations rarely repeat a pass.
+// Worst-case relative error of a column sum: (entries of the column) x 2^-(57 - BIN_SLACK); typically the fp64 rounding of S.
+constexpr int BIN_SLACK = 16;
+__device__ __forceinline__ int bin_slot(uint32_t cm, int Kp, int* copies) {
+  *copies = 1 << ((cm >> 13) & 7u);
+  return (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu);
+}
+__global__ void k_bin_check(int K, const double* __restrict__ red, const uint32_t* __restrict__ colmap, int Kp,
+                            const unsigned long long* __restrict__ colcount, const uint32_t* __restrict__ ucount,
+                            const double* __restrict__ pi, const double* __restrict__ theta,
+                            uint16_t* __restrict__ ebias, uint8_t* __restrict__ ovf, uint32_t* __restrict__ flag) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K || red[K] > 0.0) return;                       // (a pass that timed out: the sums mean nothing, the update kernel refuses them)
+  int copies;
+  const int pc = bin_slot(colmap[j], Kp, &copies);
+  const int eb = ebias[pc];
+  bool over = false;
+  for (int c = 0; c < copies; ++c) { over |= ovf[pc + c] != 0; ovf[pc + c] = 0; }
+  const double S = red[j];
+  int eb_new = eb;
+  if (over) eb_new = eb + 12;
+  else if (S == 0.0) {
+    // nothing arrived: too coarse a grid, unless the column has no entry in a row of several (those of single-entry rows feed pi
+    // through pisum0, not through this pass) or pi * theta is zero
+    if (colcount && colcount[j] > (ucount ? ucount[j] : 0u) && pi[j] * theta[j] != 0.0 && eb > 120) eb_new = eb - 24;
+  }
+  else {
+    // (a high sum a few grid steps large says little about S: move by at most 24 bits and keep 6 bits in hand)
+    const int ex4 = (int)((__double2hiint(S) >> 20) & 0x7FF) + 4;
+    if (eb - ex4 > BIN_SLACK) eb_new = max(ex4 + 6, eb - 24);
+    else if (ex4 - eb > 20) eb_new = ex4;                     // a sum 2^16 bounds large: more would not be exact (53 - 30 bits of room)
+  }
+  eb_new = min(2000, max(64, eb_new));
+  if (eb_new != eb) {
+    for (int c = 0; c < copies; ++c) ebias[pc + c] = (uint16_t)eb_new;
+    atomicOr(flag, 1u);
+  }
+}
+__global__ void k_bin_finish(int K, const double* __restrict__ red_hi, double* __restrict__ red, const uint32_t* __restrict__ colmap, int Kp,
+                             uint16_t* __restrict__ ebias, uint8_t* __restrict__ ovf, int16_t* __restrict__ hist) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) red[K] = fmax(red[K], red_hi[K]);             // a time-out of either pass
+  if (j >= K) return;
+  const double S = red_hi[j] + red[j];
+  red[j] = S;
+  int copies;
+  const int pc = bin_slot(colmap[j], Kp, &copies);
+  for (int c = 0; c < copies; ++c) ovf[pc + c] = 0;          // (the low pass sees the same contributions as the high pass: nothing new)
+  if (S == 0.0) return;                                       // no information: keep the bound
+  const int ex4 = (int)((__double2hiint(S) >> 20) & 0x7FF) + 4;
+  const int eprev = hist[j], dprev = hist[K + j];
+  const int drop = eprev ? eprev - ex4 : 0;
+  int pred = drop;
+  if (drop >= 4 && dprev >= 2) pred = min(drop * drop / dprev, 2 * drop + 2);
+  pred = max(-10, min(40, pred));
+  const int shift = pred > 3 ? pred - 3 : (pred < 0 ? pred : 0);
+  const int eb_new = min(2000, max(64, ex4 - shift));
+  for (int c = 0; c < copies; ++c) ebias[pc + c] = (uint16_t)eb_new;
+  hist[j] = (int16_t)ex4; hist[K + j] = (int16_t)max(-1000, min(1000, drop));
+}
+
+int tsem_em_pass(tsem_ctx* h) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (h->opt_precision == 1) return em_pass_f32(h);
+  hipEvent_t* pair = nullptr;
+  if (int rc = begin_timing(h, &pair)) return rc;
+  bool fused_done = false;
+  if (h->nb > 0 && h->use_fused && h->opt_reproducible) {
+    // two exact passes (high and low pieces of every contribution); the high pass is repeated while a column's bound has to move:
+    // the first iteration of a run takes a few repeats (the bounds start at the largest fragment weight), later ones rarely any
+    if (h->d_ctl) {                                          // a chunk that has stopped: nothing to compute (the passes would return at once)
+      uint32_t st = 0;
+      TSEM_HIP(hipMemcpyAsync(&st, h->d_ctl, 4, hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      if (st) { h->em_launches += 1; return TSEM_OK; }
+    }
+    auto reduce = [&](const double* partial) -> int {
+      k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                              h->d_xflags, h->P, h->d_ctl,
+                                                              h->P > 1 ? reinterpret_cast<unsigned long long*>(h->d_xchg) : nullptr,
+                                                              h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
+      // (k_colreduce cleared the exchange ring; the sync words are cleared by the memset of the next launch)
+      TSEM_HIP(hipGetLastError());
+      return TSEM_OK;
+    };
+    // exact_single: ONE launch leaves the team partials of both pieces (d_fpartial: high, d_fpartial2: low)
+    auto pass = [&](int bin, hipEvent_t* ev) -> int {
+      if (h->exact_single) {
+        if (bin == 1) { if (int rc = launch_fused(h, 3, ev, 0)) return rc; }
+        return reduce(bin == 1 ? h->d_fpartial : h->d_fpartial2);
+      }
+      if (int rc = launch_fused(h, 2, ev, bin)) return rc;
+      return reduce(h->d_fpartial);
+    };
+    for (int attempt = 0;; ++attempt) {
+      if (int rc = pass(1, attempt == 0 ? pair : nullptr)) return rc;
+      TSEM_HIP(hipMemsetAsync(h->d_binflag, 0, 4, h->stream));
+      k_bin_check<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_red, h->d_colmap, h->Kp, h->d_colcount, h->d_ucount, h->d_pi, h->d_theta,
+                                                            h->d_ebias, h->d_ovf, h->d_binflag);
+      TSEM_HIP(hipGetLastError());
+      uint32_t redo = 0;
+      TSEM_HIP(hipMemcpyAsync(&redo, h->d_binflag, 4, hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      if (!redo || attempt >= 40) break;                     // (40 x 24 bits: from the largest weight down to the smallest normal number)
+      h->n_bin_repeats += 1;
+    }
+    TSEM_HIP(hipMemcpyAsync(h->d_red_hi, h->d_red, sizeof(double) * (h->K + 2), hipMemcpyDeviceToDevice, h->stream));
+    if (int rc = pass(2, nullptr)) return rc;
+    k_bin_finish<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_red_hi, h->d_red, h->d_colmap, h->Kp, h->d_ebias, h->d_ovf, h->d_ehist);
+    TSEM_HIP(hipGetLastError());
+    if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
+    h->em_launches += 1;
+    return TSEM_OK;
+  } else if (h->nb > 0 && h->use_fused) {
+    if (int rc = launch_fused(h, 0, pair)) return rc;
+    fused_done = true;
+  } else if (h->nb > 0) {
+    const size_t lds2 = (size_t)(2 * h->Kp + h->R) * 8;
+    const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : h->nb;
+    for (int64_t b0 = 0; b0 < h->nb; b0 += chunk) {
+      const int64_t b1 = std::min(h->nb, b0 + chunk);
+      if (int rc = launch_phase1(h, h->d_ctab, b0, b1, true)) return rc;
+      k_phase2_em<1024><<<h->G2 * h->P, 1024, lds2, h->stream>>>(h->P, h->Kp, h->R, b0, b1, h->G2, b0 > 0 ? 1 : 0,
+          h->N_amb_pad, h->d_sb_off, h->d_pval, h->d_prc, h->d_ctab, h->d_ypart, h->d_amb_wcode, h->d_lut, h->d_partial, h->d_ctl);
+    }
+    TSEM_HIP(hipGetLastError());
+  }
+  if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
+  h->em_launches += 1;
+  if (fused_done) {
+    k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                            h->d_xflags, h->P, h->d_ctl,
+                                                            h->P > 1 ? reinterpret_cast<unsigned long long*>(h->d_xchg) : nullptr,
+                                                            h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
+  } else if (h->nb > 0) {
+    k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                            nullptr, h->P, h->d_ctl, nullptr, 0);
+  } else {
+    TSEM_HIP(hipMemsetAsync(h->d_red, 0, sizeof(double) * (h->K + 2), h->stream));
+  }
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+static int launch_update(tsem_ctx* h, double* d_diff_slot, bool chunked = false, double eps = 0.0, int use_lnl = 0) {
+  const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;   // model.py:696-697
+  const double tden = h->W_amb + tpw * h->K, pden = h->W_tot + ppw * h->K;      // model.py:732,738
+  const int nblk = std::min(1024, cdiv64(h->K, 256));
+  double* part = h->d_lnl_part + 10000;   // scratch for the per-block |pi_hat - pi| partials
+  if (!h->d_fz_aux) {
+    TSEM_ALLOC(h->d_fz_aux, 4);
+    TSEM_HIP(hipMemsetAsync(h->d_fz_aux, 0, sizeof(uint32_t) * 4, h->stream));
+  }
+  const bool clean = h->use_fused && h->d_xflags && h->fused_launched;
+  UpdCtl C;
+  C.ctl = chunked ? h->d_ctl : nullptr; C.eps = eps; C.use_lnl = use_lnl;
+  C.pi_first = h->first_pending ? h->d_pi_first : nullptr; C.theta_first = h->first_pending ? h->d_theta_first : nullptr;
+  k_update<<<nblk, 256, 0, h->stream>>>(C, h->K, h->d_red, h->d_pisum0, tpw, tden, ppw, pden, h->d_pi, h->d_theta,
+                                        h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab, h->d_ctab_prev,
+                                        h->d_twin_rep, part, d_diff_slot, h->d_fz_aux,
+                                        clean ? h->d_xflags : nullptr, h->d_fz_aux + 2,
+                                        reinterpret_cast<unsigned long long*>(h->d_xchg),
+                                        h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
+  TSEM_HIP(hipGetLastError());
+  if (clean) h->fz_clean = true;
+  h->em_prev = h->em_cur; h->em_cur = true;                // (a skipped update — stop flag, time-out — leaves older, equally valid M-step values)
+  return TSEM_OK;
+}
+
+// the error word of the fused kernel: live, or what k_update / k_keep_err saved before zeroing it.  Clears it.
+int tsem_twopass_attributes(tsem_ctx* h) {
+  TSEM_HIP(hipFuncSetAttribute((const void*)k_phase1<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
+  TSEM_HIP(hipFuncSetAttribute((const void*)k_phase2_em<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX));
+  TSEM_HIP(hipFuncSetAttribute((const void*)k_phase2_lnl<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+  return TSEM_OK;
+}
+
+int tsem_sum_parts(tsem_ctx* h, const double* a, int na, const double* b, int nb, double* out) {
+  k_sum_parts<<<1, 256, 0, h->stream>>>(a, na, b, nb, out);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+int tsem_take_fused_error(tsem_ctx* h, uint32_t* word) {
+  *word = 0;
+  if (!h->d_xflags || !h->fused_launched) return TSEM_OK;
+  uint32_t ee[2] = {0, 0}, kept[2] = {0, 0};
+  TSEM_HIP(hipMemcpyAsync(ee, h->d_xflags + 9, 8, hipMemcpyDeviceToHost, h->stream));
+  if (h->d_fz_aux) TSEM_HIP(hipMemcpyAsync(kept, h->d_fz_aux + 2, 8, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  *word = ee[0] | kept[0];
+  h->last_slow_path = h->fz_clean ? kept[1] : ee[1];
+  if (*word) {
+    TSEM_HIP(hipMemsetAsync(h->d_xflags + 9, 0, 4, h->stream));
+    if (h->d_fz_aux) TSEM_HIP(hipMemsetAsync(h->d_fz_aux + 2, 0, 4, h->stream));
+  }
+  return TSEM_OK;
+}
+
+int tsem_fallback_twopass(tsem_ctx* h) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (!h->use_fused) return TSEM_OK;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  uint32_t e = 0;
+  (void)tsem_take_fused_error(h, &e);
+  h->em_kernel = TSEM_EMK_TWOPASS;
+  h->opt_format = 1;                                       // the two-pass kernels read fp64 entries
+  h->opt_dbg &= ~(int64_t)(32 | 64);
+  if (int rc = tsem_choose_geometry(h)) return rc;
+  if (int rc = tsem_build_layout(h)) return rc;
+  // the permuted pi*theta tables follow the new column map
+  TSEM_ALLOC(h->d_ctab, h->Kpad); TSEM_ALLOC(h->d_ctab_prev, h->Kpad);
+  TSEM_HIP(hipMemsetAsync(h->d_ctab, 0, sizeof(double) * h->Kpad, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_ctab_prev, 0, sizeof(double) * h->Kpad, h->stream));
+  if (int rc = tsem_make_ctabs(h)) return rc;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  h->n_fallbacks += 1;
+  fprintf(stderr, "libtelescope_em: the persistent EM kernel could not keep its workgroups co-resident (watchdog code %u); "
+                  "continuing with the two-pass kernels\n", e);
+  return TSEM_OK;
+}
+
+int tsem_recover_timeout(tsem_ctx* h, int32_t* switched) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (switched) *switched = 0;
+  uint32_t mine = 0;
+  if (int rc = tsem_take_fused_error(h, &mine)) return rc;
+  if (mine && h->use_fused) {
+    if (int rc = tsem_fallback_twopass(h)) return rc;
+    if (switched) *switched = 1;
+  }
+  return TSEM_OK;
+}
+
+int tsem_em_update(tsem_ctx* h, double* diff_est) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (int rc = launch_update(h, h->d_diffs)) return rc;
+  h->first_pending = false;
+  if (diff_est) {
+    TSEM_HIP(hipMemcpyAsync(diff_est, h->d_diffs, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    // negative: the (all-reduced) error flag was up, so no rank committed this iteration
+    if (*diff_est < 0.0)
+      TSEM_FAIL(TSEM_ERR_TIMEOUT, "EM pass: the hand-off watchdog of the fused kernel fired on some rank; parameters "
+                                  "left untouched (tsem_fallback_twopass, then redo the pass)");
+  }
+  return TSEM_OK;
+}
+
+static int launch_lnl(tsem_ctx* h) {
+  int na = 0, nu = 0;
+  if (h->nb > 0 && h->use_fused) {
+    if (int rc = launch_fused(h, 1, nullptr)) return rc;
+    na = h->fz_grid;
+  } else if (h->nb > 0) {
+    if (int rc = launch_phase1(h, h->d_ctab_prev)) return rc;
+    const size_t lds2 = (size_t)(2 * h->Kp + h->R) * 8;
+    na = h->G2 * h->P;
+    k_phase2_lnl<1024><<<na, 1024, lds2, h->stream>>>(h->P, h->Kp, h->R, h->nb, h->G2, h->N_amb_pad, h->d_sb_off,
+        h->d_pval, h->d_prc, h->d_ctab_prev, h->d_ctab, h->d_ypart, h->d_lnl_part);
+    TSEM_HIP(hipGetLastError());
+  }
+  if (h->N_uni > 0) {
+    nu = (int)std::min<int64_t>(2048, (h->N_uni + 255) / 256);
+    k_lnl_unique<<<nu, 256, 0, h->stream>>>(h->N_uni, h->d_uni_col, h->d_uni_code, h->d_lut, h->d_pi_prev, h->d_pi,
+                                           h->d_lnl_part + 4096);
+    TSEM_HIP(hipGetLastError());
+  }
+  k_sum_parts<<<1, 256, 0, h->stream>>>(h->d_lnl_part, na, h->d_lnl_part + 4096, nu, h->d_red + h->K);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+int tsem_lnl_pass(tsem_ctx* h) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  return launch_lnl(h);
+}
+
+int tsem_read_reduce(tsem_ctx* h, double* out, int64_t offset, int64_t count) {
+  if (!h || !h->have_model || !out || offset < 0 || offset + count > h->K + 2) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipMemcpyAsync(out, h->d_red + offset, sizeof(double) * count, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return TSEM_OK;
+}
+
+static int ensure_ctl(tsem_ctx* h) {
+  if (h->d_ctl) return TSEM_OK;
+  TSEM_ALLOC(h->d_ctl, 8); TSEM_ALLOC(h->d_ctld, 8); TSEM_ALLOC(h->d_lnls, TS_DIFF_RING);
+  TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 32, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_ctld, 0, 64, h->stream));
+  return TSEM_OK;
+}
+
+// the lnl of the iteration just committed, all-reduced, into d_ctld[1] (value) / d_ctld[2] (error flag)
+static int enqueue_lnl_reduce(tsem_ctx* h) {
+  if (int rc = launch_lnl(h)) return rc;
+  k_lnl_slots<<<1, 1, 0, h->stream>>>(h->d_red + h->K, (h->use_fused && h->nb > 0) ? h->d_xflags : nullptr, h->d_ctld + 1);
+  TSEM_HIP(hipGetLastError());
+  if (tsem_comm_on(h)) { if (int rc = tsem_comm_allreduce_dev(h->comm, h->d_ctld + 1, 2, 0, h->stream, h->err)) return rc; }
+  return TSEM_OK;
+}
+
+int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likelihood, int32_t first,
+                  int32_t* n_done, int32_t* stopped, double* diffs_out, double* lnls_out) {
+  if (!h || !h->have_model || n_max < 0 || n_max > TS_DIFF_RING) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (int rc = ensure_ctl(h)) return rc;
+  if (first) {
+    // model.py:786 compares the first iteration's lnl with self.lnl as the previous run left it (inf on a fresh model,
+    // model.py:683): tsem_set_prev_lnl / the end of tsem_em_run keep that value for the next run
+    const double seed = h->lnl_prev_seed;
+    TSEM_HIP(hipMemcpy(h->d_ctld, &seed, sizeof(double), hipMemcpyHostToDevice));
+    if (!h->d_pi_first) { TSEM_ALLOC(h->d_pi_first, h->K); TSEM_ALLOC(h->d_theta_first, h->K); }
+    h->first_pending = true;
+  }
+  int done = 0, retries = 0;
+  bool stop = false, lnl_pending = false;
+  // (an lnl pass that timed out in the LAST iteration of the chunk is redone before returning: its value is the
+  // iteration's log-likelihood and may end the run — ADVICE r2)
+  while ((done < n_max || lnl_pending) && !stop) {
+    // enqueue everything that is left; the device stops itself
+    TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 8, h->stream));
+    const int base = done, want = n_max - done;
+    if (lnl_pending) {                                     // the lnl pass of the last committed iteration timed out
+      if (int rc = enqueue_lnl_reduce(h)) return rc;
+      k_lnl_check<<<1, 1, 0, h->stream>>>(h->d_ctl, h->d_ctld, h->d_ctld + 1, epsilon, h->d_lnls + base - 1);
+      TSEM_HIP(hipGetLastError());
+    }
+    for (int i = 0; i < want; ++i) {
+      if (int rc = tsem_em_pass(h)) return rc;
+      if (int rc = tsem_comm_allreduce_red(h, 0, h->K + 2)) return rc;
+      if (int rc = launch_update(h, h->d_diffs + base + i, true, epsilon, use_likelihood)) return rc;
+      h->first_pending = false;                            // (a failed first update is redone below with the flag restored)
+      if (use_likelihood) {
+        if (int rc = enqueue_lnl_reduce(h)) return rc;
+        k_lnl_check<<<1, 1, 0, h->stream>>>(h->d_ctl, h->d_ctld, h->d_ctld + 1, epsilon, h->d_lnls + base + i);
+        TSEM_HIP(hipGetLastError());
+      }
+    }
+    uint32_t ctl[2] = {0, 0};
+    TSEM_HIP(hipMemcpyAsync(ctl, h->d_ctl, 8, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    done = base + (int)ctl[1];
+    lnl_pending = false;
+    if (ctl[0] == 1u) { stop = true; break; }
+    if (ctl[0] == 2u || ctl[0] == 3u) {                    // some rank's fused pass timed out: nobody committed that step
+      if (++retries > 3) TSEM_FAIL(TSEM_ERR_TIMEOUT, "EM pass: repeated hand-off time-outs");
+      uint32_t mine = 0;
+      if (int rc = tsem_take_fused_error(h, &mine)) return rc;
+      if (mine) { if (int rc = tsem_fallback_twopass(h)) return rc; }
+      if (first && done == 0 && ctl[0] == 2u) h->first_pending = true;
+      lnl_pending = ctl[0] == 3u;
+      continue;
+    }
+    if (h->use_fused && !tsem_comm_on(h)) {                     // belt and braces: an error word the flags did not carry.  (Row-sharded
+      uint32_t mine = 0;                                   //  runs rely on slot K alone: failing on ONE rank would leave the others in the next collective.)
+      if (int rc = tsem_take_fused_error(h, &mine)) return rc;
+      if (mine) TSEM_FAIL(TSEM_ERR_TIMEOUT, "fused EM kernel: hand-off watchdog fired (code " + std::to_string(mine) + ")");
+    }
+  }
+  if (n_done) *n_done = done;
+  if (stopped) *stopped = stop ? 1 : 0;
+  if (done && diffs_out) TSEM_HIP(hipMemcpy(diffs_out, h->d_diffs, sizeof(double) * done, hipMemcpyDeviceToHost));
+  if (done && lnls_out && use_likelihood) TSEM_HIP(hipMemcpy(lnls_out, h->d_lnls, sizeof(double) * done, hipMemcpyDeviceToHost));
+  TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 8, h->stream));     // passes launched outside a chunk must not see a stale stop flag
+  return TSEM_OK;
+}
+
+int tsem_em_steps(tsem_ctx* h, int32_t n, double* diffs_out) {
+  int32_t done = 0;
+  return tsem_em_chunk(h, n, 0.0, 0, 0, &done, nullptr, diffs_out, nullptr);
+}
+
+// the final log-likelihood (model.py:800-801), all-reduced; redone on the two-pass kernels after a time-out
+static int final_lnl(tsem_ctx* h, double* lnl) {
+  if (int rc = ensure_ctl(h)) return rc;
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = enqueue_lnl_reduce(h)) return rc;
+    double v[2] = {0, 0};
+    TSEM_HIP(hipMemcpyAsync(v, h->d_ctld + 1, 16, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (v[1] > 0.0) {
+      if (attempt >= 2) TSEM_FAIL(TSEM_ERR_TIMEOUT, "lnl pass: repeated hand-off time-outs");
+      uint32_t mine = 0;
+      if (int rc = tsem_take_fused_error(h, &mine)) return rc;
+      if (mine) { if (int rc = tsem_fallback_twopass(h)) return rc; }
+      continue;
+    }
+    *lnl = v[0];
+    return TSEM_OK;
+  }
+}
+
+int tsem_final_lnl(tsem_ctx* h, double* lnl) {
+  if (!h || !h->have_model || !lnl) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  return final_lnl(h, lnl);
+}
+
+int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likelihood, int32_t* n_iter,
+                int32_t* converged, double* lnl_out, double* diffs, double* lnls, double* pi_init,
+                double* theta_init) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  int inum = 0;
+  bool conv = false;
+  double lnl = INFINITY;
+  do {                                        // model.py:771-797: at least one iteration
+    const int want = std::max(1, std::min(8, max_iter - inum));
+    int32_t done = 0, stopped = 0;
+    std::vector<double> d(want), l(want);
+    if (int rc = tsem_em_chunk(h, want, epsilon, use_likelihood, inum == 0, &done, &stopped, d.data(), l.data())) return rc;
+    for (int i = 0; i < done; ++i) {
+      if (diffs && inum + i < std::max(1, max_iter)) diffs[inum + i] = d[i];
+      if (lnls && use_likelihood && inum + i < std::max(1, max_iter)) lnls[inum + i] = l[i];
+      if (use_likelihood) lnl = l[i];
+    }
+    inum += done;
+    conv = stopped != 0;
+  } while (!conv && inum < max_iter);
+  if (pi_init || theta_init) { if (int rc = tsem_get_params(h, TSEM_Z_FIRST, pi_init, theta_init)) return rc; }
+  if (!use_likelihood) {                      // model.py:800-801
+    if (int rc = final_lnl(h, &lnl)) return rc;
+  }
+  h->lnl_prev_seed = lnl;                     // what the next run's first lnl is compared with (model.py:786)
+  if (n_iter) *n_iter = inum;
+  if (converged) *converged = conv ? 1 : 0;
+  if (lnl_out) *lnl_out = lnl;
+  return TSEM_OK;
+}
+
+int tsem_set_prev_lnl(tsem_ctx* h, double lnl) {
+  if (!h) return TSEM_ERR_ARG;
+  h->lnl_prev_seed = lnl;
+  return TSEM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1169 @@
+// libtelescope_em.so, report unit: passes over the canonical CSR after (or outside) the EM loop — z export, best hits,
+// reassign x 6 (model.py:808-865), the streaming report pass (conf | exclude | average of one z, model.py:432-457),
+// per-barcode sums (model.py:611-625), and the public estep / mstep / calculate_lnl on caller-supplied arrays.
+#include "tsem_internal.h"
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+// ============================================================================
+// CSR row passes: z export, best-hit counts, reassign (model.py:808-865)
+// ============================================================================
+enum { RP_EXPORT_Z = 0, RP_BEST = 1, RP_REASSIGN = 2, RP_REPORT = 3 };
+
+// Option "reproducible": values in [0, 2) — posteriors, shares of a tie — cut into a multiple of 2^-26 and the rest on the 2^-53
+// grid: up to 2^26 of either add exactly in fp64, whatever order the atomics are served in; the two sums are added once at the end.
+__device__ __forceinline__ void exact_split01(double v, double& hi, double& lo) {
+  const double m1 = 100663296.0;                            // 1.5 * 2^26: ulp 2^-26
+  hi = (v + m1) - m1;
+  lo = ((v - hi) + 0.75) - 0.75;                            // ulp(0.75) = 2^-53
+}
+__global__ void k_add_lo(int64_t n, double* __restrict__ a, const double* __restrict__ lo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += lo[i];
+}
+
+struct RowPassArgs {
+  int64_t N;
+  int32_t K;
+  const int64_t* indptr;
+  const int32_t* indices;
+  const uint16_t* raw;
+  const double* lut;
+  const double* pi;      // null => initial (c == 1)
+  const double* theta;
+  const double* zin;     // non-null: the caller's z (TSEM_Z_USER), aligned to the CSR pattern, NaN = no entry; used as is
+  const double* cnat;    // pi[j] * theta[j] per column (natural order): ONE gather per entry of an ambiguous row instead of two
+  int lut_len;           // the score table is staged in LDS ([lut_len] doubles in front of the hot slots)
+  int method;
+  double thresh;
+  const int32_t* picks;
+  double* zout;          // EXPORT_Z / mask
+  int32_t* nbest;
+  double* colsums;
+  const int32_t* group;  // REASSIGN: optional row -> group map; colsums is then [n_groups][K]
+  const int32_t* rowlist; int64_t nlist;   // REASSIGN: optional list of rows to visit (picks[] is then indexed by list position)
+  // REPORT: conf, exclude and average in ONE pass -> colsums[0..K), [K..2K), [2K..3K); best-hit counts -> nbest
+  // REASSIGN without groups: the Hs most popular slots of every column part are summed in LDS per
+  // workgroup and flushed once (global fp64 atomics: 22 G/s, 2 G/s on a popular column)
+  const uint32_t* colmap; const int32_t* col_of_pc; int P, Kp, Hs;
+  double* colsums_lo = nullptr;   // option "reproducible": the low pieces of every value (same shape as colsums; no LDS slots then)
+};
+
+// METH >= 0 fixes the reassign method at compile time (the per-entry switch and the reductions a method does not
+// need disappear: the pass is bound by instruction issue, ~300 per four rows); METH = -1 reads it from the arguments.
+template <int MODE, int METH = -1>
+__global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
+  const int method = METH >= 0 ? METH : A.method;
+  extern __shared__ double rp_lds[];                       // [lut_len] score table | [P][Hs] hot slots (REASSIGN with A.Hs > 0)
+  double* const lutS = rp_lds;
+  double* const hot = rp_lds + A.lut_len;
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  const bool initial = (A.pi == nullptr);
+  const int nhot1 = (MODE == RP_REASSIGN || MODE == RP_REPORT) ? A.P * A.Hs : 0;
+  const int nhot = MODE == RP_REPORT ? 3 * nhot1 : nhot1;
+  // The pass is bound by vector-memory INSTRUCTIONS (every gather touches 64 cache lines): the score table
+  // comes from LDS and pi*theta from one precomputed table, 3 instead of 5 vector-memory instructions per round
+  for (int t = threadIdx.x; t < A.lut_len; t += blockDim.x) lutS[t] = A.lut[t];
+  for (int t = threadIdx.x; t < nhot; t += blockDim.x) hot[t] = 0.0;
+  __syncthreads();
+  const int64_t n_visit = (MODE == RP_REASSIGN && A.rowlist) ? A.nlist : A.N;
+  for (int64_t idx = (int64_t)blockIdx.x * subs + sub; idx < n_visit; idx += (int64_t)gridDim.x * subs) {
+    const int64_t row = (MODE == RP_REASSIGN && A.rowlist) ? (int64_t)A.rowlist[idx] : idx;
+    const int64_t s = A.indptr[row], e = A.indptr[row + 1];
+    const bool amb = (e - s) > 1;
+    // one value of report column m (0 for a plain reassign) for column `col`: popular columns in LDS, the rest global
+    auto emit = [&](int m, int col, uint32_t cm, double val, int64_t grp_off) {
+      if (A.colsums_lo) {
+        double hi, lo;
+        exact_split01(val, hi, lo);
+        unsafeAtomicAdd(&A.colsums[(int64_t)m * A.K + grp_off + col], hi);
+        if (lo != 0.0) unsafeAtomicAdd(&A.colsums_lo[(int64_t)m * A.K + grp_off + col], lo);
+      } else if (nhot1 && (int)(cm & 0x1FFFu) < A.Hs) lds_add(&hot[m * nhot1 + (cm >> 16) * A.Hs + (cm & 0x1FFFu)], val);
+      else unsafeAtomicAdd(&A.colsums[(int64_t)m * A.K + grp_off + col], val);
+    };
+    auto numer = [&](int64_t k) -> double {
+      if (A.zin) return A.zin[k];
+      double q = A.lut_len ? lutS[A.raw[k]] : A.lut[A.raw[k]];
+      if (initial) return q;
+      int col = A.indices[k];
+      double c = amb ? A.cnat[col] : A.pi[col];              // cnat[col] = pi[col] * theta[col]: the same product, formed once per column
+      return q * c;
+    };
+    if (e - s <= 4 * RP_SUB) {
+      // Rows of up to 64 entries (all of them, for alignment data): the numerators are computed once
+      // and stay in registers for the row sum, the row maximum, the tie count and the output value.
+      double n[4]; bool vld[4], inp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t k = s + lane + i * RP_SUB;
+        vld[i] = k < e;
+        n[i] = vld[i] ? numer(k) : 0.0;
+        inp[i] = vld[i] && (A.zin ? !isnan(n[i]) : (initial || n[i] != 0.0));
+        if (A.zin && !inp[i]) n[i] = 0.0;
+      }
+      // same summation order as the long-row path below: lane-strided partial sums, then across lanes
+      const double rs = recip0(sg_sum<RP_SUB>(((n[0] + n[1]) + n[2]) + n[3]));
+      const double r = A.zin ? 1.0 : rs;                    // the caller's z is used as is (model.py:837)
+      double zmax = -1.0; int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (inp[i]) { zmax = fmax(zmax, n[i] * r); ++cnt; }
+      zmax = sg_max<RP_SUB>(zmax);
+      cnt = sg_sum_i<RP_SUB>(cnt);
+      if (MODE == RP_EXPORT_Z) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (vld[i]) A.zout[s + lane + i * RP_SUB] = inp[i] ? n[i] * r : -1.0;
+        continue;
+      }
+      int nb = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nb += (inp[i] && (n[i] * r) == zmax) ? 1 : 0;
+      nb = sg_sum_i<RP_SUB>(nb);
+      if (MODE == RP_BEST) {
+        if (lane == 0) A.nbest[row] = cnt ? nb : 0;
+        continue;
+      }
+      double vsum = 0.0;
+      if (method == TSEM_RA_CONF || MODE == RP_REPORT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (inp[i] && n[i] * r >= A.thresh) vsum += n[i] * r;
+        vsum = sg_sum<RP_SUB>(vsum);
+      }
+      if (MODE == RP_REPORT) {                              // conf | exclude | average of model.py:839-856 from one set of numerators
+        if (lane == 0 && A.nbest) A.nbest[row] = cnt ? nb : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double z = n[i] * r;
+          const bool best = inp[i] && (z == zmax);
+          const double vc = (inp[i] && z >= A.thresh) ? z * recip0(vsum) : 0.0;
+          if (vld[i] && (best || vc != 0.0)) {
+            const int col = A.indices[s + lane + i * RP_SUB];
+            const uint32_t cm = nhot1 ? A.colmap[col] : 0xFFFFFFFFu;
+            if (vc != 0.0) emit(0, col, cm, vc, 0);
+            if (best && nb == 1) emit(1, col, cm, 1.0, 0);
+            if (best) emit(2, col, cm, 1.0 * recip0((double)nb), 0);
+          }
+        }
+        continue;
+      }
+      const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[A.rowlist ? idx : row] : 0;
+      const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
+      int base = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t k = s + lane + i * RP_SUB;
+        const double z = n[i] * r;
+        const bool best = inp[i] && (z == zmax);
+        const unsigned long long bal = __ballot(best);
+        const unsigned grp = (unsigned)((bal >> ((threadIdx.x & 63) / RP_SUB * RP_SUB)) & 0xFFFFull);
+        const int ord = base + __popc(grp & ((1u << lane) - 1u));
+        base += __popc(grp);
+        double val = 0.0;
+        switch (method) {
+          case TSEM_RA_EXCLUDE: val = (best && nb == 1) ? 1.0 : 0.0; break;
+          case TSEM_RA_CHOOSE:  val = (best && ord == pick) ? 1.0 : 0.0; break;
+          case TSEM_RA_AVERAGE: val = best ? 1.0 * recip0((double)nb) : 0.0; break;
+          case TSEM_RA_CONF:    val = (inp[i] && z >= A.thresh) ? z * recip0(vsum) : 0.0; break;
+          case TSEM_RA_UNIQUE:  val = (inp[i] && !amb) ? ceil(z) : 0.0; break;
+          case TSEM_RA_ALL:     val = (inp[i] && z > 0.0) ? 1.0 : 0.0; break;
+        }
+        if (vld[i]) {
+          if (A.zout) A.zout[k] = val;
+          if (val != 0.0 && grp_off >= 0) {
+            const int col = A.indices[k];
+            emit(0, col, nhot1 ? A.colmap[col] : 0xFFFFFFFFu, val, grp_off);
+          }
+        }
+      }
+      continue;
+    }
+    // sweep 1: row sum
+    double y = 0.0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) { const double v = numer(k); y += (A.zin && isnan(v)) ? 0.0 : v; }
+    y = sg_sum<RP_SUB>(y);
+    const double r = A.zin ? 1.0 : recip0(y);
+    // sweep 2: row max over z's pattern
+    double zmax = -1.0;
+    int cnt = 0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      double n = numer(k);
+      bool inpat = A.zin ? !isnan(n) : (initial || (n != 0.0));
+      if (inpat) { zmax = fmax(zmax, n * r); ++cnt; }
+    }
+    zmax = sg_max<RP_SUB>(zmax);
+    cnt = sg_sum_i<RP_SUB>(cnt);
+    if (MODE == RP_EXPORT_Z) {
+      for (int64_t k = s + lane; k < e; k += RP_SUB) {
+        double n = numer(k);
+        bool inpat = A.zin ? !isnan(n) : (initial || (n != 0.0));
+        A.zout[k] = inpat ? n * r : -1.0;   // -1 marks an entry the reference drops from z's pattern
+      }
+      continue;
+    }
+    // sweep 3: number of best hits (binmax, sparse_plus.py:117-129)
+    int nb = 0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      double n = numer(k);
+      bool inpat = A.zin ? !isnan(n) : (initial || (n != 0.0));
+      if (inpat && (n * r) == zmax) ++nb;
+    }
+    nb = sg_sum_i<RP_SUB>(nb);
+    if (MODE == RP_BEST) {
+      if (lane == 0) A.nbest[row] = cnt ? nb : 0;
+      continue;
+    }
+    // ---- reassign ----
+    double vsum = 0.0;
+    if (method == TSEM_RA_CONF || MODE == RP_REPORT) {
+      for (int64_t k = s + lane; k < e; k += RP_SUB) {
+        double n = numer(k);
+        double z = n * r;
+        if ((A.zin ? !isnan(n) : (initial || n != 0.0)) && z >= A.thresh) vsum += z;
+      }
+      vsum = sg_sum<RP_SUB>(vsum);
+    }
+    if (MODE == RP_REPORT) {
+      if (lane == 0 && A.nbest) A.nbest[row] = cnt ? nb : 0;
+      for (int64_t k = s + lane; k < e; k += RP_SUB) {
+        const double n = numer(k);
+        const bool inpat = A.zin ? !isnan(n) : (initial || n != 0.0);
+        const double z = n * r;
+        const bool best = inpat && (z == zmax);
+        const double vc = (inpat && z >= A.thresh) ? z * recip0(vsum) : 0.0;
+        if (best || vc != 0.0) {
+          const int col = A.indices[k];
+          const uint32_t cm = nhot1 ? A.colmap[col] : 0xFFFFFFFFu;
+          if (vc != 0.0) emit(0, col, cm, vc, 0);
+          if (best && nb == 1) emit(1, col, cm, 1.0, 0);
+          if (best) emit(2, col, cm, 1.0 * recip0((double)nb), 0);
+        }
+      }
+      continue;
+    }
+    const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[A.rowlist ? idx : row] : 0;
+    const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
+    int base = 0;
+    for (int64_t k0 = s; k0 < e; k0 += RP_SUB) {
+      int64_t k = k0 + lane;
+      bool valid = k < e;
+      double n = valid ? numer(k) : 0.0;
+      bool inpat = valid && (A.zin ? !isnan(n) : (initial || n != 0.0));
+      double z = n * r;
+      bool best = inpat && (z == zmax);
+      unsigned long long bal = __ballot(best);
+      unsigned grp = (unsigned)((bal >> ((threadIdx.x & 63) / RP_SUB * RP_SUB)) & 0xFFFFull);
+      int ord = base + __popc(grp & ((1u << lane) - 1u));
+      base += __popc(grp);
+      double val = 0.0;
+      switch (method) {
+        case TSEM_RA_EXCLUDE: val = (best && nb == 1) ? 1.0 : 0.0; break;
+        case TSEM_RA_CHOOSE:  val = (best && ord == pick) ? 1.0 : 0.0; break;
+        case TSEM_RA_AVERAGE: val = best ? 1.0 * recip0((double)nb) : 0.0; break;
+        case TSEM_RA_CONF:    val = (inpat && z >= A.thresh) ? z * recip0(vsum) : 0.0; break;
+        case TSEM_RA_UNIQUE:  val = (inpat && !amb) ? ceil(z) : 0.0; break;
+        case TSEM_RA_ALL:     val = (inpat && z > 0.0) ? 1.0 : 0.0; break;
+      }
+      if (valid) {
+        if (A.zout) A.zout[k] = val;
+        if (val != 0.0 && grp_off >= 0) {
+          const int col = A.indices[k];
+          emit(0, col, nhot1 ? A.colmap[col] : 0xFFFFFFFFu, val, grp_off);
+        }
+      }
+    }
+  }
+  if (nhot) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < nhot; t += blockDim.x) {
+      const double v = hot[t];
+      const int m = t / nhot1, tt = t % nhot1;
+      if (v != 0.0) unsafeAtomicAdd(&A.colsums[(int64_t)m * A.K + A.col_of_pc[(tt / A.Hs) * A.Kp + tt % A.Hs]], v);
+    }
+  }
+}
+
+// ---- the report pass: conf | exclude | average of ONE z in one pass (model.py:432-457) ----------------------------
+// Round 2's RP_REPORT ran at 0.07 of the HBM peak (20 ms for 11.8 GB at 50M x 40, profiles/r02_report_kernel_stats.txt):
+// 16 lanes per row, one 4-byte + one 2-byte load per lane and sweep, every load behind the row pointers it depends on,
+// nothing in flight while a row is computed, ~700 instructions per four rows, one pi*theta gather per entry from a
+// 240 KB table in L2 (the vector cache takes ONE gather address per clock and CU: 2e9 gathers = 4 ms by themselves,
+// measured: the same pass without them 3.3 ms), global atomics on popular columns.  What this kernel changes:
+//   * it reads a 2-byte POPULARITY ID per entry (rid16, written while the layout is built: id = slot * P + part of the
+//     column's place in the blocked layout, so small ids are popular columns) and the 2-byte score code: 4 B per entry
+//     instead of 6, and the id indexes LDS tables directly — pi*theta of the HC most popular columns sits in LDS, only
+//     the cold tail is gathered from L2; the winner's scatter needs no column-map lookup; everything is accumulated per
+//     id and mapped back to columns by k_report_finish;
+//   * a lane holds E = 16 (or 8) CONSECUTIVE entries of its row, a row takes G = 1 .. 16 lanes (capacity G x E, chosen
+//     from the row-length histogram so that < 0.5 % of the rows overflow): the per-row work — butterflies, row
+//     pointers, the winner's scatter, loop control — is paid once per 64 / G rows of a wave, the per-entry work is a
+//     dozen instructions with no cross-lane step;
+//   * row pointers are fetched two iterations ahead and the entries one iteration ahead of the row they belong to,
+//     unconditionally (the entry arrays carry padding, rows past the end are clamped), so the next rows' loads are in
+//     flight while a row is reduced; the group reductions are DPP butterflies on the VALU;
+//   * a row has ONE winner in all but the tied rows: with conf_prob > 0.5 the entry with z >= conf_prob, if any, is the
+//     unique best hit.  The lane that holds it does one 32-bit LDS counter increment (`exclude` and the `average` of
+//     rows with one best hit are the same count) and one fp64 LDS add (`conf`); two-way ties (most of the 11 % tied rows of
+//     the initial z) increment a second counter, average = n1 + n2 / 2 + the shares of the wider ties.  Ids beyond the LDS
+//     slots use global atomics.  conf_prob <= 0.5 takes the general per-entry path.
+// Rows longer than G x E entries are appended to a list and reduced by k_report_slow afterwards (same arithmetic); a
+// caller-assigned z, score tables that do not fit LDS and layouts with more than 65536 slots stay on k_rowpass.  Integer
+// outputs are exact; floats differ by summation order only.
+struct ReportArgs {
+  int64_t N, nnz;
+  int32_t K, IDN;                      // ids 0 .. IDN-1 (= P * Kp)
+  const int64_t* indptr;
+  const uint16_t* rid;                 // [nnz + TS_ENTRY_PAD] popularity id of every entry's column
+  const uint16_t* raw;                 // [nnz + TS_ENTRY_PAD] score codes
+  const double* lut; int lut_len;      // staged in LDS (0 < lut_len <= 2048)
+  const double* cnat2;                 // [2 IDN] by id: pi*theta | pi (ambiguous rows use the first half, unique rows the second); null => initial z
+  double thresh;
+  int32_t* nbest;                      // [N] number of best hits per row (0: empty pattern)
+  double *g_conf, *g_n1, *g_n2, *g_avgt;   // [IDN] each, by id
+  double *g_conf_lo = nullptr, *g_avgt_lo = nullptr;   // option "reproducible": low pieces (exact_split01); LDS then holds [Hs] more doubles
+  int HC, Hs;                          // LDS slots: pi*theta of ids < HC; accumulators of ids < Hs
+  int32_t* defer_rows; unsigned long long* defer_n;   // rows left to k_report_slow
+  int dbg;                             // timing experiments (wrong results): 1 drop the emits that miss the LDS slots, 2 the row-count stores, 4 the ties
+};
+// 16- / 8-byte loads at the natural alignment of their ELEMENTS (a row starts at any entry): plain vector types with
+// a reduced alignment, so the compiler emits one global_load_dwordx4 / dwordx2 (the target allows unaligned access)
+typedef unsigned int rr_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef long long rr_i64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+// butterflies over aligned groups of G = 1 .. 16 lanes on the VALU: after the two quad permutes every lane of a quad
+// holds the quad's total, the half-row mirror (lane i <-> 7 - i) then pairs the quads, the row mirror (i <-> 15 - i) the
+// halves.  Every lane of a group must be active.
+constexpr int RR_QP_X1 = 0xB1, RR_QP_X2 = 0x4E, RR_HALF_MIRROR = 0x141, RR_MIRROR = 0x140;
+template <int G> __device__ __forceinline__ double rr_sum(double v) {
+  if (G >= 2) v += fz_dpp_d<RR_QP_X1, 0xF>(v, v);
+  if (G >= 4) v += fz_dpp_d<RR_QP_X2, 0xF>(v, v);
+  if (G >= 8) v += fz_dpp_d<RR_HALF_MIRROR, 0xF>(v, v);
+  if (G >= 16) v += fz_dpp_d<RR_MIRROR, 0xF>(v, v);
+  return v;
+}
+template <int G> __device__ __forceinline__ double rr_max(double v) {
+  if (G >= 2) v = fmax(v, fz_dpp_d<RR_QP_X1, 0xF>(v, v));
+  if (G >= 4) v = fmax(v, fz_dpp_d<RR_QP_X2, 0xF>(v, v));
+  if (G >= 8) v = fmax(v, fz_dpp_d<RR_HALF_MIRROR, 0xF>(v, v));
+  if (G >= 16) v = fmax(v, fz_dpp_d<RR_MIRROR, 0xF>(v, v));
+  return v;
+}
+template <int G> __device__ __forceinline__ int rr_sum_i(int v) {
+  if (G >= 2) v += fz_dpp_i<RR_QP_X1, 0xF>(v, v);
+  if (G >= 4) v += fz_dpp_i<RR_QP_X2, 0xF>(v, v);
+  if (G >= 8) v += fz_dpp_i<RR_HALF_MIRROR, 0xF>(v, v);
+  if (G >= 16) v += fz_dpp_i<RR_MIRROR, 0xF>(v, v);
+  return v;
+}
+
+struct ReportEmit {                                        // where a row's values go (both report kernels), by id
+  const ReportArgs& A; double* hotF; uint32_t* hot1; uint32_t* hot2; int Hs; double* hotL;
+  __device__ __forceinline__ void conf(uint32_t id, double v) const {
+    if (A.g_conf_lo) {
+      double hi, lo;
+      exact_split01(v, hi, lo);
+      if ((int)id < Hs) { lds_add(&hotF[id], hi); if (lo != 0.0) lds_add(&hotL[id], lo); }
+      else { unsafeAtomicAdd(&A.g_conf[id], hi); if (lo != 0.0) unsafeAtomicAdd(&A.g_conf_lo[id], lo); }
+      return;
+    }
+    if ((int)id < Hs) lds_add(&hotF[id], v);
+    else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_conf[id], v);
+  }
+  __device__ __forceinline__ void one(uint32_t id) const {           // the row's only best hit
+    if ((int)id < Hs) atomicAdd(&hot1[id], 1u);
+    else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_n1[id], 1.0);
+  }
+  __device__ __forceinline__ void tie(uint32_t id, int nb, double share) const {   // one of nb > 1 best hits
+    if (nb == 2) {
+      if ((int)id < Hs) atomicAdd(&hot2[id], 1u);
+      else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_n2[id], 1.0);
+    } else if (A.g_avgt_lo) {
+      double hi, lo;
+      exact_split01(share, hi, lo);
+      unsafeAtomicAdd(&A.g_avgt[id], hi);
+      if (lo != 0.0) unsafeAtomicAdd(&A.g_avgt_lo[id], lo);
+    } else {
+      unsafeAtomicAdd(&A.g_avgt[id], share);
+    }
+  }
+};
+
+// threads per workgroup: the pass over the final z needs ~92 VGPRs (pi*theta gathers in flight) and spills under the 128 of a 1024-thread
+// workgroup (15.6 vs 5.3 ms); the pass over the initial z needs 68 and gains from 16 waves per CU instead of 8 (7.8 -> 6.9 ms with its tie list)
+constexpr int rr_nt(bool init) { return init ? 1024 : 512; }
+template <int G, int E, bool INIT>
+__global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
+  static_assert(E == 8 || E == 16, "entries per lane");
+  extern __shared__ double rr_lds[];   // [lut_len] score table | [HC] pi*theta | [Hs] conf (f64) | [Hs] single winners | [Hs] two-way ties (u32)
+  double* const lutS = rr_lds;
+  double* const cH = lutS + A.lut_len;
+  double* const hotF = cH + A.HC;
+  uint32_t* const hot1 = reinterpret_cast<uint32_t*>(hotF + A.Hs);
+  uint32_t* const hot2 = hot1 + A.Hs;
+  double* const hotL = reinterpret_cast<double*>(hot2 + A.Hs);   // (only with g_conf_lo)
+  if (A.g_conf_lo) for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) hotL[t] = 0.0;
+  for (int t = threadIdx.x; t < A.lut_len; t += blockDim.x) lutS[t] = A.lut[t];
+  if (!INIT) for (int t = threadIdx.x; t < A.HC; t += blockDim.x) cH[t] = A.cnat2[t];
+  for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) { hotF[t] = 0.0; hot1[t] = 0u; hot2[t] = 0u; }
+  __syncthreads();
+  const ReportEmit EM{A, hotF, hot1, hot2, A.Hs, hotL};
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  const int64_t stride = (int64_t)gridDim.x * ngrp;
+  const int64_t nit = (A.N + stride - 1) / stride;
+  const bool one_winner = A.thresh > 0.51;                // an entry with z >= thresh is then the row's unique best hit
+  struct Ip { int64_t s; int len; };
+  struct Ent { rr_u32x4_a2 id[E / 8]; rr_u32x4_a2 cd[E / 8]; };   // 8 ids / 8 codes per 16-byte word
+  auto load_ip = [&](int64_t it) -> Ip {
+    const int64_t row = it * stride + (int64_t)blockIdx.x * ngrp + grp;
+    const int64_t rc = row < A.N ? row : A.N - 1;        // clamped, never branched around
+    const rr_i64x2_a8 se = *reinterpret_cast<const rr_i64x2_a8*>(A.indptr + rc);   // indptr[rc], indptr[rc + 1]
+    Ip r; r.s = se.x; r.len = row < A.N ? (int)min<int64_t>(se.y - se.x, 0x7FFFFFFF) : 0;
+    return r;
+  };
+  auto load_ent = [&](const Ip& p) -> Ent {
+    // lanes past the row's end read the entries that follow it (the arrays carry TS_ENTRY_PAD entries of padding: never
+    // out of bounds)
+    const int64_t k = p.s + E * gl;
+    Ent t;
+#pragma unroll
+    for (int q = 0; q < E / 8; ++q) {
+      t.id[q] = *reinterpret_cast<const rr_u32x4_a2*>(A.rid + k + 8 * q);
+      t.cd[q] = *reinterpret_cast<const rr_u32x4_a2*>(A.raw + k + 8 * q);
+    }
+    return t;
+  };
+  auto half = [](const rr_u32x4_a2* w, int j) -> uint32_t {          // 16-bit element j of the packed words
+    const uint32_t x = w[j / 8][(j / 2) & 3];
+    return (j & 1) ? x >> 16 : x & 0xFFFFu;
+  };
+  // prep: the lane's numerators (the gathers that depend on the entries); finish: everything else.  The loop issues the
+  // NEXT rows' loads between the two, so that waiting for the gathers (loads return in order) does not wait for the
+  // prefetch as well.
+  struct Prep { double n[E]; };
+  auto row_prep = [&](const Ip& p, const Ent& t) -> Prep {
+    const int k0 = E * gl;
+    const bool amb = p.len > 1;                           // ambiguous rows: pi*theta, unique rows: pi (model.py:706-714)
+    Prep q;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const bool v = k0 + j < p.len;
+      double x = lutS[v ? half(t.cd, j) : 0u];             // (lut[0] = expm1(0) = 0: a lane past the row's end holds zeros)
+      if (!INIT) {
+        const uint32_t id = v ? half(t.id, j) : 0u;
+        const bool hot = amb && (int)id < A.HC;
+        // UNCONDITIONAL gather: hot lanes read element 0 (one line for all of them) — a branch around the load would
+        // cost the compiler its count of the loads in flight
+        const double cg = A.cnat2[hot ? 0u : id + (amb ? 0u : (uint32_t)A.IDN)];
+        const double cl = cH[hot ? id : 0u];
+        x = x * (hot ? cl : cg);
+      }
+      q.n[j] = x;
+    }
+    return q;
+  };
+  auto row_finish = [&](int64_t row, const Ip& p, const Ent& t, const Prep& q) {
+    const int k0 = E * gl;
+    const double* n = q.n;
+    // row sum and the largest numerator of z's pattern (INIT: every stored entry; else the non-zero products, model.py:720)
+    double s = 0.0, nm = -1.0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      s += n[j];
+      const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+      nm = in ? fmax(nm, n[j]) : nm;
+    }
+    const double r = recip0(rr_sum<G>(s));
+    nm = rr_max<G>(nm);
+    const bool any = nm >= 0.0;
+    const double zmax = any ? nm * r : -1.0;               // = max_j fl(n_j r): rounding is monotone
+    int nbl = 0; uint32_t wid = 0u;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+      const bool b = in && (n[j] * r == zmax);
+      nbl += b ? 1 : 0;
+      wid = b ? half(t.id, j) : wid;
+    }
+    const int nb = rr_sum_i<G>(nbl);
+    if (gl == 0 && row < A.N && !(A.dbg & 2)) A.nbest[row] = any ? nb : 0;
+    if (one_winner) {
+      if (nbl != 0 && nb == 1) {                           // this lane holds the row's only best hit
+        EM.one(wid);
+        if (zmax >= A.thresh) { const double vc = zmax * recip0(zmax); if (vc != 0.0) EM.conf(wid, vc); }   // vsum = the winner's z
+      }
+      if (__builtin_amdgcn_ballot_w64(nb > 1) != 0ull && !(A.dbg & 4)) {   // tied rows
+        if (nbl == 1 && nb == 2) EM.tie(wid, 2, 0.5);      // (the usual tie: two best hits, this lane holds one of them)
+        if (__builtin_amdgcn_ballot_w64(nb > 1 && !(nbl == 1 && nb == 2) && nbl != 0) != 0ull) {
+          const double share = 1.0 * recip0((double)nb);
+#pragma unroll
+          for (int j = 0; j < E; ++j) {
+            const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+            if (nb > 1 && !(nbl == 1 && nb == 2) && in && n[j] * r == zmax) EM.tie(half(t.id, j), nb, share);
+          }
+        }
+      }
+    } else {                                               // conf_prob <= 0.5: several entries of a row may pass the threshold
+      double vs = 0.0;
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+        const double z = n[j] * r;
+        if (in && z >= A.thresh) vs += z;
+      }
+      const double rv = recip0(rr_sum<G>(vs)), share = 1.0 * recip0((double)nb);
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+        const double z = n[j] * r;
+        if (!in || !(z == zmax || z >= A.thresh)) continue;
+        const uint32_t id = half(t.id, j);
+        if (z >= A.thresh) { const double vc = z * rv; if (vc != 0.0) EM.conf(id, vc); }
+        if (z == zmax) { if (nb == 1) EM.one(id); else EM.tie(id, nb, share); }
+      }
+    }
+  };
+  if (nit > 0) {
+    Ip ip0 = load_ip(0), ip1 = load_ip(1);
+    Ent e0 = load_ent(ip0);
+    for (int64_t it = 0; it < nit; ++it) {
+      const int64_t row = it * stride + (int64_t)blockIdx.x * ngrp + grp;
+      const bool defer = ip0.len > G * E;                  // left to k_report_slow
+      Ip cur = ip0;
+      if (defer) cur.len = 0;
+      const Prep q = row_prep(cur, e0);                    // gathers of this row first ...
+      __builtin_amdgcn_sched_barrier(0);
+      const Ent e1 = load_ent(ip1);                        // ... then the loads of the next rows: they have this row's
+      const Ip ip2 = load_ip(it + 2);                      //     arithmetic to arrive in
+      __builtin_amdgcn_sched_barrier(0);
+      if (defer) {
+        if (gl == 0) A.defer_rows[atomicAdd(A.defer_n, 1ull)] = (int32_t)row;
+      } else {
+        row_finish(row, cur, e0, q);
+      }
+      ip0 = ip1; ip1 = ip2; e0 = e1;
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) {
+    const double v = hotF[t];
+    const uint32_t c1 = hot1[t], c2 = hot2[t];
+    if (v != 0.0) unsafeAtomicAdd(&A.g_conf[t], v);
+    if (A.g_conf_lo) { const double l = hotL[t]; if (l != 0.0) unsafeAtomicAdd(&A.g_conf_lo[t], l); }
+    if (c1) unsafeAtomicAdd(&A.g_n1[t], (double)c1);
+    if (c2) unsafeAtomicAdd(&A.g_n2[t], (double)c2);
+  }
+}
+
+// the rows k_report_rows left: any length, sweeps of 16 entries, one 16-lane group per row
+template <bool INIT>
+__global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
+  constexpr int G = 16;
+  const ReportEmit EM{A, nullptr, nullptr, nullptr, 0, nullptr};  // (no LDS slots here: a handful of rows)
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  const int64_t nd = (int64_t)*A.defer_n;
+  for (int64_t d = (int64_t)blockIdx.x * ngrp + grp; d < nd; d += (int64_t)gridDim.x * ngrp) {
+    const int64_t row = A.defer_rows[d];
+    const int64_t s = A.indptr[row];
+    const int len = (int)(A.indptr[row + 1] - s);
+    const uint32_t coff = len > 1 ? 0u : (uint32_t)A.IDN;
+    auto numer = [&](int k) -> double {
+      double x = A.lut[A.raw[s + k]];
+      if (!INIT) x = x * A.cnat2[A.rid[s + k] + coff];
+      return x;
+    };
+    double y = 0.0;
+    for (int k = gl; k < len; k += G) y += numer(k);
+    const double r = recip0(sg_sum<G>(y));
+    double zmax = -1.0, vs = 0.0; int cnt = 0;
+    for (int k = gl; k < len; k += G) {
+      const double n = numer(k);
+      if (INIT || n != 0.0) { const double z = n * r; zmax = fmax(zmax, z); ++cnt; if (z >= A.thresh) vs += z; }
+    }
+    zmax = sg_max<G>(zmax); cnt = sg_sum_i<G>(cnt);
+    const double vsum = sg_sum<G>(vs);
+    int nb = 0;
+    for (int k = gl; k < len; k += G) { const double n = numer(k); if ((INIT || n != 0.0) && n * r == zmax) ++nb; }
+    nb = sg_sum_i<G>(nb);
+    if (gl == 0) A.nbest[row] = cnt ? nb : 0;
+    const double share = 1.0 * recip0((double)nb);
+    for (int k = gl; k < len; k += G) {
+      const double n = numer(k);
+      if (!(INIT || n != 0.0)) continue;
+      const double z = n * r;
+      if (!(z == zmax || z >= A.thresh)) continue;
+      const uint32_t id = A.rid[s + k];
+      if (z >= A.thresh) { const double vc = z * recip0(vsum); if (vc != 0.0) EM.conf(id, vc); }
+      if (z == zmax) { if (nb == 1) EM.one(id); else EM.tie(id, nb, share); }
+    }
+  }
+}
+// by id -> by column: out[0..K) = conf, out[K..2K) = exclude, out[2K..3K) = average = n1 + n2 / 2 + the wider ties' shares
+__global__ void k_report_finish(int IDN, int K, const int32_t* __restrict__ col_of_id, const double* __restrict__ g_conf,
+                                const double* __restrict__ g_n1, const double* __restrict__ g_n2, const double* __restrict__ g_avgt,
+                                const double* __restrict__ g_conf_lo, const double* __restrict__ g_avgt_lo, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= IDN) return;
+  const int j = col_of_id[i];
+  if (j < 0) return;
+  const double cf = g_conf_lo ? g_conf[i] + g_conf_lo[i] : g_conf[i], av = g_avgt_lo ? g_avgt[i] + g_avgt_lo[i] : g_avgt[i];
+  out[j] = cf; out[K + j] = g_n1[i]; out[2 * (int64_t)K + j] = (g_n1[i] + 0.5 * g_n2[i]) + av;
+}
+__global__ void k_cnat2_id(int IDN, const int32_t* __restrict__ col_of_id, const double* __restrict__ pi, const double* __restrict__ theta,
+                           double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= IDN) return;
+  const int j = col_of_id[i];
+  out[i] = j >= 0 ? pi[j] * theta[j] : 0.0; out[IDN + i] = j >= 0 ? pi[j] : 0.0;
+}
+
+// mstep(z) on caller-supplied z (model.py:724-742): colsums[j] = sum_i (z_ij * w_i) * Y_i
+__global__ __launch_bounds__(256) void k_mstep_rows(RowPassArgs A, const double* __restrict__ zin) {
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < A.N; row += (int64_t)gridDim.x * subs) {
+    const int64_t s = A.indptr[row], e = A.indptr[row + 1];
+    if (e - s < 2) continue;
+    int m = 0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) m = max(m, (int)A.raw[k]);
+    m = sg_max_i<RP_SUB>(m);
+    const double w = A.lut[m];
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      double v = zin[k] * w;
+      if (v != 0.0) unsafeAtomicAdd(&A.colsums[A.indices[k]], v);
+    }
+  }
+}
+
+// calculate_lnl(z, pi, theta) on caller-supplied z (model.py:744-760)
+__global__ __launch_bounds__(256) void k_lnl_rows(RowPassArgs A, const double* __restrict__ zin,
+                                                  double* __restrict__ part) {
+  __shared__ double scratch[16];
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  double acc = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < A.N; row += (int64_t)gridDim.x * subs) {
+    const int64_t s = A.indptr[row], e = A.indptr[row + 1];
+    const bool amb = (e - s) > 1;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      int col = A.indices[k];
+      double c = amb ? A.pi[col] * A.theta[col] : A.pi[col];
+      double inner = A.lut[A.raw[k]] * c;
+      double z = zin[k];
+      if (inner != 0.0 && z != 0.0) acc += z * ts_log1p_pos(inner);
+    }
+  }
+  double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// closed forms of mstep without committing (model.py:733-740)
+__global__ void k_hats(int K, const double* __restrict__ ts, const double* __restrict__ pisum0, double theta_pw,
+                       double theta_den, double pi_pw, double pi_den, double* __restrict__ pi_hat,
+                       double* __restrict__ theta_hat) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  theta_hat[j] = (ts[j] + theta_pw) / theta_den;
+  pi_hat[j] = ((pisum0[j] + ts[j]) + pi_pw) / pi_den;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// results
+// ---------------------------------------------------------------------------
+__global__ void k_cnat(int K, const double* __restrict__ pi, const double* __restrict__ theta, double* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < K) out[j] = pi[j] * theta[j];
+}
+// pi*theta per column for the row passes (A.pi / A.theta must be set)
+static int make_cnat(tsem_ctx* h, RowPassArgs& A) {
+  if (!h->d_cnat) TSEM_ALLOC(h->d_cnat, h->K);
+  k_cnat<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, A.pi, A.theta, h->d_cnat);
+  TSEM_HIP(hipGetLastError());
+  A.cnat = h->d_cnat;
+  return TSEM_OK;
+}
+
+static int rowpass_args(tsem_ctx* h, int which, RowPassArgs& A) {
+  A.N = h->N; A.K = h->K; A.indptr = h->d_indptr; A.indices = h->d_indices; A.raw = h->d_raw; A.lut = h->d_lut;
+  A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr; A.group = nullptr; A.rowlist = nullptr; A.nlist = 0; A.colmap = nullptr; A.col_of_pc = nullptr; A.P = 0; A.Kp = 0; A.Hs = 0;
+  A.zin = nullptr; A.cnat = nullptr; A.lut_len = h->lut_len <= 2048 ? h->lut_len : 0;   // (larger tables stay in global memory)
+  if (which == TSEM_Z_USER) {
+    if (!h->d_user_z) TSEM_FAIL(TSEM_ERR_ARG, "TSEM_Z_USER without tsem_set_user_z");
+    A.pi = h->d_pi; A.theta = h->d_theta; A.zin = h->d_user_z;
+    return TSEM_OK;
+  }
+  if (which == TSEM_Z_INITIAL) { A.pi = nullptr; A.theta = nullptr; }
+  else if (which == TSEM_Z_PREV) { A.pi = h->d_pi_prev; A.theta = h->d_theta_prev; }
+  else if (which == TSEM_Z_CUR) { A.pi = h->d_pi; A.theta = h->d_theta; }
+  else TSEM_FAIL(TSEM_ERR_ARG, "bad `which`");
+  if (which != TSEM_Z_INITIAL && !h->have_model) TSEM_FAIL(TSEM_ERR_ARG, "model not set");
+  if (A.pi) { if (int rc = make_cnat(h, A)) return rc; }
+  return TSEM_OK;
+}
+int tsem_rowpass_grid(tsem_ctx* h) { return (int)std::min<int64_t>(8192, std::max<int64_t>(1, (h->N + 15) / 16)); }
+
+static int export_z_with(tsem_ctx* h, RowPassArgs& A, double* z) {
+  double* d_z = nullptr;
+  TSEM_ALLOC(d_z, h->nnz);
+  A.zout = d_z;
+  if (h->N) k_rowpass<RP_EXPORT_Z><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  if (h->nnz) TSEM_HIP(hipMemcpyAsync(z, d_z, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_z);
+  return TSEM_OK;
+}
+
+int tsem_export_z(tsem_ctx* h, int which, double* z) {
+  if (!h || !h->d_indptr || !z) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  return export_z_with(h, A, z);
+}
+
+int tsem_set_user_z(tsem_ctx* h, const double* z) {
+  if (!h || !h->d_indptr) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (!z) { dfree(h->d_user_z); return TSEM_OK; }
+  TSEM_ALLOC(h->d_user_z, h->nnz);
+  if (h->nnz) TSEM_HIP(hipMemcpy(h->d_user_z, z, sizeof(double) * h->nnz, hipMemcpyHostToDevice));
+  return TSEM_OK;
+}
+
+int tsem_estep(tsem_ctx* h, const double* pi, const double* theta, double* z) {
+  if (!h || !h->have_model || !pi || !theta || !z) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipMemcpyAsync(h->d_tmp_pi, pi, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_tmp_theta, theta, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
+  A.pi = h->d_tmp_pi; A.theta = h->d_tmp_theta;
+  if (int rc = make_cnat(h, A)) return rc;
+  return export_z_with(h, A, z);
+}
+
+int tsem_best_counts(tsem_ctx* h, int which, int32_t* nbest) {
+  if (!h || !h->d_indptr || !nbest) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  int32_t* d_nb = nullptr;
+  TSEM_ALLOC(d_nb, h->N);
+  A.nbest = d_nb;
+  if (h->N) k_rowpass<RP_BEST><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  if (h->N) TSEM_HIP(hipMemcpyAsync(nbest, d_nb, sizeof(int32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_nb);
+  return TSEM_OK;
+}
+
+struct TiedRow {                                            // predicate of tsem_best_ties: rows with several best hits
+  const int32_t* nb;
+  __device__ bool operator()(const int32_t& i) const { return nb[i] > 1; }
+};
+__global__ void k_gather_i32(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ src, int32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+
+int tsem_best_ties(tsem_ctx* h, int which, int64_t cap, int32_t* rows, int32_t* counts, int64_t* n_out) {
+  if (!h || !h->d_indptr || !n_out || cap < 0 || (cap && (!rows || !counts))) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  *n_out = 0;
+  if (h->N == 0) return TSEM_OK;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  int32_t *d_nb = nullptr, *d_rows = nullptr, *d_cnt = nullptr;
+  unsigned long long* d_n = nullptr;
+  TSEM_ALLOC(d_nb, h->N); TSEM_ALLOC(d_rows, h->N); TSEM_ALLOC(d_n, 1);
+  A.nbest = d_nb;
+  k_rowpass<RP_BEST><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  size_t tb = 0;
+  TiedRow pred{d_nb};
+  rocprim::counting_iterator<int32_t> first(0);
+  TSEM_HIP(rocprim::select(nullptr, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
+  void* tmp = nullptr;
+  TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+  TSEM_HIP(rocprim::select(tmp, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
+  unsigned long long n = 0;
+  TSEM_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(tmp);
+  *n_out = (int64_t)n;
+  int rc = TSEM_OK;
+  if ((int64_t)n > cap) {
+    h->err = "tsem_best_ties: more tied rows than the caller's arrays hold (call again with the returned count)";
+    rc = TSEM_ERR_ARG;
+  } else if (n) {
+    TSEM_ALLOC(d_cnt, n);
+    k_gather_i32<<<cdiv64((int64_t)n, 256), 256, 0, h->stream>>>((int64_t)n, d_rows, d_nb, d_cnt);
+    TSEM_HIP(hipMemcpyAsync(rows, d_rows, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(counts, d_cnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+  }
+  (void)hipFree(d_nb); (void)hipFree(d_rows); (void)hipFree(d_n);
+  if (d_cnt) (void)hipFree(d_cnt);
+  return rc;
+}
+
+// option "reproducible": a second, zeroed buffer for the low pieces of the values a row pass sums (exact_split01);
+// rowpass_lo_end adds it to the sums and frees it
+static int rowpass_lo_begin(tsem_ctx* h, RowPassArgs& A, int64_t n, double** lo) {
+  *lo = nullptr;
+  if (!h->opt_reproducible || n <= 0) return TSEM_OK;
+  TSEM_ALLOC(*lo, n);
+  TSEM_HIP(hipMemsetAsync(*lo, 0, sizeof(double) * n, h->stream));
+  A.colsums_lo = *lo;
+  return TSEM_OK;
+}
+static int rowpass_lo_end(tsem_ctx* h, double* sums, double* lo, int64_t n) {
+  if (!lo) return TSEM_OK;
+  k_add_lo<<<cdiv64(n, 256), 256, 0, h->stream>>>(n, sums, lo);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(lo);
+  return TSEM_OK;
+}
+
+int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks, double* colsums,
+                  double* mask) {
+  if (!h || !h->d_indptr || !colsums) return TSEM_ERR_ARG;
+  if (method < TSEM_RA_EXCLUDE || method > TSEM_RA_ALL) TSEM_FAIL(TSEM_ERR_ARG, "bad reassign method");
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  // Two of the report's columns do not depend on the posteriors and were counted while the matrix was set up
+  // (option "report_shortcuts", default 1; the row pass gives the same numbers, tests/test_gpu_round2.py):
+  //   all, initial=True (model.py:860-862 on Q.norm(1)): one per stored entry with a positive score = the column's
+  //     entry count (every score > 0: z = q / rowsum > 0 for every entry);
+  //   unique (model.py:857-859): ceil(z) over the single-entry rows = the column's number of such rows with a positive
+  //     score — z = n * (1/n) in (0, 1] whenever n = q * pi_j is a normal positive number, which holds for the
+  //     parameters the M-step produces (pi_j >= pisum0_j / W_tot > 1e-60 for a column that has such a row).
+  if (!mask && h->opt_shortcuts && h->d_ucount && h->have_rowstats && which != TSEM_Z_USER) {
+    uint32_t has_zero = 0;
+    TSEM_HIP(hipMemcpyAsync(&has_zero, h->d_ucount + h->K, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (method == TSEM_RA_ALL && which == TSEM_Z_INITIAL && !has_zero && h->d_colcount) {
+      std::vector<unsigned long long> c(h->K);
+      TSEM_HIP(hipMemcpy(c.data(), h->d_colcount, sizeof(unsigned long long) * h->K, hipMemcpyDeviceToHost));
+      for (int j = 0; j < h->K; ++j) colsums[j] = (double)c[j];
+      return TSEM_OK;
+    }
+    if (method == TSEM_RA_UNIQUE && (which == TSEM_Z_INITIAL || (which == TSEM_Z_CUR ? h->em_cur : h->em_prev))) {
+      std::vector<uint32_t> c(h->K);
+      TSEM_HIP(hipMemcpy(c.data(), h->d_ucount, sizeof(uint32_t) * h->K, hipMemcpyDeviceToHost));
+      for (int j = 0; j < h->K; ++j) colsums[j] = (double)c[j];
+      return TSEM_OK;
+    }
+  }
+  A.method = method; A.thresh = thresh;
+  double *d_cs = nullptr, *d_mask = nullptr;
+  int32_t* d_picks = nullptr;
+  TSEM_ALLOC(d_cs, h->K);
+  TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
+  if (mask) TSEM_ALLOC(d_mask, h->nnz);
+  if (method == TSEM_RA_CHOOSE && picks) {
+    TSEM_ALLOC(d_picks, h->N);
+    if (h->N) TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+  }
+  A.colsums = d_cs; A.zout = d_mask; A.picks = d_picks;
+  double* d_lo = nullptr;
+  if (int rc = rowpass_lo_begin(h, A, h->K, &d_lo)) return rc;
+  if (h->N && h->d_colmap && h->d_col_of_pc && h->P > 0) {
+    // hot slots of every part in LDS.  `all` emits one value per stored entry, so it wants as many slots as fit: one
+    // 1024-thread workgroup per CU with ~150 KB of accumulators.  The other modes emit at most a few values per ROW
+    // and the pass is bound by the latency of its dependent loads (row pointers -> entries), not by atomics: two
+    // workgroups per CU (32 waves) with half the slots each (option "rowpass_wgs").
+    const int wgs = (method == TSEM_RA_ALL || h->opt_rowpass_wgs < 2) ? 1 : 2;
+    A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;
+    A.Hs = std::max(0, std::min(h->Kp, (int)((TS_LDS_MAX / wgs - 8192 / wgs - 1024 - A.lut_len * 8) / 8 / h->P)));
+    TSEM_HIP(hipFuncSetAttribute((const void*)k_rowpass<RP_REASSIGN>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+    void (*kern)(RowPassArgs) = k_rowpass<RP_REASSIGN>;
+    switch (method) {
+      case TSEM_RA_EXCLUDE: kern = k_rowpass<RP_REASSIGN, TSEM_RA_EXCLUDE>; break;
+      case TSEM_RA_CHOOSE:  kern = k_rowpass<RP_REASSIGN, TSEM_RA_CHOOSE>; break;
+      case TSEM_RA_AVERAGE: kern = k_rowpass<RP_REASSIGN, TSEM_RA_AVERAGE>; break;
+      case TSEM_RA_CONF:    kern = k_rowpass<RP_REASSIGN, TSEM_RA_CONF>; break;
+      case TSEM_RA_UNIQUE:  kern = k_rowpass<RP_REASSIGN, TSEM_RA_UNIQUE>; break;
+      case TSEM_RA_ALL:     kern = k_rowpass<RP_REASSIGN, TSEM_RA_ALL>; break;
+    }
+    TSEM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+    kern<<<h->n_cu * wgs, 1024, (size_t)(A.P * A.Hs + A.lut_len) * 8, h->stream>>>(A);
+  } else if (h->N) {
+    k_rowpass<RP_REASSIGN><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+  }
+  TSEM_HIP(hipGetLastError());
+  if (int rc = rowpass_lo_end(h, d_cs, d_lo, h->K)) return rc;
+  TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  if (mask && h->nnz) TSEM_HIP(hipMemcpyAsync(mask, d_mask, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_cs);
+  if (d_mask) (void)hipFree(d_mask);
+  if (d_picks) (void)hipFree(d_picks);
+  return TSEM_OK;
+}
+
+// One pass for the column sums output_report takes from one z (model.py:432-457): conf | exclude | average, and the rows
+// with several best hits (the only rows `choose` treats differently from `exclude`) compacted in row order.
+int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, int64_t* n_ties) {
+  if (!h || !h->d_indptr || !out3K) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;
+  if (n_ties) *n_ties = 0;
+  const int K = h->K;
+  double* d_cs = nullptr;
+  TSEM_ALLOC(d_cs, 3 * (int64_t)K);
+  TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * 3 * K, h->stream));
+  if (h->N) {
+    // per-row best-hit counts, the compacted tie list and the scan's scratch stay allocated between reports (two N-sized
+    // vectors: allocating and freeing them cost more than the pass's kernels)
+    if (!h->d_rep_nb) { TSEM_ALLOC(h->d_rep_nb, h->N); TSEM_ALLOC(h->d_rep_rows, h->N); TSEM_ALLOC(h->d_rep_n, 1); }
+    int32_t *const d_nb = h->d_rep_nb, *const d_rows = h->d_rep_rows;
+    unsigned long long* const d_n = h->d_rep_n;
+    A.thresh = thresh; A.colsums = d_cs; A.nbest = d_nb;
+    void (*kern)(RowPassArgs) = k_rowpass<RP_REPORT>;
+    if (h->opt_report_kernel != 0 && which != TSEM_Z_USER && h->d_rid16 && h->d_col_of_id && A.lut_len > 0) {
+      // the streaming report kernel (k_report_rows): lanes per row x entries per lane = the smallest capacity that
+      // fewer than 0.5 % of the rows exceed (row-length histogram of tsem_rowstats); the rest goes to k_report_slow
+      const int IDN = h->Kpad;
+      ReportArgs R;
+      R.N = h->N; R.nnz = h->nnz; R.K = K; R.IDN = IDN; R.indptr = h->d_indptr; R.rid = h->d_rid16; R.raw = h->d_raw;
+      R.lut = h->d_lut; R.lut_len = A.lut_len; R.cnat2 = nullptr; R.thresh = thresh; R.nbest = d_nb;
+      const bool init = A.pi == nullptr;
+      double *d_g = nullptr, *d_c2 = nullptr;
+      const bool exact = h->opt_reproducible != 0;
+      TSEM_ALLOC(d_g, 6 * (int64_t)IDN);
+      TSEM_HIP(hipMemsetAsync(d_g, 0, sizeof(double) * 6 * IDN, h->stream));
+      if (!init) {
+        TSEM_ALLOC(d_c2, 2 * (int64_t)IDN);
+        k_cnat2_id<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, h->d_col_of_id, A.pi, A.theta, d_c2);
+        R.cnat2 = d_c2;
+      }
+      R.g_conf = d_g; R.g_n1 = d_g + IDN; R.g_n2 = d_g + 2 * (int64_t)IDN; R.g_avgt = d_g + 3 * (int64_t)IDN;
+      if (exact) { R.g_conf_lo = d_g + 4 * (int64_t)IDN; R.g_avgt_lo = d_g + 5 * (int64_t)IDN; }
+      // LDS: one workgroup of rr_nt() threads per CU (or two, option rowpass_wgs).  The final z wants pi*theta of as many
+      // ids as fit (8 B each) next to a few thousand accumulator slots (16 B each); the initial z has no pi*theta.
+      const int wgs = h->opt_rowpass_wgs >= 2 && h->opt_report_wgs2 ? 2 : 1;
+      const int lds_avail = TS_LDS_MAX / wgs - 2048 - R.lut_len * 8;
+      const int slot_bytes = exact ? 24 : 16;                // conf (f64) + two counters (+ the low pieces)
+      R.Hs = std::min(IDN, init ? lds_avail / slot_bytes : std::min(3072, lds_avail / slot_bytes / 4));
+      R.HC = init ? 0 : std::max(0, std::min(IDN, (lds_avail - R.Hs * slot_bytes) / 8));
+      int cap = 256;                                       // G x E
+      if (h->opt_report_lanes > 0) {
+        cap = (int)h->opt_report_lanes;
+      } else if (h->have_rowstats) {
+        for (int q = 0; q < 6; ++q)
+          if ((double)h->len_gt[q] <= 0.005 * (double)h->N) { cap = 8 << q; break; }
+      }
+      void (*rk)(ReportArgs) = nullptr;
+#define RK(G_, E_) (init ? k_report_rows<G_, E_, true> : k_report_rows<G_, E_, false>)
+      if (cap <= 8) rk = RK(1, 8); else if (cap <= 16) rk = RK(1, 16); else if (cap <= 32) rk = RK(2, 16);
+      else if (cap <= 64) rk = RK(4, 16); else if (cap <= 128) rk = RK(8, 16); else rk = RK(16, 16);
+#undef RK
+      TSEM_HIP(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      R.dbg = (int)h->opt_report_dbg;
+      R.defer_rows = d_rows; R.defer_n = d_n;               // (d_rows is the tie list later: the slow kernel is done with it by then)
+      TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
+      rk<<<h->n_cu * wgs, rr_nt(init), (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * slot_bytes, h->stream>>>(R);
+      TSEM_HIP(hipGetLastError());
+      if (init) k_report_slow<true><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
+      else k_report_slow<false><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
+      TSEM_HIP(hipGetLastError());
+      k_report_finish<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, K, h->d_col_of_id, R.g_conf, R.g_n1, R.g_n2, R.g_avgt, R.g_conf_lo, R.g_avgt_lo, d_cs);
+      TSEM_HIP(hipGetLastError());
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      (void)hipFree(d_g);
+      if (d_c2) (void)hipFree(d_c2);
+    } else if (h->d_colmap && h->d_col_of_pc && h->P > 0) {
+      const int wgs = h->opt_rowpass_wgs < 2 ? 1 : 2;
+      A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;
+      A.Hs = std::max(0, std::min(h->Kp, (int)((TS_LDS_MAX / wgs - 8192 / wgs - 1024 - A.lut_len * 8) / 8 / h->P / 3)));
+      TSEM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      double* d_lo = nullptr;
+      if (int rc = rowpass_lo_begin(h, A, 3 * (int64_t)K, &d_lo)) return rc;
+      kern<<<h->n_cu * wgs, 1024, (size_t)(3 * A.P * A.Hs + A.lut_len) * 8, h->stream>>>(A);
+      TSEM_HIP(hipGetLastError());
+      if (int rc = rowpass_lo_end(h, d_cs, d_lo, 3 * (int64_t)K)) return rc;
+    } else {
+      double* d_lo = nullptr;
+      if (int rc = rowpass_lo_begin(h, A, 3 * (int64_t)K, &d_lo)) return rc;
+      kern<<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+      TSEM_HIP(hipGetLastError());
+      if (int rc = rowpass_lo_end(h, d_cs, d_lo, 3 * (int64_t)K)) return rc;
+    }
+    TSEM_HIP(hipGetLastError());
+    size_t tb = 0;
+    TiedRow pred{d_nb};
+    rocprim::counting_iterator<int32_t> first(0);
+    TSEM_HIP(rocprim::select(nullptr, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
+    if (h->rep_tmp_bytes < tb || !h->d_rep_tmp) {
+      if (h->d_rep_tmp) (void)hipFree(h->d_rep_tmp);
+      h->d_rep_tmp = nullptr; h->rep_tmp_bytes = 0;
+      TSEM_HIP(hipMalloc(&h->d_rep_tmp, tb ? tb : 1));
+      h->rep_tmp_bytes = tb;
+    }
+    void* const tmp = h->d_rep_tmp;
+    TSEM_HIP(rocprim::select(tmp, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
+    unsigned long long n = 0;
+    TSEM_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(out3K, d_cs, sizeof(double) * 3 * K, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (n) {
+      TSEM_ALLOC(h->d_tie_rows, n); TSEM_ALLOC(h->d_tie_cnt, n);
+      TSEM_HIP(hipMemcpyAsync(h->d_tie_rows, d_rows, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, h->stream));
+      k_gather_i32<<<cdiv64((int64_t)n, 256), 256, 0, h->stream>>>((int64_t)n, d_rows, d_nb, h->d_tie_cnt);
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+    }
+    h->n_ties = (int64_t)n;
+    if (n_ties) *n_ties = (int64_t)n;
+  } else {
+    for (int64_t j = 0; j < 3 * (int64_t)K; ++j) out3K[j] = 0.0;
+  }
+  (void)hipFree(d_cs);
+  return TSEM_OK;
+}
+
+int tsem_report_ties(tsem_ctx* h, int64_t cap, int32_t* rows, int32_t* counts) {
+  if (!h || cap < 0) return TSEM_ERR_ARG;
+  if (h->n_ties > cap) TSEM_FAIL(TSEM_ERR_ARG, "tsem_report_ties: the arrays are shorter than the tie count of the last tsem_report_colsums");
+  if (h->n_ties == 0) return TSEM_OK;
+  if (!rows || !counts) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipMemcpyAsync(rows, h->d_tie_rows, sizeof(int32_t) * h->n_ties, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipMemcpyAsync(counts, h->d_tie_cnt, sizeof(int32_t) * h->n_ties, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return TSEM_OK;
+}
+
+// The contribution of a LIST of rows to reassign(method).sum(0): `choose` = `exclude` + the picked entries of the tied
+// rows (rows == NULL: the tie rows the last tsem_report_colsums left on the device; picks[i] belongs to list entry i).
+int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const int32_t* rows, const int32_t* picks,
+                       int64_t n, double* colsums) {
+  if (!h || !h->d_indptr || !colsums || n < 0) return TSEM_ERR_ARG;
+  if (method < TSEM_RA_EXCLUDE || method > TSEM_RA_ALL) TSEM_FAIL(TSEM_ERR_ARG, "bad reassign method");
+  if (!rows && n != h->n_ties) TSEM_FAIL(TSEM_ERR_ARG, "tsem_reassign_rows: rows == NULL needs n == the tie count of the last report");
+  if (int rc = ensure_device(h)) return rc;
+  for (int j = 0; j < h->K; ++j) colsums[j] = 0.0;
+  if (n == 0) return TSEM_OK;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  if (rows)
+    for (int64_t i = 0; i < n; ++i)
+      if (rows[i] < 0 || rows[i] >= h->N) TSEM_FAIL(TSEM_ERR_ARG, "tsem_reassign_rows: row out of range");
+  double* d_cs = nullptr;
+  int32_t *d_rows = nullptr, *d_picks = nullptr;
+  TSEM_ALLOC(d_cs, h->K);
+  TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
+  if (rows) {
+    TSEM_ALLOC(d_rows, n);
+    TSEM_HIP(hipMemcpyAsync(d_rows, rows, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  }
+  if (method == TSEM_RA_CHOOSE && picks) {
+    TSEM_ALLOC(d_picks, n);
+    TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  }
+  A.method = method; A.thresh = thresh; A.colsums = d_cs; A.picks = d_picks;
+  A.rowlist = rows ? d_rows : h->d_tie_rows; A.nlist = n;
+  const int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + 15) / 16));
+  double* d_lo = nullptr;
+  if (int rc = rowpass_lo_begin(h, A, h->K, &d_lo)) return rc;
+  k_rowpass<RP_REASSIGN><<<grid, 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  if (int rc = rowpass_lo_end(h, d_cs, d_lo, h->K)) return rc;
+  TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_cs);
+  if (d_rows) (void)hipFree(d_rows);
+  if (d_picks) (void)hipFree(d_picks);
+  return TSEM_OK;
+}
+
+int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks,
+                         const int32_t* group_of_row, int32_t n_groups, double* out) {
+  if (!h || !h->d_indptr || !group_of_row || !out || n_groups < 0) return TSEM_ERR_ARG;
+  if (method < TSEM_RA_EXCLUDE || method > TSEM_RA_ALL) TSEM_FAIL(TSEM_ERR_ARG, "bad reassign method");
+  if (int rc = ensure_device(h)) return rc;
+  for (int64_t i = 0; i < h->N; ++i)
+    if (group_of_row[i] >= n_groups) TSEM_FAIL(TSEM_ERR_ARG, "group_of_row entry out of range");
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  A.method = method; A.thresh = thresh;
+  const int64_t n_out = (int64_t)n_groups * h->K;
+  double* d_out = nullptr;
+  int32_t *d_picks = nullptr, *d_grp = nullptr;
+  TSEM_ALLOC(d_out, n_out);
+  TSEM_ALLOC(d_grp, h->N);
+  TSEM_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * std::max<int64_t>(1, n_out), h->stream));
+  if (h->N) TSEM_HIP(hipMemcpyAsync(d_grp, group_of_row, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+  if (method == TSEM_RA_CHOOSE && picks) {
+    TSEM_ALLOC(d_picks, h->N);
+    if (h->N) TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+  }
+  A.colsums = d_out; A.picks = d_picks; A.group = d_grp;
+  double* d_lo = nullptr;
+  if (int rc = rowpass_lo_begin(h, A, n_out, &d_lo)) return rc;
+  if (h->N && n_out) k_rowpass<RP_REASSIGN><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  if (int rc = rowpass_lo_end(h, d_out, d_lo, n_out)) return rc;
+  if (n_out) TSEM_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_out); (void)hipFree(d_grp);
+  if (d_picks) (void)hipFree(d_picks);
+  return TSEM_OK;
+}
+
+int tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat) {
+  if (!h || !h->have_model || !z || !pi_hat || !theta_hat) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
+  double *d_z = nullptr, *d_cs = nullptr;
+  TSEM_ALLOC(d_z, h->nnz);
+  TSEM_ALLOC(d_cs, h->K);
+  if (h->nnz) TSEM_HIP(hipMemcpyAsync(d_z, z, sizeof(double) * h->nnz, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
+  A.colsums = d_cs;
+  if (h->N) k_mstep_rows<<<tsem_rowpass_grid(h), 256, 0, h->stream>>>(A, d_z);
+  if (tsem_comm_on(h)) {                                         // row-sharded: thetasum over all ranks (model.py:731)
+    if (int rc = tsem_comm_allreduce_dev(h->comm, d_cs, (size_t)h->K, 0, h->stream, h->err)) { (void)hipFree(d_z); (void)hipFree(d_cs); return rc; }
+  }
+  const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;
+  k_hats<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, d_cs, h->d_pisum0, tpw, h->W_amb + tpw * h->K, ppw,
+                                                  h->W_tot + ppw * h->K, h->d_tmp_pi, h->d_tmp_theta);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipMemcpyAsync(pi_hat, h->d_tmp_pi, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipMemcpyAsync(theta_hat, h->d_tmp_theta, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_z); (void)hipFree(d_cs);
+  return TSEM_OK;
+}
+
+int tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* theta, double* lnl) {
+  if (!h || !h->have_model || !z || !pi || !theta || !lnl) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
+  double* d_z = nullptr;
+  TSEM_ALLOC(d_z, h->nnz);
+  if (h->nnz) TSEM_HIP(hipMemcpyAsync(d_z, z, sizeof(double) * h->nnz, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_tmp_pi, pi, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_tmp_theta, theta, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
+  A.pi = h->d_tmp_pi; A.theta = h->d_tmp_theta;
+  int grid = std::min(4096, tsem_rowpass_grid(h));
+  if (h->N) k_lnl_rows<<<grid, 256, 0, h->stream>>>(A, d_z, h->d_lnl_part);
+  if (int rc = tsem_sum_parts(h, h->d_lnl_part, h->N ? grid : 0, h->d_lnl_part, 0, h->d_lnl_part + 8000)) return rc;
+  TSEM_HIP(hipGetLastError());
+  if (tsem_comm_on(h)) {
+    if (int rc = tsem_comm_allreduce_dev(h->comm, h->d_lnl_part + 8000, 1, 0, h->stream, h->err)) { (void)hipFree(d_z); return rc; }
+  }
+  TSEM_HIP(hipMemcpyAsync(lnl, h->d_lnl_part + 8000, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_z);
+  return TSEM_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,1264 @@
+// libtelescope_em.so, set-up unit: row statistics (Y, w, W_tot, W_amb, pisum0: model.py:679-699), column signatures (exact twins),
+// the column partition and the blocked layout of the ambiguous rows (tsem_build_layout), model and parameter set-up.
+#include "tsem_internal.h"
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+// ============================================================================
+// row statistics (model.py:679-699)
+// ============================================================================
+// One 16-lane group per row.  Outputs: per-row (len>=2 ? max raw code : 0),
+// flags, per-WG partial sums of w (total / ambiguous), global max code,
+// pisum0[col] += Q for unique rows — EXACTLY, so that the result does not depend on the order of the atomics (round 3; the
+// fp64 atomics this replaced made pi differ in the last bit from run to run): Q is cut into pieces on PIS_LEVELS fixed grids
+// 26 bits apart, from the largest score-table value down past the last mantissa bit of the smallest; a level's sum of up to
+// 2^26 pieces is exact in fp64, k_pisum_finish adds the levels in a fixed order.  A 53-bit Q has pieces on 3-4 levels.
+constexpr int PIS_LEVELS = 9, PIS_W = 26;
+// G lanes per row, sixteen consecutive scores per lane (two 16-byte loads), G from the mean row length: the round-2 shape
+// (16 lanes per row, one 2-byte load per lane and step) read the scores at 1 TB/s: 3.8 ms at 2e9 entries.
+typedef unsigned int rs_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+template <int G>
+__global__ __launch_bounds__(256) void k_rowstats(int64_t N, const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
+    const double* __restrict__ lut, uint16_t* __restrict__ row_code, uint8_t* __restrict__ row_class,
+    double* __restrict__ wsum_part /* [grid][2] */, uint32_t* __restrict__ maxcode,
+    double* __restrict__ pis_lv /* [PIS_LEVELS][K] */, int pis_e0 /* biased exponent of a power of two above every Q */,
+    uint32_t* __restrict__ ucount /* [K] unique rows with a positive score per column; [K] = 1 if any stored score is 0 */,
+    int K, unsigned long long* __restrict__ len_gt /* [6] rows longer than 8, 16, 32, 64, 128, 256 entries */) {
+  __shared__ double scratch[16];
+  constexpr int E = 16;
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  double wt = 0.0, wa = 0.0;
+  int mymax = 0;
+  unsigned lg[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t row = (int64_t)blockIdx.x * ngrp + grp; row < N; row += (int64_t)gridDim.x * ngrp) {
+    const int64_t s = indptr[row];
+    const int len = (int)(indptr[row + 1] - s);
+    int m = 0;
+    bool zero = false;
+    if (gl == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) lg[q] += len > (8 << q) ? 1u : 0u;
+    }
+    for (int k0 = E * gl; k0 < len; k0 += E * G) {           // (the array carries TS_ENTRY_PAD entries of padding)
+      rs_u32x4_a2 cd[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) cd[q] = *reinterpret_cast<const rs_u32x4_a2*>(raw + s + k0 + 8 * q);
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const uint32_t w = cd[j / 8][(j / 2) & 3];
+        const int r = (int)((j & 1) ? w >> 16 : w & 0xFFFFu);
+        if (k0 + j < len) { m = max(m, r); zero |= r == 0; }
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, G));
+    if (zero) ucount[K] = 1u;                              // (a stored score of 0: the shortcuts of tsem_reassign do not apply)
+    if (gl == 0) {
+      double w = (len > 0) ? lut[m] : 0.0;
+      wt += w;
+      if (len > 1) wa += w;
+      row_code[row] = (uint16_t)m;
+      row_class[row] = (len > 1) ? 2 : (len == 1 ? 1 : 0);
+      mymax = max(mymax, m);
+      if (len == 1) {
+        double r = lut[raw[s]];
+        const int col = indices[s];
+        for (int lv = 0; lv < PIS_LEVELS && r != 0.0; ++lv) {
+          const int eb = pis_e0 - PIS_W * lv;               // pieces of this level: |piece| <= 2^(eb-1023), multiples of 2^(eb-1023-PIS_W)
+          if (eb + 52 - PIS_W < 1) break;                   // (below the normal range: nothing of a finite score table gets here)
+          const double mm = __hiloint2double((int)(((uint32_t)(eb + 52 - PIS_W) << 20) | 0x80000u), 0);
+          const double piece = (r + mm) - mm;
+          if (piece != 0.0) unsafeAtomicAdd(&pis_lv[(size_t)lv * K + col], piece);
+          r -= piece;
+        }
+        if (raw[s]) atomicAdd(&ucount[col], 1u);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int t = sg_sum_i<64>((int)lg[q]);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(&len_gt[q], (unsigned long long)t);
+  }
+  double bt = block_sum(wt, scratch);
+  double ba = block_sum(wa, scratch);
+  int bm = sg_max_i<64>(mymax);
+  if ((threadIdx.x & 63) == 0 && bm > 0) atomicMax(maxcode, (uint32_t)bm);
+  if (threadIdx.x == 0) { wsum_part[2 * blockIdx.x] = bt; wsum_part[2 * blockIdx.x + 1] = ba; }
+}
+
+// ============================================================================
+// layout build
+// ============================================================================
+__global__ void k_class_flags(int64_t N, const uint8_t* __restrict__ cls, int32_t* __restrict__ famb,
+                              int32_t* __restrict__ funi) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { famb[i] = cls[i] == 2; funi[i] = cls[i] == 1; }
+}
+
+__global__ void k_compact_rows(int64_t N, const uint8_t* __restrict__ cls, const int32_t* __restrict__ samb,
+    const int32_t* __restrict__ suni, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const uint16_t* __restrict__ raw, const uint16_t* __restrict__ row_code,
+    int32_t* __restrict__ amb_row, uint16_t* __restrict__ amb_wcode, int32_t* __restrict__ uni_col,
+    uint16_t* __restrict__ uni_code) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (cls[i] == 2) { int a = samb[i]; amb_row[a] = (int32_t)i; amb_wcode[a] = row_code[i]; }
+  else if (cls[i] == 1) { int u = suni[i]; int64_t s = indptr[i]; uni_col[u] = indices[s]; uni_code[u] = raw[s]; }
+}
+
+// per-column entry count and order-independent signature sum_i hash(row_i, raw_ij)
+// over ALL rows, LDS-privatised over a window of SIG_WIN columns per sweep.
+// Counts order columns by popularity; (count, hash) identifies exact twin
+// columns (same rows, same scores) whose parameters the reference keeps
+// bit-identical (it accumulates every column in row order).
+constexpr int SIG_WIN = 18432;      // 8 B of LDS per column: 147 KB
+// One 64-bit LDS atomic per entry: the low half counts the column's entries, the high half sums a 32-bit hash of
+// (global row, score) modulo 2^32 (a workgroup sees fewer than 2^32 entries of a column, so the halves never mix).
+// Twins must agree on the count and on the hash sum of every rank — and k_update still only ties two columns whose
+// accumulated sums agree to 1e-12, so a 32-bit signature is a filter, not the proof.  (Round 1: a 32-bit counter and
+// a 64-bit hash, 12 B per column: three passes over the matrix at K = 30k instead of two, and two atomics per entry:
+// 29 -> 14 ms at 2e9 entries.)
+// Round 3: G lanes per row, SIXTEEN consecutive entries per lane (two 16-byte loads of column ids... four, and two of
+// scores), the row half of the hash formed once per lane — the round-2 kernel (16 lanes per row, one 4-byte and one
+// 2-byte load per lane and step, both hash rounds per entry) took 9.9 ms per sweep at 2e9 entries, bound by instruction
+// issue like the row pass it resembled.  Same signature values.
+typedef unsigned int cs_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int cs_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+template <int G>
+__global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw, int col_base, int K,
+    unsigned long long* __restrict__ counts, unsigned long long* __restrict__ hashes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* hh = reinterpret_cast<unsigned long long*>(smem);
+  for (int t = threadIdx.x; t < SIG_WIN; t += blockDim.x) hh[t] = 0;
+  __syncthreads();
+  constexpr int E = 16;
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  for (int64_t i = (int64_t)blockIdx.x * ngrp + grp; i < N; i += (int64_t)gridDim.x * ngrp) {
+    const int64_t s = indptr[i];
+    const int len = (int)(indptr[i + 1] - s);
+    const uint64_t hrow = ts_mix64(0x7715ull ^ ((uint64_t)(row_offset + i) * TS_GOLDEN));   // the row half of ts_hash3
+    for (int k0 = E * gl; k0 < len; k0 += E * G) {         // (the arrays carry TS_ENTRY_PAD entries of padding)
+      cs_u32x4_a4 ix[4]; cs_u32x4_a2 cd[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ix[q] = *reinterpret_cast<const cs_u32x4_a4*>(indices + s + k0 + 4 * q);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) cd[q] = *reinterpret_cast<const cs_u32x4_a2*>(raw + s + k0 + 8 * q);
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const int c = (int)ix[j / 4][j & 3] - col_base;
+        if (k0 + j < len && c >= 0 && c < SIG_WIN) {
+          const uint32_t w = cd[j / 8][(j / 2) & 3];
+          const uint64_t r = (j & 1) ? w >> 16 : w & 0xFFFFu;
+          atomicAdd(&hh[c], (ts_mix64(hrow ^ (r * TS_M1)) & 0xFFFFFFFF00000000ull) | 1ull);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < SIG_WIN; t += blockDim.x)
+    if (hh[t] && col_base + t < K) {
+      atomicAdd(&counts[col_base + t], hh[t] & 0xFFFFFFFFull);
+      atomicAdd(&hashes[col_base + t], hh[t] >> 32);
+    }
+}
+
+// entries of each ambiguous row per column part, packed 8 x 16 bit in two words (fused layout, P <= 8); the popularity
+// ids of the report pass are written on the way (the column map is gathered here anyway).  G lanes per row, sixteen
+// consecutive entries per lane (round 2: 16 lanes per row, one entry per lane and step: 8.3 ms at 2e9 entries).
+// LM: the column map (4 B per column) in LDS, one 1024-thread workgroup per CU — 2e9 gathers of a 120 KB table through the vector
+// cache (about one address per clock and CU) were most of this kernel's 8.1 ms at 2e9 entries; LDS serves 16+ lanes per clock.
+template <int G, bool LM>
+__global__ __launch_bounds__(LM ? 1024 : 256) void k_row_partcounts(int64_t N_amb, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap_g, int K,
+    unsigned long long* __restrict__ out /* [N_amb][2] */, uint16_t* __restrict__ rid /* popularity ids (k_report_rows) or null */, int P) {
+  constexpr int E = 16;
+  extern __shared__ uint32_t pc_cm[];                      // LM: [K]
+  if (LM) {
+    for (int t = threadIdx.x; t < K; t += blockDim.x) pc_cm[t] = colmap_g[t];
+    __syncthreads();
+  }
+  const uint32_t* const colmap = LM ? pc_cm : colmap_g;
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  for (int64_t a = (int64_t)blockIdx.x * ngrp + grp; a < N_amb; a += (int64_t)gridDim.x * ngrp) {
+    const int64_t i = amb_row[a];
+    const int64_t s = indptr[i];
+    const int len = (int)(indptr[i + 1] - s);
+    unsigned long long lo = 0, hi = 0;                     // 4 x 16-bit counters each (a lane sees at most 16 entries per step; rows < 65536)
+    for (int k0 = E * gl; k0 < len; k0 += E * G) {
+      cs_u32x4_a4 ix[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ix[q] = *reinterpret_cast<const cs_u32x4_a4*>(indices + s + k0 + 4 * q);
+      uint32_t cm[E];
+#pragma unroll
+      for (int j = 0; j < E; ++j) cm[j] = colmap[k0 + j < len ? ix[j / 4][j & 3] : 0u];
+      uint32_t idv[E];
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const uint32_t p = cm[j] >> 16;
+        idv[j] = (cm[j] & 0x1FFFu) * P + p;
+        if (k0 + j < len) {
+          const unsigned long long one = 1ull << (16 * (p & 3));
+          if (p < 4) lo += one; else hi += one;
+        }
+      }
+      if (rid) {
+        if (k0 + E <= len) {                               // a full lane: two 16-byte stores instead of sixteen 2-byte ones
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            cs_u32x4_a2 w;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = idv[8 * q + 2 * t] | (idv[8 * q + 2 * t + 1] << 16);
+            *reinterpret_cast<cs_u32x4_a2*>(rid + s + k0 + 8 * q) = w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < E; ++j) if (k0 + j < len) rid[s + k0 + j] = (uint16_t)idv[j];
+        }
+      }
+    }
+    // sums over the group (the packed 16-bit fields cannot carry into each other: a row has fewer than 65536 entries)
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { lo += __shfl_xor(lo, o, G); hi += __shfl_xor(hi, o, G); }
+    if (gl == 0) { out[2 * a] = lo; out[2 * a + 1] = hi; }
+  }
+}
+
+// Block boundaries of the fused layout: a block takes consecutive ambiguous rows until one part would
+// exceed `cap` entries (or R rows).  The rule is sequential, so the rows are cut into chunks of L rows
+// (>= 256 blocks each: the forced break at a chunk end costs ~0.2 % more blocks) and one WAVE walks
+// each chunk 64 rows at a time: lane prefix sums of the per-part counts, then the first lane that does
+// not fit starts the next block.  pass 0 counts the blocks of a chunk, pass 1 (after an exclusive scan
+// of the counts) writes their first rows.  flags[0]: a single row overflows the tile (-> two-pass).
+__global__ __launch_bounds__(64) void k_block_greedy(int64_t na, int P, int R, int cap, int64_t L, int pass,
+    const unsigned long long* __restrict__ pc, int64_t* __restrict__ cnt, const int64_t* __restrict__ off,
+    int64_t* __restrict__ bstart, int* __restrict__ flags) {
+  const int64_t ch = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t a0 = ch * L, a1 = min(na, a0 + L);
+  if (a0 >= a1) return;
+  int c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rows = 0;         // the open block so far (uniform across the wave)
+  int64_t n = 1;
+  const int64_t o = pass ? off[ch] : 0;
+  if (pass && lane == 0) bstart[o] = a0;
+  for (int64_t t0 = a0; t0 < a1; t0 += 64) {
+    const bool v = t0 + lane < a1;
+    const unsigned long long lo = v ? pc[2 * (t0 + lane)] : 0ull, hi = v ? pc[2 * (t0 + lane) + 1] : 0ull;
+    int S[8];
+    bool too_big = false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      S[q] = q < P ? (int)(((q < 4 ? lo : hi) >> (16 * (q & 3))) & 0xFFFF) : 0;
+      too_big |= S[q] > cap;
+    }
+    if (too_big) flags[0] = 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                          // inclusive prefix over the lanes
+      if (q < P) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(S[q], d, 64); if (lane >= d) S[q] += t; }
+      }
+    }
+    int sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // prefix just before the open block's first lane of this tile
+    int s = 0;                                             // that lane (0: the block continues from earlier tiles)
+    for (;;) {
+      bool bad = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bad |= c[q] + S[q] - sub[q] > cap;
+      bad |= rows + lane - s + 1 > R;
+      bad &= v && lane >= s && !(rows == 0 && lane == s);  // the first row of a block always goes in
+      const unsigned long long m = __ballot(bad);
+      if (!m) break;
+      const int b = __ffsll((long long)m) - 1;             // first row that does not fit: it starts the next block
+      if (pass && lane == 0) bstart[o + n] = t0 + b;
+      ++n;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { sub[q] = b > 0 ? __shfl(S[q], b - 1, 64) : 0; c[q] = 0; }
+      rows = 0; s = b;
+    }
+    const int last = (int)min<int64_t>(63, a1 - t0 - 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] += __shfl(S[q], last, 64) - sub[q];
+    rows += last - s + 1;
+  }
+  if (!pass && lane == 0) cnt[ch] = n;
+}
+// sub-block sizes from the per-row part counts the block boundaries were computed from (one wave per block)
+__global__ __launch_bounds__(64) void k_sb_count_pc(int64_t nb, int P, const int64_t* __restrict__ bstart,
+    const unsigned long long* __restrict__ pc, int64_t* __restrict__ sb_cnt) {
+  const int64_t b = blockIdx.x;
+  int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t a = bstart[b] + threadIdx.x; a < bstart[b + 1]; a += 64) {
+    const unsigned long long lo = pc[2 * a], hi = pc[2 * a + 1];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] += (int)(((q < 4 ? lo : hi) >> (16 * (q & 3))) & 0xFFFF);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int t = sg_sum_i<64>(c[q]);
+    if (threadIdx.x == 0 && q < P) sb_cnt[b * P + q] = t;
+  }
+}
+__global__ void k_fixed_blocks(int64_t nb, int R, int64_t na, int64_t* __restrict__ bstart) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= nb) bstart[b] = min(na, b * R);
+}
+
+// rows of block b are the compact ambiguous rows [bstart[b], bstart[b+1]); the rest of its R slots are holes
+__global__ __launch_bounds__(256) void k_make_slots(int64_t nb, int R, const int64_t* __restrict__ bstart,
+    const int32_t* __restrict__ amb_row, const uint16_t* __restrict__ wcode_c, int32_t* __restrict__ slot_row,
+    uint16_t* __restrict__ slot_wcode) {
+  int64_t b = blockIdx.x;
+  const int64_t a0 = bstart[b], n = bstart[b + 1] - a0;
+  for (int lr = threadIdx.x; lr < R; lr += blockDim.x) {
+    const bool v = lr < n;
+    slot_row[b * R + lr] = v ? amb_row[a0 + lr] : -1;
+    slot_wcode[b * R + lr] = v ? wcode_c[a0 + lr] : (uint16_t)0;
+  }
+}
+
+// per (row block, part) entry counts — one WG per block
+__global__ __launch_bounds__(256) void k_sb_count(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint32_t* __restrict__ colmap,
+    int64_t* __restrict__ sb_cnt) {
+  __shared__ uint32_t cnt[64];
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int64_t b = blockIdx.x;
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int lr = sub; lr < R; lr += subs) {
+    int64_t i = amb_row[b * R + lr];                  // row slot -> CSR row, -1 = hole
+    if (i < 0) continue;
+    int64_t s = indptr[i], e = indptr[i + 1];
+    for (int64_t k = s + lane; k < e; k += RS_SUB) atomicAdd(&cnt[colmap[indices[k]] >> 16], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < P) sb_cnt[b * P + threadIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
+    const double* __restrict__ lut, const uint32_t* __restrict__ colmap, const int64_t* __restrict__ sb_off,
+    double* __restrict__ pval, uint16_t* __restrict__ pcode, uint32_t* __restrict__ prc) {
+  __shared__ uint32_t cur[64];
+  if (threadIdx.x < 64) cur[threadIdx.x] = 0;
+  __syncthreads();
+  int64_t b = blockIdx.x;
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int lr = sub; lr < R; lr += subs) {
+    int64_t i = amb_row[b * R + lr];
+    if (i < 0) continue;
+    int64_t s = indptr[i], e = indptr[i + 1];
+    for (int64_t k = s + lane; k < e; k += RS_SUB) {
+      uint32_t cm = colmap[indices[k]];
+      uint32_t p = cm >> 16;
+      // Entries of one row are handed consecutive tickets; writing ticket t of a
+      // sub-block to slot (t % S) * L + t / S (S strands of L slots) puts them S..L
+      // slots apart, so the lanes of one wave instruction hit different rows and the
+      // LDS row-sum atomics do not serialise on one address.
+      const int64_t base = sb_off[b * P + p];
+      const uint32_t L = (uint32_t)((sb_off[b * P + p + 1] - base) / TS_STRANDS);
+      const uint32_t t = atomicAdd(&cur[p], 1u);
+      int64_t pos = base + (int64_t)(t % TS_STRANDS) * L + t / TS_STRANDS;
+      if (pcode) pcode[pos] = raw[k];
+      else pval[pos] = lut[raw[k]];
+      prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
+    }
+  }
+}
+
+// Fused layout: the entries of a sub-block are stored densely in ROW order (any order inside a row), so
+// a thread's four consecutive entries and its neighbours' mostly share a row and the row sums can be
+// reduced in registers / across lanes instead of one LDS atomic per entry (tsem_fused.h, phase 1).
+// The padding at the end of a sub-block repeats the last row with value 0.
+constexpr int FILL_MAX_RP = 768 * 8;                       // row slots x parts of a block the row-order fill can take (1152 x 4, 768 x 8)
+// Round 3 (second pass over this kernel, 13.9 ms at 2e9 entries): it was bound by the LATENCY of three dependent loads
+// per row (row slot -> row pointers -> entries, then one more round trip per 16 entries of the row) with 16 rows in
+// flight per workgroup.  Now the row pointers of the whole block go to LDS in one parallel sweep, and a 16-lane group
+// loads the first 64 ids and scores of its NEXT row before it places the current one (unconditional loads: the arrays
+// carry TS_ENTRY_PAD entries of padding), so a group waits for memory about once per row instead of four times.
+__host__ __device__ inline size_t fill_lds_bytes(int R, int P) { return (size_t)(((R * P + 1) & ~1) * 4) + (size_t)R * 12; }
+__global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, int P, const int32_t* __restrict__ amb_row,
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const uint16_t* __restrict__ raw,
+    const double* __restrict__ lut, const uint32_t* __restrict__ colmap, const int64_t* __restrict__ sb_off,
+    double* __restrict__ pval, uint16_t* __restrict__ pcode, uint32_t* __restrict__ prc,
+    const int64_t* __restrict__ bstart, const unsigned long long* __restrict__ pc,
+    const uint16_t* __restrict__ rid /* popularity ids (slot * P + part) instead of the column-map gather, or null */,
+    uint32_t magicP /* ceil(2^32 / P) */, int nsplit /* ids below this may be split columns */, const uint8_t* __restrict__ lgtab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fl_lds[];
+  uint32_t* const cnt = reinterpret_cast<uint32_t*>(fl_lds);                   // [row slot][part]: counts, then write cursors
+  int64_t* const rstart = reinterpret_cast<int64_t*>(cnt + ((R * P + 1) & ~1));   // [row slot] first entry of the row in the CSR
+  int32_t* const rlen = reinterpret_cast<int32_t*>(rstart + R);                // [row slot] its length (0: empty slot)
+  __shared__ uint32_t total[8], lastrow[8];
+  __shared__ int64_t sbase[8];
+  const int64_t b = blockIdx.x;
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int t = threadIdx.x; t < R * P; t += blockDim.x) cnt[t] = 0;
+  for (int lr = threadIdx.x; lr < R; lr += blockDim.x) {
+    const int64_t i = amb_row[b * R + lr];
+    const int64_t s0 = i >= 0 ? indptr[i] : 0;
+    rstart[lr] = s0; rlen[lr] = i >= 0 ? (int32_t)(indptr[i + 1] - s0) : 0;
+  }
+  if (threadIdx.x < P) sbase[threadIdx.x] = sb_off[b * P + threadIdx.x];
+  __syncthreads();
+  if (pc) {                                                // the per-row part counts are already known
+    const int64_t a0 = bstart[b], n = bstart[b + 1] - a0;
+    for (int lr = threadIdx.x; lr < n; lr += blockDim.x) {
+      const unsigned long long lo = pc[2 * (a0 + lr)], hi = pc[2 * (a0 + lr) + 1];
+      for (int q = 0; q < P; ++q) cnt[lr * P + q] = (uint32_t)(((q < 4 ? lo : hi) >> (16 * (q & 3))) & 0xFFFF);
+    }
+  } else {
+    for (int lr = sub; lr < R; lr += subs) {
+      const int64_t s0 = rstart[lr];
+      for (int k = lane; k < rlen[lr]; k += RS_SUB) atomicAdd(&cnt[lr * P + (colmap[indices[s0 + k]] >> 16)], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < P) {                                   // exclusive scan down the rows, one thread per part
+    uint32_t run = 0, last = 0;
+    for (int lr = 0; lr < R; ++lr) {
+      const uint32_t c = cnt[lr * P + threadIdx.x];
+      cnt[lr * P + threadIdx.x] = run;
+      if (c) last = (uint32_t)lr;
+      run += c;
+    }
+    total[threadIdx.x] = run; lastrow[threadIdx.x] = last;
+  }
+  __syncthreads();
+  // A row's entries keep their CSR order inside each part: the position of an entry = the row's cursor for its part
+  // (read-only after the scan) + the number of earlier entries of the row in that part, counted with wave ballots over
+  // the 16 lanes that walk the row — no LDS atomic per entry (2e9 of them with a return value were half of this
+  // kernel's time), and the layout is the same from run to run.
+  const int sgbase = (threadIdx.x & 63) / RS_SUB * RS_SUB;
+  const uint32_t below = (1u << lane) - 1u;
+  // one step of 16 entries: column-map word cm of this lane's entry (0xFFFF.... part for lanes past the row's end), its score
+  auto place = [&](int lr, uint32_t (&run)[8], bool valid, uint32_t cm, uint32_t code) {
+    const uint32_t p = valid ? cm >> 16 : 0xFFFFu;
+    uint32_t t = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q < P) {
+        const uint32_t m = (uint32_t)(__ballot(p == (uint32_t)q) >> sgbase) & 0xFFFFu;
+        if (p == (uint32_t)q) t = run[q] + __popc(m & below);
+        run[q] += __popc(m);
+      }
+    }
+    if (valid) {
+      t += cnt[lr * P + p];
+      const int64_t pos = sbase[p] + t;
+      if (pcode) pcode[pos] = (uint16_t)code;
+      else pval[pos] = lut[code];
+      prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
+    }
+  };
+  auto cm_of_id = [&](uint32_t id) -> uint32_t {           // the ids k_row_partcounts wrote: a coalesced 2-byte read instead of a gather
+    const uint32_t slot = P == 1 ? id : __umulhi(id, magicP);   // id / P, exact for 16-bit ids and 2 <= P <= 8 (ceil(2^32 / 1) does not fit 32 bits)
+    const uint32_t lg = (int)id < nsplit ? (uint32_t)lgtab[id] : 0u;
+    return ((id - slot * (uint32_t)P) << 16) | (lg << 13) | slot;
+  };
+  if (rid) {
+    constexpr int PF = 4;                                  // steps of a row loaded ahead (64 entries)
+    uint32_t nid[PF], nrw[PF];
+    auto load_row = [&](int lr) {
+      const int64_t s0 = rstart[lr < R ? lr : R - 1];
+#pragma unroll
+      for (int j = 0; j < PF; ++j) { nid[j] = rid[s0 + 16 * j + lane]; nrw[j] = raw[s0 + 16 * j + lane]; }
+    };
+    load_row(sub);
+    for (int lr = sub; lr < R; lr += subs) {
+      uint32_t cid[PF], crw[PF];
+#pragma unroll
+      for (int j = 0; j < PF; ++j) { cid[j] = nid[j]; crw[j] = nrw[j]; }
+      load_row(lr + subs);                                 // (past the block's last row: the last row again, unused)
+      const int len = rlen[lr];
+      const int64_t s0 = rstart[lr];
+      uint32_t run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < PF; ++j)
+        if (16 * j < len) place(lr, run, 16 * j + lane < len, cm_of_id(cid[j]), crw[j]);   // (uniform over the 16 lanes)
+      for (int k0 = 16 * PF; k0 < len; k0 += RS_SUB) {      // the rest of a long row
+        const bool valid = k0 + lane < len;
+        const uint32_t id = valid ? (uint32_t)rid[s0 + k0 + lane] : 0u;
+        place(lr, run, valid, cm_of_id(id), valid ? (uint32_t)raw[s0 + k0 + lane] : 0u);
+      }
+    }
+  } else {
+    for (int lr = sub; lr < R; lr += subs) {
+      const int len = rlen[lr];
+      const int64_t s0 = rstart[lr];
+      uint32_t run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k0 = 0; k0 < len; k0 += RS_SUB) {           // (all 16 lanes stay in the loop: the ballots need them)
+        const bool valid = k0 + lane < len;
+        place(lr, run, valid, valid ? colmap[indices[s0 + k0 + lane]] : 0u, valid ? (uint32_t)raw[s0 + k0 + lane] : 0u);
+      }
+    }
+  }
+  for (int p = 0; p < P; ++p) {                            // padding: value 0 (buffers are zero-filled), row = last row
+    const int64_t base = sbase[p], end = sb_off[b * P + p + 1];
+    for (int64_t pos = base + total[p] + threadIdx.x; pos < end; pos += blockDim.x) prc[pos] = lastrow[p] << 16;
+  }
+}
+
+// Conflict-aware entry order INSIDE the rows of the row-ordered layout (score codes).  The column scatter of the
+// fused kernel (ds_add_f64 into the part's accumulators) is served in four groups of 16 lanes, each at 2 clk x the
+// largest number of lanes whose slots agree modulo 16 (tools/ubench/lds.hip: 16 slots distinct mod 32 but pairwise
+// equal mod 16 cost 16 clk, distinct mod 16 cost 8, random 24.5); SQ_LDS_BANK_CONFLICT is a third of the LDS-array
+// cycles of the pass (profiles/r02_lds_counters.txt).  One such group and instruction covers the entries at
+// positions = j (mod 4) of a WINDOW of 64 consecutive entries (16 lanes x 4 entries; sub-blocks are padded to 64,
+// so windows never straddle them).  Any order inside a row is valid, so every window is walked once and each
+// position takes, among itself and the next two entries of the same row, the one whose slot class is rarest so
+// far in its (window, j) bin: mean worst multiplicity 3.2 -> 2.3 (two look-ahead entries already give what a search
+// over the whole row gives; the bound for a fixed row order is ~2.1, a window holds ~8 entries of its most popular
+// class).  One thread per window, windows are independent; the walk is fully unrolled, so every index is static and
+// the 64 four-bit classes, the row boundaries, the four 16-counter histograms and the permutation itself are
+// packed in registers — no LDS, no memory access, no divergent loop.  The permutation is applied while copying
+// the window into fresh arrays.  The padding at the end of a sub-block (code 0) stays where it is.
+constexpr int DC_NT = 256;
+// Round 3: the window lives in REGISTERS (64 packed row/column words + 64 codes) and the chosen entry is swapped into
+// place with selects — every position is a compile-time constant of the unrolled walk.  The round-2 version built a
+// permutation and applied it with 128 scattered loads per window afterwards: 8192 vector-cache address cycles per
+// wave against 1536 for reading the window, which was most of its 14 ms at 2e9 entries.
+__global__ __launch_bounds__(DC_NT) void k_sb_deconflict(int64_t n_win, const uint32_t* __restrict__ prc_in, const uint16_t* __restrict__ code_in,
+                                                          uint32_t* __restrict__ prc_out, uint16_t* __restrict__ code_out) {
+  for (int64_t w = (int64_t)blockIdx.x * DC_NT + threadIdx.x; w < n_win; w += (int64_t)gridDim.x * DC_NT) {
+    const int64_t base = w * 64;
+    const uint4* pin = reinterpret_cast<const uint4*>(prc_in + base);
+    const uint2* cin = reinterpret_cast<const uint2*>(code_in + base);
+    uint32_t P[64], Cd[64];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const uint4 a = pin[q];
+      const uint2 cd = cin[q];
+      P[4 * q] = a.x; P[4 * q + 1] = a.y; P[4 * q + 2] = a.z; P[4 * q + 3] = a.w;
+      Cd[4 * q] = cd.x & 0xFFFFu; Cd[4 * q + 1] = cd.x >> 16; Cd[4 * q + 2] = cd.y & 0xFFFFu; Cd[4 * q + 3] = cd.y >> 16;
+    }
+    unsigned long long cont = 0ull;                        // bit i: entry i continues the row of entry i-1 (and neither is padding)
+#pragma unroll
+    for (int i = 1; i < 64; ++i)
+      if (Cd[i] != 0u && Cd[i - 1] != 0u && (P[i] >> 16) == (P[i - 1] >> 16)) cont |= 1ull << i;
+    unsigned long long h[4] = {0ull, 0ull, 0ull, 0ull};   // per instruction slot j: 16 four-bit counters, one per class
+#pragma unroll
+    for (int pos = 0; pos < 64; ++pos) {
+      const int j = pos & 3;
+      const uint32_t c0 = P[pos] & 15u;
+      uint32_t best = 0u, cb = c0, lb = (uint32_t)(h[j] >> (c0 * 4u)) & 15u;
+      if (pos + 1 < 64) {
+        const bool ok1 = (cont >> (pos + 1)) & 1ull;
+        const uint32_t c1 = P[pos + 1] & 15u;
+        const uint32_t l1 = (uint32_t)(h[j] >> (c1 * 4u)) & 15u;
+        if (ok1 && l1 < lb) { best = 1u; cb = c1; lb = l1; }
+        if (pos + 2 < 64) {
+          const bool ok2 = ok1 && ((cont >> (pos + 2)) & 1ull);
+          const uint32_t c2 = P[pos + 2] & 15u;
+          const uint32_t l2 = (uint32_t)(h[j] >> (c2 * 4u)) & 15u;
+          if (ok2 && l2 < lb) { best = 2u; cb = c2; lb = l2; }
+        }
+        // swap entry pos with entry pos + best (same row: the continuation bits stay valid)
+        const uint32_t tp = P[pos], tc = Cd[pos];
+        if (pos + 2 < 64) {
+          P[pos] = best == 1u ? P[pos + 1] : (best == 2u ? P[pos + 2] : tp);
+          Cd[pos] = best == 1u ? Cd[pos + 1] : (best == 2u ? Cd[pos + 2] : tc);
+          P[pos + 2] = best == 2u ? tp : P[pos + 2];
+          Cd[pos + 2] = best == 2u ? tc : Cd[pos + 2];
+        } else {
+          P[pos] = best == 1u ? P[pos + 1] : tp;
+          Cd[pos] = best == 1u ? Cd[pos + 1] : tc;
+        }
+        P[pos + 1] = best == 1u ? tp : P[pos + 1];
+        Cd[pos + 1] = best == 1u ? tc : Cd[pos + 1];
+      }
+      h[j] += (unsigned long long)(lb < 15u ? 1u : 0u) << (cb * 4u);
+    }
+    uint4* pout = reinterpret_cast<uint4*>(prc_out + base);
+    uint2* cout = reinterpret_cast<uint2*>(code_out + base);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      pout[q] = make_uint4(P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]);
+      cout[q] = make_uint2(Cd[4 * q] | (Cd[4 * q + 1] << 16), Cd[4 * q + 2] | (Cd[4 * q + 3] << 16));
+    }
+  }
+}
+
+__global__ void k_make_ctab(int K, const double* __restrict__ pi, const double* __restrict__ theta,
+                            const uint32_t* __restrict__ colmap, int Kp, double* __restrict__ ctab) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  const uint32_t cm = colmap[j];
+  const int pc = (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu), copies = 1 << ((cm >> 13) & 7u);
+  for (int c = 0; c < copies; ++c) ctab[pc + c] = pi[j] * theta[j];
+}
+
+__global__ void k_row_weights(int64_t n, const uint16_t* __restrict__ code, const double* __restrict__ lut,
+                              double* __restrict__ w) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = lut[code[i]];
+}
+
+__global__ void k_fill(double* p, int64_t n, double v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+
+// popularity ids: id = slot * P + part of the column's first slot in the blocked layout (popular columns come first in
+// every part, so small ids are popular columns); cnat2 by id
+__global__ __launch_bounds__(256) void k_rid16_rows(int64_t N, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const uint32_t* __restrict__ colmap, int P, int only_short, uint16_t* __restrict__ rid) {
+  const int sub = threadIdx.x / RS_SUB, lane = threadIdx.x % RS_SUB, subs = blockDim.x / RS_SUB;
+  for (int64_t i = (int64_t)blockIdx.x * subs + sub; i < N; i += (int64_t)gridDim.x * subs) {
+    const int64_t s = indptr[i], e = indptr[i + 1];
+    if (only_short && e - s > 1) continue;                 // (the ambiguous rows were written by k_row_partcounts)
+    for (int64_t k = s + lane; k < e; k += RS_SUB) { const uint32_t cm = colmap[indices[k]]; rid[k] = (uint16_t)((cm & 0x1FFFu) * P + (cm >> 16)); }
+  }
+}
+
+extern "C" {
+
+// option "reproducible": the slots' bounds as a run finds them: 2^E > the largest fragment weight >= every contribution w * z
+// (refined column by column, see k_bin_check).  Called when parameters are set from outside, so that a run's bits depend on its
+// starting point only, not on what the context computed before.
+int tsem_bin_reset(tsem_ctx* h) {
+  if (!h->d_ebias) return TSEM_OK;
+  int e2 = 0;
+  (void)std::frexp(h->w_max > 0 ? h->w_max : 1.0, &e2);    // w_max = m * 2^e2, m in [0.5, 1)  ->  w_max < 2^e2
+  std::vector<uint16_t> eb((size_t)h->Kpad, (uint16_t)std::min(2000, std::max(64, e2 + 1023)));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  TSEM_HIP(hipMemcpy(h->d_ebias, eb.data(), sizeof(uint16_t) * h->Kpad, hipMemcpyHostToDevice));
+  TSEM_HIP(hipMemset(h->d_ovf, 0, (size_t)h->Kpad));
+  TSEM_HIP(hipMemset(h->d_ehist, 0, sizeof(int16_t) * (2 * (size_t)h->K + 2)));
+  return TSEM_OK;
+}
+
+
+
+int tsem_choose_geometry(tsem_ctx* h) {
+  const int K = h->K;
+  const int64_t na = h->N_amb, nu = h->N_uni;
+  {
+    // column parts (tables of one part must fit LDS) and rows per block
+    // option "reproducible" = 1: both pieces of the exact sums in ONE pass if three tables per part fit the LDS with at most 8
+    // parts (score codes; 26 B of LDS per column); else — or with "reproducible" = 2 — two passes over two tables
+    h->exact_single = false;
+    if (h->opt_reproducible == 1 && h->em_kernel != TSEM_EMK_TWOPASS && h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048) {
+      const int p3 = h->opt_P > 0 ? (int)h->opt_P : (K + TS_MAX_KP3 - 64 - 1) / (TS_MAX_KP3 - 64);
+      // teams of 5-8 have ONE geometry (384 row slots): worth it only when the rows are long enough to fill their register
+      // tiles (20M x 30k: 100 per row 9.4 -> 6.3 ms per iteration, 18 per row 2.4 -> 3.3; K = 15k, teams of 4: 3.9 -> 2.6 at
+      // 40 per row, 1.9 -> 1.4 at 18; profiles/r03_reproducible.txt)
+      const double ml = na > 0 ? (double)(h->nnz - nu) / (double)na : 0.0;
+      // (one pass costs ~1.25 default passes on a full tile, two passes cost 2: worth it down to tiles ~2/3 full — K = 30k, 40 per
+      //  row, teams of 7: 3.58 against 3.79 ms per iteration)
+      const bool long_enough = p3 <= 4 || h->opt_P > 0 || ml * fz_rmax(2) >= 0.62 * 1.05 * fz_cap(1) * p3;
+      if (p3 >= 1 && p3 <= FZ_MAX_P && (K + p3 - 1) / p3 + 64 <= TS_MAX_KP3 && long_enough) h->exact_single = true;
+    }
+    const int max_kp = h->exact_single ? TS_MAX_KP3 - 64 : TS_MAX_KP;
+    int P = h->opt_P > 0 ? (int)h->opt_P : (K + max_kp - 1) / max_kp;
+    if (P < 1) P = 1;
+    if (h->opt_P <= 0 && h->em_kernel != TSEM_EMK_TWOPASS && P < FZ_MAX_P && na > 0) {
+      // Teams never span XCDs, so floor(cpx / P) * P of an XCD's cpx CUs work: 28 of 32 for teams of 7.
+      // One more member per team is worth it when it puts >= 10 % more CUs to work and the rows are
+      // long enough to fill the register tiles of the larger team (measured: K = 50k, 100 nnz/row,
+      // P 7 -> 8: fp64 5.80 -> 5.48 ms, codes 4.82 -> 4.28 ms; K = 38k, 40 nnz/row is better off at P = 5).
+      const int cpx = std::max(1, h->n_cu / 8);
+      auto util = [&](int p) { return (double)(cpx / p * p) / cpx; };
+      const double mean_len = (double)(h->nnz - nu) / (double)na;
+      for (int p2 = P + 1; p2 <= FZ_MAX_P; ++p2)
+        if (util(p2) >= util(P) + 0.10 && mean_len * fz_rmax(2) >= 1.05 * fz_cap(1) * p2) { P = p2; break; }
+    }
+    if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
+    int Kp = (K + P - 1) / P;
+    if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
+    // spare accumulator slots per part for very popular columns (build_layout splits them)
+    h->hot_extra = h->opt_hot_split ? std::min(64, (h->exact_single ? TS_MAX_KP3 : TS_MAX_KP) - Kp) : 0;
+    Kp += h->hot_extra;
+    h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
+    h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
+    int R = 2048;
+    h->geo = P > 4 ? 1 : 0;
+    h->run_len_est = na > 0 ? (double)(h->nnz - nu) / (double)na / P : 0.0;   // entries per ambiguous row and part
+    if (h->use_fused && na > 0) {
+      // size blocks so a member's sub-block (~R*len/P entries) fills ~85 % of its register tile
+      double mean_len = (double)(h->nnz - nu) / (double)na;
+      // row SLOTS per block: ~7 % above the average a register tile takes, so blocks end on the
+      // tile's capacity, not on R (the exchange cost depends on R, hence not more than needed)
+      // geometry: teams of 5-8 have one; smaller teams switch to three exchange waves when the rows
+      // are so short that 512 row slots cannot fill the register tile and the pass is bound by the
+      // exchange (fp64 entries; with score codes the 14th data wave is worth more)
+      // (profiles/r02_sweep_short.txt, 50M rows, both entry formats: the third exchange wave pays once the tile
+      // needs more than ~1.25x the 512 row slots of geometry 0 — 20 entries per row: codes 2.21 -> 1.98 ms, fp64
+      // 2.63 -> 2.57; 28 per row: codes 2.55 -> 2.66, fp64 equal)
+      // teams of 5-8 (round 3): 768 row slots (geometry 2: two row pairs per exchange lane, (P - 1) x 2 partner values in its
+      // registers: 118-124 VGPRs, no spill) when 384 cannot fill the register tiles
+      h->geo = P > 4 ? ((1.07 * fz_cap(1) * P / std::max(2.0, mean_len) > 1.25 * fz_rmax(1)) ? 2 : 1)
+                     : ((1.07 * fz_cap(0) * P / std::max(2.0, mean_len) > 1.25 * fz_rmax(0)) ? 2 : 0);
+      // rows so short that 768 of them cannot fill the tile either: geometry 3 (32 B of LDS per row slot instead of 48)
+      // (profiles/r03_sweep_short.txt: 8 / 10 / 12 entries per row 1.27 / 1.31 / 1.39 -> 1.18 / 1.23 / 1.34 ms, 14 equal, 16 and more slower:
+      //  the exchange of a step grows with its row slots)
+      if (P <= 4 && h->geo == 2 && 1.07 * fz_cap(2) * P / std::max(2.0, mean_len) > 1.4 * fz_rmax(2)) h->geo = 3;
+      if (h->opt_geo >= 0 && P <= 4) h->geo = (h->opt_geo == 2 || h->opt_geo == 3) ? (int)h->opt_geo : 0;
+      if (h->opt_geo >= 0 && P > 4) h->geo = h->opt_geo == 2 ? 2 : 1;
+      double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
+      const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - (h->exact_single ? 3 : 2) * Kp * 8 - lut_bytes - std::max(h->opt_reproducible ? Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16)) / ((fz_yr(h->geo) + 2) * 8));
+      rmax = std::min(rmax, FILL_MAX_RP / P);                // (k_sb_fill_sorted keeps R x P counters in LDS)
+      R = (int)std::min<double>(r, rmax);
+      R = std::max(64, (R + 63) / 64 * 64);
+      R = std::min(R, rmax / 8 * 8);
+    }
+    if (h->opt_R > 0) R = (int)h->opt_R;
+    h->R = R;
+  }
+  if (h->R > 65536 || h->R < 64) TSEM_FAIL(TSEM_ERR_ARG, "block_rows must be in [64, 65536]");
+  h->nb = (na + h->R - 1) / h->R;
+  h->N_amb_pad = std::max<int64_t>(1, h->nb) * h->R;
+  return TSEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rowstats: classes, weights, local sums; compacts ambiguous / unique rows
+// ---------------------------------------------------------------------------
+__global__ void k_pisum_finish(int K, const double* __restrict__ lv, double* __restrict__ pisum0) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  double t = 0.0;
+  for (int l = PIS_LEVELS - 1; l >= 0; --l) t += lv[(size_t)l * K + j];   // small to large
+  pisum0[j] = t;
+}
+
+int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_count, uint64_t* col_hash) {
+  if (!h || !h->d_indptr) return TSEM_ERR_ARG;
+  if (!h->d_lut || h->lut_len <= 0) TSEM_FAIL(TSEM_ERR_ARG, "no score table: call tsem_set_lut after tsem_generate");
+  if (int rc = ensure_device(h)) return rc;
+  const int64_t N = h->N;
+  const int K = h->K;
+  uint16_t* d_code = nullptr; uint8_t* d_cls = nullptr; double* d_wpart = nullptr;
+  int32_t *d_fa = nullptr, *d_fu = nullptr;
+  TSEM_ALLOC(d_code, N); TSEM_ALLOC(d_cls, N);
+  const int grid = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (N + 15) / 16));
+  TSEM_ALLOC(d_wpart, 2 * grid);
+  TSEM_ALLOC(h->d_pisum0, K);
+  TSEM_ALLOC(h->d_ucount, K + 1);
+  TSEM_HIP(hipMemsetAsync(h->d_ucount, 0, sizeof(uint32_t) * (K + 1), h->stream));
+  double* d_pis_lv = nullptr;
+  TSEM_ALLOC(d_pis_lv, (size_t)PIS_LEVELS * K);
+  TSEM_HIP(hipMemsetAsync(d_pis_lv, 0, sizeof(double) * PIS_LEVELS * K, h->stream));
+  int pis_e2 = 0;
+  (void)std::frexp(h->lut_host[h->lut_len - 1] > 0 ? h->lut_host[h->lut_len - 1] : 1.0, &pis_e2);   // Q < 2^e2 (the table is increasing)
+  TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
+  TSEM_HIP(hipMemsetAsync(d_wpart, 0, sizeof(double) * 2 * grid, h->stream));
+  unsigned long long* d_lg = nullptr;
+  TSEM_ALLOC(d_lg, 8);
+  TSEM_HIP(hipMemsetAsync(d_lg, 0, 64, h->stream));
+  if (N) {
+    const double mean_len = (double)h->nnz / (double)N;    // lanes per row x 16 entries >= ~1.5 mean row lengths
+    const int G = mean_len * 1.5 <= 16 ? 1 : mean_len * 1.5 <= 32 ? 2 : mean_len * 1.5 <= 64 ? 4 : mean_len * 1.5 <= 128 ? 8 : 16;
+    auto rk = G == 1 ? k_rowstats<1> : G == 2 ? k_rowstats<2> : G == 4 ? k_rowstats<4> : G == 8 ? k_rowstats<8> : k_rowstats<16>;
+    rk<<<grid, 256, 0, h->stream>>>(N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, d_code, d_cls,
+                                    d_wpart, h->d_maxcode, d_pis_lv, pis_e2 + 1023, h->d_ucount, K, d_lg);
+  }
+  k_pisum_finish<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, d_pis_lv, h->d_pisum0);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipMemcpyAsync(h->len_gt, d_lg, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> wpart(2 * grid);
+  uint32_t maxcode = 0;
+  TSEM_HIP(hipMemcpyAsync(wpart.data(), d_wpart, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipMemcpyAsync(&maxcode, h->d_maxcode, 4, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  double wt = 0, wa = 0;
+  for (int i = 0; i < grid; ++i) { wt += wpart[2 * i]; wa += wpart[2 * i + 1]; }
+  if (stats3) { stats3[0] = wt; stats3[1] = wa; stats3[2] = (N && h->nnz) ? h->lut_host[maxcode] : 0.0; }
+  if (pisum0) TSEM_HIP(hipMemcpy(pisum0, h->d_pisum0, sizeof(double) * K, hipMemcpyDeviceToHost));
+
+  // column signatures (popularity + twin detection)
+  if (col_count && col_hash) {
+    unsigned long long *d_cnt = nullptr, *d_hash = nullptr;
+    TSEM_ALLOC(d_cnt, K); TSEM_ALLOC(d_hash, K);
+    TSEM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * K, h->stream));
+    TSEM_HIP(hipMemsetAsync(d_hash, 0, sizeof(unsigned long long) * K, h->stream));
+    if (N) {
+      const int lds = SIG_WIN * 8;
+      // lanes per row from the row-length histogram taken a moment ago: 16 entries per lane, the smallest group that
+      // takes 99.5 % of the rows in one step (longer rows loop)
+      int cap = 256;
+      for (int q = 1; q < 6; ++q)
+        if ((double)h->len_gt[q] <= 0.005 * (double)N) { cap = 8 << q; break; }
+      void (*ck)(int64_t, int64_t, const int64_t*, const int32_t*, const uint16_t*, int, int, unsigned long long*, unsigned long long*) =
+          cap <= 16 ? k_colsig<1> : cap <= 32 ? k_colsig<2> : cap <= 64 ? k_colsig<4> : cap <= 128 ? k_colsig<8> : k_colsig<16>;
+      TSEM_HIP(hipFuncSetAttribute((const void*)ck, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      int g2 = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, (N + 63) / 64));
+      for (int base = 0; base < K; base += SIG_WIN)
+        ck<<<g2, 1024, lds, h->stream>>>(N, h->row_offset, h->d_indptr, h->d_indices, h->d_raw, base, K, d_cnt, d_hash);
+      TSEM_HIP(hipGetLastError());
+    }
+    TSEM_HIP(hipMemcpyAsync(col_count, d_cnt, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(col_hash, d_hash, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    dfree(h->d_colcount);
+    h->d_colcount = d_cnt;                                 // LOCAL stored entries per column: reassign('all', initial) of this rank
+    (void)hipFree(d_hash);
+  }
+  // compact ambiguous and unique rows
+  TSEM_ALLOC(d_fa, N + 1); TSEM_ALLOC(d_fu, N + 1);
+  int32_t na = 0, nu = 0;
+  TSEM_HIP(hipMemsetAsync(d_fa + N, 0, 4, h->stream));
+  TSEM_HIP(hipMemsetAsync(d_fu + N, 0, 4, h->stream));
+  if (N) {
+    k_class_flags<<<cdiv64(N, 256), 256, 0, h->stream>>>(N, d_cls, d_fa, d_fu);
+    size_t tb = 0;
+    TSEM_HIP(rocprim::exclusive_scan(nullptr, tb, d_fa, d_fa, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(), h->stream));
+    void* tmp = nullptr;
+    TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+    TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_fa, d_fa, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(), h->stream));
+    TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_fu, d_fu, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(), h->stream));
+    TSEM_HIP(hipMemcpyAsync(&na, d_fa + N, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(&nu, d_fu + N, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(tmp);
+  }
+  h->N_amb = na; h->N_uni = nu;
+  if (int rc = tsem_choose_geometry(h)) return rc;
+  TSEM_ALLOC(h->d_amb_row, na);
+  TSEM_ALLOC(h->d_amb_wcode_c, na);                       // per compact row; build_layout makes the slot copy
+  TSEM_ALLOC(h->d_uni_col, nu);
+  TSEM_ALLOC(h->d_uni_code, nu);
+  if (N)
+    k_compact_rows<<<cdiv64(N, 256), 256, 0, h->stream>>>(N, d_cls, d_fa, d_fu, h->d_indptr, h->d_indices, h->d_raw,
+                                                         d_code, h->d_amb_row, h->d_amb_wcode_c, h->d_uni_col,
+                                                         h->d_uni_code);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_code); (void)hipFree(d_cls); (void)hipFree(d_wpart); (void)hipFree(d_fa); (void)hipFree(d_fu); (void)hipFree(d_lg); (void)hipFree(d_pis_lv);
+  h->have_rowstats = true;
+  return TSEM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// layout: column partition by popularity, blocked COO of ambiguous rows
+// ---------------------------------------------------------------------------
+int tsem_build_layout(tsem_ctx* h) {
+  PhaseTimer pt(h->stream);
+  const int K = h->K;
+  const int64_t na = h->N_amb;
+  tsem_free_layout(h);
+  h->nnz_amb = 0;
+  // 1. column popularity: global entry counts handed in by set_model
+  const std::vector<uint64_t>& counts = h->col_count;
+  // 2. parts: deal columns by popularity so every part carries ~equal nnz
+  const int P = h->P, Kp = h->Kp;
+  std::vector<int> order(K);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return counts[a] > counts[b]; });
+  // colmap[j] = part << 16 | log2(copies) << 13 | first slot.  A column that holds a large share of its
+  // part's entries would serialise the LDS scatter (64 f lanes of every ds_add_f64 on ONE address:
+  // the hottest column of a Zipf-like matrix, or Telescope's `__no_feature`, reaches 8-way), so it
+  // gets 2..16 consecutive slots; k_sb_fill deals its entries over them, k_colreduce adds them up.
+  std::vector<uint32_t> colmap(K);
+  std::vector<int32_t> col_of_pc(h->Kpad, -1);
+  // Columns go, most popular first, to the part that holds the fewest entries so far (and still has
+  // a free slot): every member of a team then streams the same number of entries per row block, so
+  // the register tiles of all parts fill evenly and no member waits for a heavier one.
+  std::vector<double> part_nnz(P, 0.0);
+  std::vector<int> part_of(K), ncols(P, 0);
+  const int percap = h->Kp - h->hot_extra;                 // plain columns per part
+  for (int rank = 0; rank < K; ++rank) {
+    int best = -1;
+    for (int p = 0; p < P; ++p)
+      if (ncols[p] < percap && (best < 0 || part_nnz[p] < part_nnz[best])) best = p;
+    part_of[rank] = best;
+    ncols[best] += 1;
+    part_nnz[best] += (double)counts[order[rank]];
+  }
+  std::vector<int> cursor(P, 0), spare(P, h->hot_extra);
+  h->n_hot_cols = 0;
+  for (int rank = 0; rank < K; ++rank) {
+    const int j = order[rank], p = part_of[rank];
+    const double lanes = 64.0 * (double)counts[j] / std::max(1.0, part_nnz[p]);
+    int lg = 0;
+    while (lg < 4 && lanes / (1 << lg) > 1.5 && (2 << lg) - 1 <= spare[p]) ++lg;
+    spare[p] -= (1 << lg) - 1;
+    if (lg) h->n_hot_cols += 1;
+    colmap[j] = ((uint32_t)p << 16) | ((uint32_t)lg << 13) | (uint32_t)cursor[p];
+    col_of_pc[p * Kp + cursor[p]] = j;                     // the first slot owns the column; the others stay -1
+    cursor[p] += 1 << lg;
+  }
+  pt.lap("layout: column map (host)");
+  TSEM_ALLOC(h->d_colmap, K);
+  TSEM_ALLOC(h->d_col_of_pc, h->Kpad);
+  TSEM_HIP(hipMemcpy(h->d_colmap, colmap.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice));
+  TSEM_HIP(hipMemcpy(h->d_col_of_pc, col_of_pc.data(), sizeof(int32_t) * h->Kpad, hipMemcpyHostToDevice));
+  // popularity ids for the report pass (k_report_rows): id = slot * P + part, 2 bytes per stored entry
+  const bool want_rid = h->Kpad <= 65536 && h->opt_report_kernel != 0 && h->nnz > 0;
+  if (want_rid) {
+    std::vector<int32_t> col_of_id(h->Kpad, -1);
+    for (int p = 0; p < P; ++p)
+      for (int sl = 0; sl < Kp; ++sl) col_of_id[sl * P + p] = col_of_pc[p * Kp + sl];
+    TSEM_ALLOC(h->d_col_of_id, h->Kpad);
+    TSEM_HIP(hipMemcpy(h->d_col_of_id, col_of_id.data(), sizeof(int32_t) * h->Kpad, hipMemcpyHostToDevice));
+    TSEM_ALLOC(h->d_rid16, h->nnz + TS_ENTRY_PAD);
+  }
+  pt.lap("layout: maps to the device, rid16 alloc");
+  // 3. row blocks.  Two-pass layout: R rows each.  Fused layout: as many consecutive rows as the
+  //    register tile takes (no part may exceed FZ_CAP entries, at most R rows) — rows per block vary,
+  //    every block still owns R row SLOTS (holes at the end), so all kernels keep b*R+lr indexing.
+  const int R = h->R;
+  int64_t nb = 0;
+  int64_t* d_bs = nullptr;                                 // first compact row of every block, [nb + 1]
+  unsigned long long* d_pc = nullptr;                      // per-row part counts (fused layout only)
+  bool rid_amb_done = false;
+  if (h->use_fused && na > 0 && P <= FZ_MAX_P) {
+    TSEM_ALLOC(d_pc, 2 * na);
+    {
+      int capc = 256;                                      // lanes per row x 16 entries, from the row-length histogram
+      for (int q = 1; q < 6; ++q)
+        if ((double)h->len_gt[q] <= 0.005 * (double)h->N) { capc = 8 << q; break; }
+      const int G = capc <= 16 ? 1 : capc <= 32 ? 2 : capc <= 64 ? 4 : capc <= 128 ? 8 : 16;
+      if ((size_t)K * 4 <= (size_t)TS_LDS_MAX - 2048 && na >= 65536) {   // the column map fits LDS (K <= 40k) and the matrix is worth a 120 KB preload per CU
+        auto pk = G == 1 ? k_row_partcounts<1, true> : G == 2 ? k_row_partcounts<2, true> : G == 4 ? k_row_partcounts<4, true>
+                : G == 8 ? k_row_partcounts<8, true> : k_row_partcounts<16, true>;
+        TSEM_HIP(hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        pk<<<h->n_cu, 1024, (size_t)K * 4, h->stream>>>(na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, K, d_pc, h->d_rid16, P);
+      } else {
+        const unsigned grid = (unsigned)std::min<int64_t>(65535, (na + 256 / G - 1) / (256 / G));
+        auto pk = G == 1 ? k_row_partcounts<1, false> : G == 2 ? k_row_partcounts<2, false> : G == 4 ? k_row_partcounts<4, false>
+                : G == 8 ? k_row_partcounts<8, false> : k_row_partcounts<16, false>;
+        pk<<<grid, 256, 0, h->stream>>>(na, h->d_amb_row, h->d_indptr, h->d_indices, h->d_colmap, K, d_pc, h->d_rid16, P);
+      }
+    }
+    TSEM_HIP(hipGetLastError());
+    rid_amb_done = true;
+    const int cap = fz_cap(h->geo) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
+    // chunk length: >= 64 blocks' worth of rows (the forced break at a chunk end costs ~0.8 % more blocks; round 2 used 256 blocks' worth,
+    // 484 sequential waves for 47M rows: 2 x 2.5 ms; four times as many waves walk a quarter each)
+    const int64_t L = std::max<int64_t>((int64_t)R * 64, (na + 16383) / 16384);
+    const int64_t nch = (na + L - 1) / L;
+    int64_t *d_cnt = nullptr, *d_off = nullptr;
+    int* d_flag = nullptr;
+    TSEM_ALLOC(d_cnt, nch + 1); TSEM_ALLOC(d_off, nch + 1); TSEM_ALLOC(d_flag, 1);
+    TSEM_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), h->stream));
+    TSEM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int64_t) * (nch + 1), h->stream));
+    k_block_greedy<<<(unsigned)nch, 64, 0, h->stream>>>(na, P, R, cap, L, 0, d_pc, d_cnt, nullptr, nullptr, d_flag);
+    TSEM_HIP(hipGetLastError());
+    {
+      size_t tb = 0;
+      TSEM_HIP(rocprim::exclusive_scan(nullptr, tb, d_cnt, d_off, (int64_t)0, (size_t)(nch + 1), rocprim::plus<int64_t>(), h->stream));
+      void* tmp = nullptr;
+      TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+      TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_cnt, d_off, (int64_t)0, (size_t)(nch + 1), rocprim::plus<int64_t>(), h->stream));
+      int flag = 0;
+      TSEM_HIP(hipMemcpyAsync(&nb, d_off + nch, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      (void)hipFree(tmp);
+      if (flag) { h->use_fused = false; nb = 0; }          // one row overflows the register tile
+    }
+    if (h->use_fused) {
+      TSEM_ALLOC(d_bs, nb + 1);
+      k_block_greedy<<<(unsigned)nch, 64, 0, h->stream>>>(na, P, R, cap, L, 1, d_pc, d_cnt, d_off, d_bs, d_flag);
+      TSEM_HIP(hipGetLastError());
+      TSEM_HIP(hipMemcpyAsync(d_bs + nb, &na, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+    }
+    (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_flag);
+    if (!h->use_fused) { (void)hipFree(d_pc); d_pc = nullptr; }
+  }
+  if (!d_bs) {                                             // two-pass layout: R rows per block
+    nb = (na + R - 1) / R;
+    TSEM_ALLOC(d_bs, nb + 1);
+    k_fixed_blocks<<<cdiv64(nb + 1, 256), 256, 0, h->stream>>>(nb, R, na, d_bs);
+    TSEM_HIP(hipGetLastError());
+  }
+  if (h->d_rid16 && h->N) {                                // the rows k_row_partcounts did not visit (all of them without the fused layout)
+    k_rid16_rows<<<(unsigned)std::min<int64_t>(65535, (h->N + 15) / 16), 256, 0, h->stream>>>(
+        h->N, h->d_indptr, h->d_indices, h->d_colmap, P, rid_amb_done ? 1 : 0, h->d_rid16);
+    TSEM_HIP(hipGetLastError());
+  }
+  h->nb = nb;
+  h->N_amb_pad = std::max<int64_t>(1, nb) * R;
+  {
+    TSEM_ALLOC(h->d_slot_row, h->N_amb_pad);
+    TSEM_ALLOC(h->d_amb_wcode, h->N_amb_pad);
+    if (nb) k_make_slots<<<(unsigned)nb, 256, 0, h->stream>>>(nb, R, d_bs, h->d_amb_row, h->d_amb_wcode_c,
+                                                             h->d_slot_row, h->d_amb_wcode);
+    else TSEM_HIP(hipMemsetAsync(h->d_amb_wcode, 0, sizeof(uint16_t) * h->N_amb_pad, h->stream));
+    TSEM_HIP(hipGetLastError());
+  }
+  pt.lap("layout: part counts, blocks, slots");
+  // 4. sub-block sizes -> offsets
+  std::vector<int64_t> sb(nb * P + 1, 0);
+  if (nb) {
+    int64_t* d_cnt = nullptr;
+    TSEM_ALLOC(d_cnt, nb * P);
+    if (d_pc) k_sb_count_pc<<<(unsigned)nb, 64, 0, h->stream>>>(nb, P, d_bs, d_pc, d_cnt);
+    else k_sb_count<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_colmap, d_cnt);
+    TSEM_HIP(hipGetLastError());
+    TSEM_HIP(hipMemcpyAsync(sb.data(), d_cnt, sizeof(int64_t) * nb * P, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_cnt);
+  }
+  if (h->use_fused) {
+    int64_t mx = 0;
+    for (int64_t i = 0; i < nb * P; ++i) mx = std::max(mx, sb[i]);
+    h->max_subblock = mx;
+    if (mx > fz_cap(h->geo)) h->use_fused = false;
+  }
+  int64_t off = 0;
+  for (int64_t i = 0; i < nb * P; ++i) {   // sub-blocks padded to TS_STRANDS*4 entries (strand-transposed order)
+    h->nnz_amb += sb[i];
+    int64_t c = (sb[i] + (TS_STRANDS * 4 - 1)) / (TS_STRANDS * 4) * (TS_STRANDS * 4);
+    sb[i] = off; off += c;
+  }
+  sb[nb * P] = off;
+  h->nnz_pad = off;
+  TSEM_ALLOC(h->d_sb_off, nb * P + 1);
+  TSEM_HIP(hipMemcpy(h->d_sb_off, sb.data(), sizeof(int64_t) * (nb * P + 1), hipMemcpyHostToDevice));
+  if (h->use_fused && (off >> 2) < 0xFFFFFFFFll) {
+    std::vector<uint32_t> q32(nb * P + 2, 0);
+    for (int64_t i = 0; i <= nb * P; ++i) q32[i] = (uint32_t)(sb[i] >> 2);
+    TSEM_ALLOC(h->d_sb_q32, nb * P + 2);
+    TSEM_HIP(hipMemcpy(h->d_sb_q32, q32.data(), sizeof(uint32_t) * (nb * P + 2), hipMemcpyHostToDevice));
+  } else if (h->use_fused) {
+    h->use_fused = false;
+  }
+  if (h->use_fused && (R > fz_rmax(h->geo) || (R & 1) || fz_lds_bytes(h, false) > (size_t)TS_LDS_MAX - 1024)) h->use_fused = false;
+  h->fmt_code = h->use_fused && fz_wants_codes(h) && fz_lds_bytes(h, true) <= (size_t)TS_LDS_MAX - 1024;
+  h->fmt_wcode = h->use_fused && !h->fmt_code && h->lut_len > 0 && h->lut_len <= 2048 &&
+                 fz_lds_bytes(h, true) <= (size_t)TS_LDS_MAX - 1024;
+  if (h->opt_format == 2 && !h->fmt_code)
+    TSEM_FAIL(TSEM_ERR_ARG, "value_format=codes needs the fused kernel and a score table of at most 2048 entries");
+  if (h->opt_reproducible && !(h->use_fused && (h->fmt_code || h->fmt_wcode)))
+    TSEM_FAIL(TSEM_ERR_ARG, "reproducible mode needs the fused kernel (at most 8 column parts, every row within the register tile) and a score "
+                            "table of at most 2048 entries");
+  pt.lap("layout: sub-block offsets");
+  TSEM_ALLOC(h->d_prc, off);
+  TSEM_HIP(hipMemsetAsync(h->d_prc, 0, sizeof(uint32_t) * std::max<int64_t>(1, off), h->stream));
+  if (h->fmt_code) {
+    TSEM_ALLOC(h->d_pcode, off);
+    TSEM_HIP(hipMemsetAsync(h->d_pcode, 0, sizeof(uint16_t) * std::max<int64_t>(1, off), h->stream));   // code 0 -> Q = 0
+  } else {
+    TSEM_ALLOC(h->d_pval, off);
+    TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
+  }
+  pt.lap("layout: entry buffers (alloc + zero)");
+  // Row order (row sums reduced in registers, a tenth of the LDS atomics) for every fused layout.  Score codes: 40
+  // entries per row at P = 4 4.44 -> 3.59 ms, 20 per row 2.30 -> 1.92, 10 per row 1.65 -> 1.40.  fp64 entries
+  // were indifferent to it while the exchange wave stalled behind the memory pipe (round 1: 4.62 against 4.57 ms);
+  // since the exchange is one generation per step, the step ends when the LDS queue has drained, and less LDS work
+  // shortens it for them too: 40 per row 4.33 -> 4.14 ms (0.73 of the HBM peak), teams of 8 4.42 -> 4.20, 20 per
+  // row 2.70 -> 2.48 (profiles/r02_sweep.txt, r02_sweep_short.txt).
+  h->sorted_layout = h->use_fused && R * P <= FILL_MAX_RP &&   // (the fill kernel keeps R x P counters in LDS)
+                     (h->opt_sorted >= 0 ? h->opt_sorted != 0 : true);
+  if (nb && h->sorted_layout) {
+    // the popularity ids stand in for the column-map gather when every row's ids are written (they are: k_row_partcounts +
+    // k_rid16_rows above) and the split columns' ids fit the small table
+    const uint16_t* rid_fill = nullptr;
+    uint8_t* d_lgtab = nullptr;
+    int nsplit = 0;
+    if (h->d_rid16 && P <= 8) {
+      std::vector<uint8_t> lgt;
+      for (int j = 0; j < K; ++j) {
+        const uint32_t cm = colmap[j], lg = (cm >> 13) & 7u;
+        if (lg) { const uint32_t id = (cm & 0x1FFFu) * P + (cm >> 16); if (id >= lgt.size()) lgt.resize(id + 1, 0); lgt[id] = (uint8_t)lg; }
+      }
+      nsplit = (int)lgt.size();
+      if (nsplit <= 4096) {
+        TSEM_ALLOC(d_lgtab, std::max(1, nsplit));
+        if (nsplit) TSEM_HIP(hipMemcpyAsync(d_lgtab, lgt.data(), nsplit, hipMemcpyHostToDevice, h->stream));
+        TSEM_HIP(hipStreamSynchronize(h->stream));         // (lgt is a local)
+        rid_fill = h->d_rid16;
+      }
+    }
+    const uint32_t magicP = (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P);
+    k_sb_fill_sorted<<<(unsigned)nb, 256, fill_lds_bytes(R, P), h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
+                                                         h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
+                                                         d_pc ? d_bs : nullptr, d_pc, rid_fill, magicP, nsplit, d_lgtab);
+    TSEM_HIP(hipGetLastError());
+    if (d_lgtab) { TSEM_HIP(hipStreamSynchronize(h->stream)); (void)hipFree(d_lgtab); }
+    TSEM_HIP(hipGetLastError());
+    // (reproducible mode keeps the row order: a row's entries in a sub-block then form ONE run, which ends in at most two LDS
+    // atomics on its row sum — two additions commute, three need not)
+    if (h->fmt_code && h->opt_deconflict != 0 && !h->opt_reproducible && off >= 64) {
+      const int64_t n_win = off / 64;
+      uint32_t* prc2 = nullptr; uint16_t* code2 = nullptr;
+      TSEM_ALLOC(prc2, off); TSEM_ALLOC(code2, off);
+      k_sb_deconflict<<<(unsigned)std::min<int64_t>(n_win / DC_NT + 1, (int64_t)h->n_cu * 32), DC_NT, 0, h->stream>>>(
+          n_win, h->d_prc, h->d_pcode, prc2, code2);
+      TSEM_HIP(hipGetLastError());
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      (void)hipFree(h->d_prc); (void)hipFree(h->d_pcode);
+      h->d_prc = prc2; h->d_pcode = code2;
+    }
+  } else if (nb) {
+    k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
+                                                  h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc);
+    TSEM_HIP(hipGetLastError());
+  }
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_bs);
+  if (d_pc) (void)hipFree(d_pc);
+  pt.lap("layout: fill + conflict-aware order");
+  if (!h->use_fused) TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad);   // partial row sums of the two-pass kernels
+  // launch geometry
+  const size_t lds1 = (size_t)(Kp + R) * 8, lds2 = (size_t)(2 * Kp + R) * 8;
+  if (lds2 > (size_t)TS_LDS_MAX - 1024) TSEM_FAIL(TSEM_ERR_ARG, "LDS budget exceeded (reduce block_rows)");
+  int w1 = std::max(1, std::min(4, (int)(TS_LDS_MAX / lds1)));   // 512-thread WGs per CU
+  int w2 = std::max(1, std::min(2, (int)(TS_LDS_MAX / lds2)));   // 1024-thread WGs per CU
+  h->G1 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w1 / P));
+  h->G2 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w2 / P));
+  if (!h->use_fused) TSEM_ALLOC(h->d_partial, (int64_t)h->G2 * h->Kpad);
+  if (h->use_fused) {
+    {
+      h->fz_grid = h->n_cu;
+      h->fz_teams = std::max(1, h->fz_grid / P);
+      TSEM_ALLOC(h->d_fpartial, (int64_t)h->fz_teams * h->Kpad);
+      TSEM_ALLOC(h->d_xchg, (int64_t)h->fz_teams * FZ_XS * P * R);
+      TSEM_ALLOC(h->d_xflags, FZ_SYNC_WORDS);
+      TSEM_HIP(hipMemset(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS));
+      if (!h->fmt_code && !h->fmt_wcode) {                 // fp64 row weights; otherwise the kernel reads d_amb_wcode
+        TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
+        k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
+      }
+      for (int mode = 0; mode < 2; ++mode)
+        TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h), h->geo),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      if (h->opt_reproducible) {
+        if (h->exact_single && !fz_kernel(P, 3, fz_fmt(h), h->geo)) h->exact_single = false;   // (not score codes after all: fz_lds_bytes then counts two tables again)
+        if (h->exact_single) TSEM_ALLOC(h->d_fpartial2, (int64_t)h->fz_teams * h->Kpad);
+        fz_fn f2 = fz_kernel(P, h->exact_single ? 3 : 2, fz_fmt(h), h->geo);
+        if (!f2) TSEM_FAIL(TSEM_ERR_ARG, "reproducible mode needs the fused kernel with a score table of at most 2048 entries");
+        TSEM_HIP(hipFuncSetAttribute((const void*)f2, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        TSEM_ALLOC(h->d_ebias, h->Kpad); TSEM_ALLOC(h->d_ovf, h->Kpad); TSEM_ALLOC(h->d_red_hi, K + 2); TSEM_ALLOC(h->d_binflag, 4);
+        TSEM_ALLOC(h->d_ehist, 2 * (size_t)K + 2);
+        if (int rc = tsem_bin_reset(h)) return rc;
+      }
+    }
+  }
+  if (int rc = tsem_twopass_attributes(h)) return rc;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  pt.lap("layout: launch buffers, attributes");
+  return TSEM_OK;
+}
+
+int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, const uint64_t* col_count,
+                   const uint64_t* col_hash, double pi_prior, double theta_prior) {
+  if (!h || !h->have_rowstats || !stats3 || !pisum0 || !col_count || !col_hash) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  PhaseTimer pt0(h->stream);
+  const int K = h->K;
+  h->col_count.assign(col_count, col_count + K);
+  {  // exact twin columns -> representative = smallest column index of the class
+    struct Sig { uint64_t count, hash; int col; };            // (sorted in place)
+    std::vector<Sig> sg((size_t)K);
+    for (int j = 0; j < K; ++j) sg[j] = Sig{col_count[j], col_hash[j], j};
+    std::sort(sg.begin(), sg.end(), [](const Sig& a, const Sig& b) {
+      if (a.count != b.count) return a.count < b.count;
+      if (a.hash != b.hash) return a.hash < b.hash;
+      return a.col < b.col;
+    });
+    std::vector<int> ord(K);
+    for (int j = 0; j < K; ++j) ord[j] = sg[j].col;
+    std::vector<int32_t> rep(K);
+    h->n_twin_cols = 0;
+    for (int i = 0; i < K;) {
+      int j = i;
+      while (j + 1 < K && col_count[ord[j + 1]] == col_count[ord[i]] && col_hash[ord[j + 1]] == col_hash[ord[i]]) ++j;
+      for (int t = i; t <= j; ++t) rep[ord[t]] = (col_count[ord[i]] == 0) ? ord[t] : ord[i];
+      if (j > i && col_count[ord[i]] != 0) h->n_twin_cols += (j - i + 1);
+      i = j + 1;
+    }
+    TSEM_ALLOC(h->d_twin_rep, K);
+    TSEM_HIP(hipMemcpy(h->d_twin_rep, rep.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice));
+    h->twin_rep_host = rep;
+  }
+  h->W_tot = stats3[0]; h->W_amb = stats3[1]; h->w_max = stats3[2];
+  h->pi_prior = pi_prior; h->theta_prior = theta_prior;
+  {
+    std::vector<double> ps(pisum0, pisum0 + K);
+    for (int j = 0; j < K; ++j) {   // twins: identical unique-row sums up to atomics order
+      int r = h->twin_rep_host[j];
+      if (r != j && std::fabs(ps[j] - ps[r]) <= 1e-12 * std::max(std::fabs(ps[j]), std::fabs(ps[r]))) ps[j] = ps[r];
+    }
+    TSEM_HIP(hipMemcpy(h->d_pisum0, ps.data(), sizeof(double) * K, hipMemcpyHostToDevice));
+  }
+  pt0.lap("set_model: twins, pisum0 (host)");
+  if (int rc = tsem_build_layout(h)) return rc;
+  pt0.lap("set_model: build_layout total");
+  TSEM_ALLOC(h->d_pi, K); TSEM_ALLOC(h->d_theta, K); TSEM_ALLOC(h->d_pi_prev, K); TSEM_ALLOC(h->d_theta_prev, K);
+  TSEM_ALLOC(h->d_tmp_pi, K); TSEM_ALLOC(h->d_tmp_theta, K);
+  TSEM_ALLOC(h->d_ctab, h->Kpad); TSEM_ALLOC(h->d_ctab_prev, h->Kpad);
+  if (!h->d_red) {
+    TSEM_ALLOC(h->d_red_own, K + 2);
+    h->d_red = h->d_red_own; h->red_count = K + 2;
+  } else if (h->red_count < K + 2) {
+    TSEM_FAIL(TSEM_ERR_ARG, "bound reduce buffer is smaller than K+2 doubles");
+  }
+  TSEM_HIP(hipMemsetAsync(h->d_ctab, 0, sizeof(double) * h->Kpad, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_ctab_prev, 0, sizeof(double) * h->Kpad, h->stream));
+  const double init = 1.0 / (double)K;   // model.py:667,673
+  k_fill<<<cdiv64(K, 256), 256, 0, h->stream>>>(h->d_pi, K, init);
+  k_fill<<<cdiv64(K, 256), 256, 0, h->stream>>>(h->d_theta, K, init);
+  k_fill<<<cdiv64(K, 256), 256, 0, h->stream>>>(h->d_pi_prev, K, init);
+  k_fill<<<cdiv64(K, 256), 256, 0, h->stream>>>(h->d_theta_prev, K, init);
+  k_make_ctab<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, h->d_colmap, h->Kp, h->d_ctab);
+  k_make_ctab<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, h->d_colmap, h->Kp, h->d_ctab_prev);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  h->have_model = true;
+  h->lnl_prev_seed = INFINITY;                             // model.py:683
+  h->em_cur = h->em_prev = true;                           // pi = theta = 1/K
+  return TSEM_OK;
+}
+
+int tsem_make_ctabs(tsem_ctx* h) {
+  k_make_ctab<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_pi, h->d_theta, h->d_colmap, h->Kp, h->d_ctab);
+  k_make_ctab<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab_prev);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
+
+int tsem_set_params(tsem_ctx* h, const double* pi, const double* theta) {
+  if (!h || !h->have_model || !pi || !theta) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  h->em_prev = h->em_cur; h->em_cur = false;               // arbitrary values (possibly 0): no shortcut in tsem_reassign
+  const int K = h->K;
+  TSEM_HIP(hipMemcpyAsync(h->d_pi_prev, h->d_pi, sizeof(double) * K, hipMemcpyDeviceToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_theta_prev, h->d_theta, sizeof(double) * K, hipMemcpyDeviceToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_ctab_prev, h->d_ctab, sizeof(double) * h->Kpad, hipMemcpyDeviceToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_pi, pi, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(h->d_theta, theta, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
+  k_make_ctab<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, h->d_pi, h->d_theta, h->d_colmap, h->Kp, h->d_ctab);
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return tsem_bin_reset(h);
+}
+
+int tsem_get_params(tsem_ctx* h, int which, double* pi, double* theta) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  if (which == TSEM_Z_FIRST && !h->d_pi_first) TSEM_FAIL(TSEM_ERR_ARG, "no EM run yet: pi_init / theta_init are not set");
+  const double* sp = which == TSEM_Z_FIRST ? h->d_pi_first : (which == TSEM_Z_PREV ? h->d_pi_prev : h->d_pi);
+  const double* st = which == TSEM_Z_FIRST ? h->d_theta_first : (which == TSEM_Z_PREV ? h->d_theta_prev : h->d_theta);
+  if (pi) TSEM_HIP(hipMemcpy(pi, sp, sizeof(double) * h->K, hipMemcpyDeviceToHost));
+  if (theta) TSEM_HIP(hipMemcpy(theta, st, sizeof(double) * h->K, hipMemcpyDeviceToHost));
+  return TSEM_OK;
+}
+
+int tsem_reduce_buffer(tsem_ctx* h, void** dptr, int64_t* count) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (dptr) *dptr = h->d_red;
+  if (count) *count = h->K + 2;
+  return TSEM_OK;
+}
+
+int tsem_bind_reduce_buffer(tsem_ctx* h, void* dptr, int64_t count) {
+  if (!h || !dptr) return TSEM_ERR_ARG;
+  if (h->K && count < h->K + 2) TSEM_FAIL(TSEM_ERR_ARG, "reduce buffer needs K+2 doubles");
+  h->d_red = (double*)dptr;
+  h->red_count = count;
+  return TSEM_OK;
+}
+
+
+}  // extern "C"

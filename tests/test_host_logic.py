@@ -173,10 +173,10 @@ def test_single_process_cli_runs_do_not_import_torch():
 
 
 def test_every_translation_unit_is_built():
-    """telescope_amd/_lib.py compiles tsem.hip and the units that instantiate the fused kernel in parallel: every *.hip under csrc/
+    """telescope_amd/_lib.py compiles the library's units and the units that instantiate the fused kernel in parallel: every *.hip under csrc/
     must be on its list (a unit left out would only show up as a missing kernel at run time)."""
     import glob
     from telescope_amd import _lib
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'telescope_amd', 'csrc')
     on_disk = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(csrc, '*.hip')))
-    assert on_disk == sorted(['tsem'] + list(_lib.FZ_UNITS))
+    assert on_disk == sorted(list(_lib.LIB_UNITS) + list(_lib.FZ_UNITS))
