@@ -80,6 +80,9 @@ def parse():
                     help='DRY RUN of --gpus N on a box with fewer GPUs: every rank uses device 0, torch.distributed gloo, the reduce '
                          'buffer staged through the host (RCCL refuses two ranks on one device).  Exercises the launcher, the row '
                          'shards, the set-up and per-iteration collectives and the result line; its throughput means nothing')
+    ap.add_argument('--fail-rank', type=int, default=-1,
+                    help='TEST HOOK: the persistent kernel of this rank reports a hand-off time-out in its first EM pass (fused_dbg bit 5); '
+                         'every rank must refuse to commit, this rank falls back to the two-pass kernels, all redo the iteration')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the multi-rank code path (RCCL group, per-iteration all-reduce) even at world size 1')
     return ap.parse_args()
@@ -254,8 +257,8 @@ def main():
         eng.set_option('sorted_fill', args.sorted_fill)
     if args.chunk_blocks:
         eng.set_option('chunk_blocks', args.chunk_blocks)
-    if args.fused_dbg:
-        eng.set_option('fused_dbg', args.fused_dbg)
+    if args.fused_dbg or args.fail_rank == rank:
+        eng.set_option('fused_dbg', args.fused_dbg | (32 if args.fail_rank == rank else 0))
     eng.set_option('hot_split', args.hot_split)
     eng.set_option('deconflict', args.deconflict)
     eng.set_option('kernel_timing', args.kernel_timing)

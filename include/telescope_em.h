@@ -297,6 +297,9 @@ int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launch
 int  tsem_layout_info(tsem_ctx* h, int64_t* info24);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
+/* the same option's start-up timeline: per workgroup b (up to 512), out[8 b ..] = 100 MHz wall clock at entry / tickets counted /
+ * LDS zeroed / tables loaded / loop start / loop end / exit, and (team << 32 | member << 16 | blocks) */
+int  tsem_debug_fused_startup(tsem_ctx* h, uint64_t* out4096);
 /* the packed local row / local column words of one sub-block of the blocked layout (layout studies) */
 int64_t tsem_debug_subblock(tsem_ctx* h, int64_t block, int32_t part, uint32_t* out, int64_t cap);
 /* y[i] = the device log1p the lnl passes use (finite x >= 0), for accuracy tests against libm */

@@ -162,6 +162,7 @@ def lib():
     L.tsem_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
     L.tsem_layout_info.argtypes = [vp, vp]
     L.tsem_debug_fused_prof.argtypes = [vp, vp]
+    L.tsem_debug_fused_startup.argtypes = [vp, vp]
     L.tsem_debug_log1p.argtypes = [C.c_int, C.c_int32, vp, vp]
     L.tsem_debug_log1p_tab.argtypes = [C.c_int, C.c_int32, vp, vp]
     L.tsem_debug_subblock.argtypes = [vp, C.c_int64, C.c_int32, vp, C.c_int64]
@@ -471,6 +472,13 @@ class Engine(object):
     def fused_prof(self):
         out = np.zeros((64, 16), np.uint64)
         self._ck(self._L.tsem_debug_fused_prof(self._h, ptr(out)))
+        return out
+
+    def fused_startup(self):
+        """Start-up timeline of the last profiled fused launch: [workgroup][entry, counted, zeroed, tables, loop start, loop end, exit, id]
+        in 10 ns ticks (include/telescope_em.h)."""
+        out = np.zeros((512, 8), np.uint64)
+        self._ck(self._L.tsem_debug_fused_startup(self._h, ptr(out)))
         return out
 
     def debug_subblock(self, block, part, cap=8192):

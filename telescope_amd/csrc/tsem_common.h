@@ -154,6 +154,7 @@ struct tsem_ctx {
   uint32_t* d_sb_q32 = nullptr;     // [nb*P+2] sub-block offsets / 4
   bool fused_launched = false;
   unsigned long long* d_prof = nullptr;
+  int prof_steps = 64;
 
   // ---- parameters ----
   double *d_pi = nullptr, *d_theta = nullptr, *d_pi_prev = nullptr, *d_theta_prev = nullptr;
@@ -199,6 +200,7 @@ struct tsem_ctx {
 };
 
 constexpr int TS_DIFF_RING = 65536;
+constexpr int TS_PROF_WORDS = 64 * 16 + 512 * 8;   // option "fused_prof": per-step slots of team 0 + start-up stamps of up to 512 workgroups
 
 struct tsem_local_group;            // in-process transport: several handles on ONE device (tsem_comm_create_local)
 

@@ -401,7 +401,7 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
   A.ctab = lnl ? h->d_ctab_prev : h->d_ctab; A.ctab2 = h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = lnl ? 1 : 0;
   A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg; A.sorted = h->sorted_layout ? 1 : 0;
   A.sync = h->d_xflags;
-  A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? 64 : 0; A.dbg = (int)h->opt_dbg;
+  A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? h->prof_steps : 0; A.dbg = (int)h->opt_dbg;
   A.ctl = h->d_ctl;
   A.ebias = h->d_ebias; A.bin = bin; A.ovf = h->d_ovf; A.partial2 = h->d_fpartial2;
 

@@ -472,34 +472,72 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   uint32_t* const sync = A.sync;
   uint32_t* const err = sync + 9;
   if (A.ctl && fz_ld_u32(A.ctl) != 0u) return;            // stopped by an earlier update kernel of this chunk
+  // start-up timeline (tools/startup_prof.py): 100 MHz wall clock of every workgroup's thread 0 at entry / tickets counted / LDS
+  // zeroed / tables loaded / loop start / loop end / exit, behind the per-step slots of team 0
+  unsigned long long* const sprof = (A.prof && tid == 0) ? A.prof + 64 * FZ_PROF_SLOTS + (size_t)blockIdx.x * 8 : nullptr;
+  if (sprof) sprof[0] = wall_clock64();
   if (A.dbg & (MODE != 1 ? 32 : 64)) {                    // test hook: what a watchdog time-out leaves behind
     if (blockIdx.x == 0 && tid == 0) atomicOr(err, 2u);
     return;
   }
 
   // ---- team formation from the hardware XCC id --------------------------------
+  // Round 4: the start-up took 17.6 us of a 560 us shard pass (tools/startup_prof.py: every workgroup enters within 1.2 us, but
+  // had the tickets counted only 13 us later — two dependent device-scope atomics, a release fence (an L2 write-back per
+  // workgroup) and a polling loop of two uncached loads per turn — and loaded its tables after that).  Now: ONE atomic gives the
+  // ticket, hence the column part; the part's tables are loaded and the LDS is zeroed WHILE the other workgroups take theirs; the
+  // count every workgroup waits for is the sum of the eight ticket counters themselves (no second counter, no fence: nothing but
+  // the counters is communicated).
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
-  if (tid == 0) {
-    ibox[0] = (int)atomicAdd(&sync[xcc], 1u);
-    __threadfence();
-    atomicAdd(&sync[8], 1u);
-    unsigned spins = 0;
-    while (fz_ld_u32(&sync[8]) < gridDim.x) {          // every workgroup has taken its ticket
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > FZ_SPIN_LIMIT) { atomicOr(err, 1u); break; }
-      if (fz_ld_u32(err)) break;
-    }
-    for (int x = 0; x < 8; ++x) ibox[1 + x] = (int)fz_ld_u32(&sync[x]);
-  }
+  if (tid == 0) ibox[0] = (int)__hip_atomic_fetch_add(&sync[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int t = tid; t < Kp; t += FZ_NT) acc[t] = 0.0;   // (lnl mode: overwritten with ctab2 below)
   if (MODE == 3) for (int t = tid; t < Kp; t += FZ_NT) acc2[t] = 0.0;
   for (int t = tid; t < FZ_YR * R; t += FZ_NT) y[t] = 0.0;
   for (int t = tid; t < 2 * R; t += FZ_NT) s[t] = 0.0;
+  uint32_t* offs = reinterpret_cast<uint32_t*>(ibox + 16);   // [8][2] sub-block quad ranges (ring), LDS
+  double* dum = reinterpret_cast<double*>(ibox + 32);        // [64] one slot per lane: where idle lanes send their (zero) atomics
+  double* lutS = dum + 64;                                   // FMT 1: score table [lut_len]
+  if (tid < 64) dum[tid] = 0.0;
+  if (FMT != 0)
+    for (int t = tid; t < A.lut_len; t += FZ_NT) lutS[t] = A.lut[t];
+  uint16_t* const eS = reinterpret_cast<uint16_t*>(lutS + A.lut_len);   // MODE 2: [Kp] the slots' exponent bounds
+  // MODE 1: [FZ_LOGTAB] (1 / c_i, log c_i) for fz_log1p_tab, in the same place (the two modes never share a launch)
+  double2* const logtab = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(lutS + A.lut_len) + 15) & ~(uintptr_t)15);
+  if (MODE == 1 && tid < FZ_LOGTAB) {
+    const double ci = 1.0 + (double)tid * (1.0 / FZ_LOGTAB);
+    logtab[tid] = make_double2(1.0 / ci, ts_log1p_pos((double)tid * (1.0 / FZ_LOGTAB)));
+  }
   __syncthreads();
+  if (sprof) sprof[2] = wall_clock64();
   const int ticket = __builtin_amdgcn_readfirstlane(ibox[0]);   // LDS broadcasts: tell the compiler they are uniform
   const int u = ticket / P, p = ticket % P;
+  for (int t = tid; t < Kp; t += FZ_NT) c[t] = A.ctab[p * Kp + t];
+  if (MODE == 1)
+    for (int t = tid; t < Kp; t += FZ_NT) acc[t] = A.ctab2[p * Kp + t];
+  if (MODE >= 2)
+    for (int t = tid; t < Kp; t += FZ_NT) eS[t] = A.ebias[p * Kp + t];
+  if (tid == 0) {
+    unsigned spins = 0;
+    for (;;) {                                             // every workgroup has taken its ticket
+      unsigned tot = 0;
+      int cnt[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) { cnt[x] = (int)fz_ld_u32(&sync[x]); tot += (unsigned)cnt[x]; }
+      if (tot >= gridDim.x) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) ibox[1 + x] = cnt[x];
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > FZ_SPIN_LIMIT) { atomicOr(err, 1u); break; }
+      if ((spins & 15u) == 0 && fz_ld_u32(err)) break;
+    }
+    if (sprof) sprof[1] = wall_clock64();
+  }
+  __syncthreads();
+  if (sprof) sprof[3] = wall_clock64();
   int T = 0, tbase = 0;
   for (int x = 0; x < 8; ++x) {
     int teams = __builtin_amdgcn_readfirstlane(ibox[1 + x]) / P;
@@ -509,11 +547,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   const bool valid = (u + 1) * P <= __builtin_amdgcn_readfirstlane(ibox[1 + xcc]) && fz_ld_u32(err) == 0;
   if (!valid || T == 0) return;                          // leftover workgroup of an incomplete team
   const int team = tbase + u;                            // 0..T-1
-  for (int t = tid; t < Kp; t += FZ_NT) c[t] = A.ctab[p * Kp + t];
-  if (MODE == 1)
-    for (int t = tid; t < Kp; t += FZ_NT) acc[t] = A.ctab2[p * Kp + t];
   unsigned long long* const xbase = reinterpret_cast<unsigned long long*>(A.xchg) + (int64_t)team * FZ_XS * P * R;
-  __syncthreads();
 
   // Block k of this team is row block team + k*T.  Schedule of one block:
   //   step k-2 : prefetch burst          load(k)            -> register set k % 6
@@ -534,21 +568,6 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   auto tag_of = [&](int64_t k) -> unsigned long long {   // slot k % XS is rewritten every XS blocks; first tag is 1
     return (unsigned long long)((((k / FZ_XS) & 1) ^ 1));
   };
-  uint32_t* offs = reinterpret_cast<uint32_t*>(ibox + 16);   // [8][2] sub-block quad ranges (ring), LDS
-  double* dum = reinterpret_cast<double*>(ibox + 32);        // [64] one slot per lane: where idle lanes send their (zero) atomics
-  double* lutS = dum + 64;                                   // FMT 1: score table [lut_len]
-  if (tid < 64) dum[tid] = 0.0;
-  if (FMT != 0)
-    for (int t = tid; t < A.lut_len; t += FZ_NT) lutS[t] = A.lut[t];
-  uint16_t* const eS = reinterpret_cast<uint16_t*>(lutS + A.lut_len);   // MODE 2: [Kp] the slots' exponent bounds
-  // MODE 1: [FZ_LOGTAB] (1 / c_i, log c_i) for fz_log1p_tab, in the same place (the two modes never share a launch)
-  double2* const logtab = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(lutS + A.lut_len) + 15) & ~(uintptr_t)15);
-  if (MODE == 1 && tid < FZ_LOGTAB) {
-    const double ci = 1.0 + (double)tid * (1.0 / FZ_LOGTAB);
-    logtab[tid] = make_double2(1.0 / ci, ts_log1p_pos((double)tid * (1.0 / FZ_LOGTAB)));
-  }
-  if (MODE >= 2)
-    for (int t = tid; t < Kp; t += FZ_NT) eS[t] = A.ebias[p * Kp + t];
   const int64_t nsteps = nblk + FZ_LAG + 1;               // last scatter is block nblk-1 at step nblk+3
   // prologue: offsets of blocks 0..4 straight into LDS
   if (tid < 10) {
@@ -556,6 +575,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     if (k < nblk) offs[tid] = A.sb_q32[(team + k * T) * P + p + (tid & 1)];
   }
   __syncthreads();
+  if (sprof) { sprof[4] = wall_clock64(); sprof[7] = ((unsigned long long)xcc << 48) | ((unsigned long long)team << 32) | ((unsigned long long)p << 16) | (unsigned long long)nblk; }
 
   double lsum = 0.0;                                      // lnl mode: this thread's share of the sum
 #ifdef FZ_EXPERIMENT
@@ -827,6 +847,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
 #endif
   }
   __syncthreads();
+  if (sprof) sprof[5] = wall_clock64();
   if (MODE == 1) {                                        // one partial per workgroup, summed by k_sum_parts
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
     double* wsum = y;                                     // the y ring is idle now
@@ -851,4 +872,5 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     double* out2 = A.partial2 + (int64_t)team * (P * Kp) + p * Kp;
     for (int t = tid; t < Kp; t += FZ_NT) out2[t] = acc2[t];
   }
+  if (sprof) sprof[6] = wall_clock64();
 }

@@ -182,8 +182,9 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "report_lanes") h->opt_report_lanes = v;     // capacity (lanes per row x entries per lane) of k_report_rows: 8 .. 256 (0 = from the row lengths)
   else if (k == "issue_early") h->opt_issue = v;       // (kept for old scripts; the exchange has one order now)
   else if (k == "fused_prof") {
-    if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, 64 * 16 * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
-    if (h->d_prof) (void)hipMemset(h->d_prof, 0, 64 * 16 * 8);
+    if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, TS_PROF_WORDS * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
+    if (h->d_prof) (void)hipMemset(h->d_prof, 0, TS_PROF_WORDS * 8);
+    h->prof_steps = v == 2 ? 0 : 64;                       // 2: the start-up stamps only (the per-step stamps slow team 0 down)
   }
   else TSEM_FAIL(TSEM_ERR_ARG, "unknown option " + k);
   return TSEM_OK;
@@ -413,6 +414,13 @@ int tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out /* 64*16 */) {
   if (!h || !h->d_prof || !out) return TSEM_ERR_ARG;
   TSEM_HIP(hipStreamSynchronize(h->stream));
   TSEM_HIP(hipMemcpy(out, h->d_prof, 64 * 16 * 8, hipMemcpyDeviceToHost));
+  return TSEM_OK;
+}
+
+int tsem_debug_fused_startup(tsem_ctx* h, uint64_t* out /* 512*8 */) {
+  if (!h || !h->d_prof || !out) return TSEM_ERR_ARG;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  TSEM_HIP(hipMemcpy(out, h->d_prof + 64 * 16, 512 * 8 * 8, hipMemcpyDeviceToHost));
   return TSEM_OK;
 }
 
