@@ -172,15 +172,32 @@ int  tsem_em_steps(tsem_ctx* h, int32_t n, double* diffs_out /* n or NULL */);
  * or the lnl test) is decided ON THE DEVICE: the update kernel raises a stop
  * flag and every kernel enqueued behind it returns at once, so the host
  * synchronises once per chunk, not once per iteration, and the state after the
- * call is exactly the reference's after its last iteration.  first != 0 starts
- * a run (lnl_prev = inf, the next update saves pi_init / theta_init).
+ * call is exactly the reference's after its last iteration.  flags bit 0
+ * starts a run (lnl_prev = inf or tsem_set_prev_lnl, the next update saves
+ * pi_init / theta_init).
  * *n_done = iterations committed, *stopped = 1 when the convergence test fired.
+ * use_likelihood on a layout built for it (option "use_likelihood" = 1 before
+ * tsem_set_model, or tsem_prepare_likelihood): no lnl pass per iteration — the
+ * EM pass of iteration t+1 also sums lnl_t = sum z_t log1p(Q c_t) (model.py:
+ * 783-789: its numerators ARE Q c_t; pi*theta of the previous parameters is a
+ * third LDS table, the previous row sums are kept per row), and that
+ * iteration's update kernel tests |lnl_t - lnl_(t-1)| < epsilon BEFORE it
+ * commits: a run that converges in iteration t ends in the state of iteration
+ * t.  The lnl of the chunk's LAST iteration is then unknown when the chunk
+ * returns (lnls_out[n_done - 1] = NaN): it arrives as *lnl_carry of the next
+ * chunk — which may do nothing else: n_done = 0, stopped = 1 — or, with flags
+ * bit 1 (last chunk of the run), from the dedicated lnl pass before the call
+ * returns.  *lnl_carry is NaN when nothing was owed.
  * A hand-off time-out of the fused kernel on ANY rank (the flag travels in the
  * all-reduce) leaves the parameters untouched on every rank; the failing rank
  * rebuilds its layout for the two-pass kernels and the iteration is redone. */
-int  tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likelihood, int32_t first,
+int  tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likelihood, int32_t flags,
                    int32_t* n_done, int32_t* stopped, double* diffs_out /* n_max or NULL */,
-                   double* lnls_out /* n_max or NULL */);
+                   double* lnls_out /* n_max or NULL */, double* lnl_carry /* 1 or NULL */);
+/* em(use_likelihood=True) on a model laid out without option "use_likelihood": rebuild the blocked layout so that the EM
+ * pass can carry the log-likelihood (above).  A no-op when the layout has it or cannot have it (two-pass kernels, fp64
+ * entries, option "reproducible", K > 8 x 5056): tsem_em_chunk then runs the lnl pass every iteration. */
+int  tsem_prepare_likelihood(tsem_ctx* h);
 /* Switch this handle to the two-pass kernels (rebuilds the blocked layout, keeps the parameters): what
  * tsem_em_chunk does after a time-out; public for hosts that drive pass / update themselves. */
 int  tsem_fallback_twopass(tsem_ctx* h);

@@ -32,10 +32,11 @@ static inline double recip0(double v) { double r = 1.0 / v; return isinf(r) ? 0.
 
 /* returns the number of iterations run, or -1 on allocation failure.
  * out: pi[K], theta[K], pi_init[K] (after the first iteration), *lnl, *converged, diffs[max_iter] (may be NULL) */
-int oracle_em_fused2(int64_t N, int32_t K, const int64_t* indptr, const int32_t* indices, const uint16_t* raw,
+/* (oracle_em_fused3: lnls[max_iter] (may be NULL) = the log-likelihood of every iteration under use_likelihood, model.py:785) */
+int oracle_em_fused3(int64_t N, int32_t K, const int64_t* indptr, const int32_t* indices, const uint16_t* raw,
                      const double* lut, double pi_prior, double theta_prior, double epsilon, int32_t max_iter,
                      int32_t use_likelihood, int32_t nthreads, double* pi, double* theta, double* pi_init, double* lnl,
-                     int32_t* converged, double* diffs) {
+                     int32_t* converged, double* diffs, double* lnls) {
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
   const int T = omp_get_max_threads();
@@ -117,6 +118,7 @@ int oracle_em_fused2(int64_t N, int32_t K, const int64_t* indptr, const int32_t*
       }
       if (use_likelihood) conv = fabs(l - total_lnl) < epsilon;       /* model.py:786-788; self.lnl starts at inf (model.py:676) */
       total_lnl = l;
+      if (lnls) lnls[it - 1] = l;
     }
     memcpy(pi, pin, sizeof(double) * K);
     memcpy(theta, thn, sizeof(double) * K);
@@ -126,6 +128,14 @@ int oracle_em_fused2(int64_t N, int32_t K, const int64_t* indptr, const int32_t*
   if (converged) *converged = conv;
   free(acc); free(pisum0); free(c); free(pin); free(thn); free(w);
   return it;
+}
+
+int oracle_em_fused2(int64_t N, int32_t K, const int64_t* indptr, const int32_t* indices, const uint16_t* raw,
+                     const double* lut, double pi_prior, double theta_prior, double epsilon, int32_t max_iter,
+                     int32_t use_likelihood, int32_t nthreads, double* pi, double* theta, double* pi_init, double* lnl,
+                     int32_t* converged, double* diffs) {
+  return oracle_em_fused3(N, K, indptr, indices, raw, lut, pi_prior, theta_prior, epsilon, max_iter, use_likelihood, nthreads, pi,
+                          theta, pi_init, lnl, converged, diffs, (double*)0);
 }
 
 int oracle_em_fused(int64_t N, int32_t K, const int64_t* indptr, const int32_t* indices, const uint16_t* raw,

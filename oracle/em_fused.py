@@ -25,6 +25,9 @@ def lib():
         L.oracle_em_fused2.restype = C.c_int
         L.oracle_em_fused2.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, dbl, dbl, dbl, C.c_int32, C.c_int32, C.c_int32,
                                        vp, vp, vp, vp, vp, vp]
+        L.oracle_em_fused3.restype = C.c_int
+        L.oracle_em_fused3.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, dbl, dbl, dbl, C.c_int32, C.c_int32, C.c_int32,
+                                       vp, vp, vp, vp, vp, vp, vp]
         L.oracle_exclude_counts.restype = C.c_int
         L.oracle_exclude_counts.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
         _lib = L
@@ -67,11 +70,12 @@ def em_fused_arrays(indptr, indices, data, k, pi_prior=0, theta_prior=200000, ep
     lut = np.ascontiguousarray(score_lut(int(data.max())) if data.size else np.zeros(1))
     pi, theta, pi_init = np.zeros(k), np.zeros(k), np.zeros(k)
     lnl, conv = C.c_double(), C.c_int32()
-    diffs = np.zeros(max(1, max_iter))
+    diffs, lnls = np.zeros(max(1, max_iter)), np.zeros(max(1, max_iter))
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    it = lib().oracle_em_fused2(n, k, p(indptr), p(indices), p(data), p(lut), float(pi_prior), float(theta_prior),
+    it = lib().oracle_em_fused3(n, k, p(indptr), p(indices), p(data), p(lut), float(pi_prior), float(theta_prior),
                                 float(epsilon), int(max_iter), 1 if use_likelihood else 0, int(nthreads), p(pi), p(theta),
-                                p(pi_init), C.addressof(lnl), C.addressof(conv), p(diffs))
+                                p(pi_init), C.addressof(lnl), C.addressof(conv), p(diffs), p(lnls))
     if it < 0:
         raise MemoryError('oracle_em_fused')
-    return dict(pi=pi, theta=theta, pi_init=pi_init, lnl=lnl.value, n_iter=it, converged=bool(conv.value), diffs=diffs[:it])
+    return dict(pi=pi, theta=theta, pi_init=pi_init, lnl=lnl.value, n_iter=it, converged=bool(conv.value), diffs=diffs[:it],
+                lnls=lnls[:it] if use_likelihood else None)

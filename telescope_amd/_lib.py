@@ -122,7 +122,8 @@ def lib():
     L.tsem_lnl_pass.argtypes = [vp]
     L.tsem_read_reduce.argtypes = [vp, vp, i64, i64]
     L.tsem_em_steps.argtypes = [vp, i32, vp]
-    L.tsem_em_chunk.argtypes = [vp, i32, dbl, i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp]
+    L.tsem_em_chunk.argtypes = [vp, i32, dbl, i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp, C.POINTER(dbl)]
+    L.tsem_prepare_likelihood.argtypes = [vp]
     L.tsem_fallback_twopass.argtypes = [vp]
     L.tsem_recover_timeout.argtypes = [vp, C.POINTER(i32)]
     L.tsem_final_lnl.argtypes = [vp, C.POINTER(dbl)]
@@ -318,16 +319,24 @@ class Engine(object):
         self._ck(self._L.tsem_em_steps(self._h, int(n), ptr(out)))
         return out
 
-    def em_chunk(self, n_max, epsilon=0.0, use_likelihood=False, first=False):
+    def em_chunk(self, n_max, epsilon=0.0, use_likelihood=False, first=False, last=False):
         """Up to `n_max` iterations of the em() loop body enqueued back to back; convergence is decided on
-        the device (include/telescope_em.h).  Returns (diffs, lnls, stopped) of the committed iterations."""
+        the device (include/telescope_em.h).  Returns (diffs, lnls, stopped) of the committed iterations.
+        With `use_likelihood` on a layout prepared for it (`prepare_likelihood`) the lnl of the chunk's last
+        iteration is NaN unless `last` (it comes with the next chunk: `self.lnl_carry`, NaN when nothing was owed)."""
         n_max = int(n_max)
         diffs, lnls = np.empty(max(1, n_max)), np.empty(max(1, n_max))
-        done, stopped = C.c_int32(), C.c_int32()
-        self._ck(self._L.tsem_em_chunk(self._h, n_max, float(epsilon), int(bool(use_likelihood)), int(bool(first)),
-                                       C.byref(done), C.byref(stopped), ptr(diffs), ptr(lnls)))
+        done, stopped, carry = C.c_int32(), C.c_int32(), C.c_double(float('nan'))
+        self._ck(self._L.tsem_em_chunk(self._h, n_max, float(epsilon), int(bool(use_likelihood)), int(bool(first)) | (2 if last else 0),
+                                       C.byref(done), C.byref(stopped), ptr(diffs), ptr(lnls), C.byref(carry)))
         n = done.value
+        self.lnl_carry = carry.value
         return diffs[:n], (lnls[:n] if use_likelihood else None), bool(stopped.value)
+
+    def prepare_likelihood(self):
+        """em(use_likelihood=True): lay the matrix out so that the EM pass carries the previous iteration's log-likelihood
+        (a no-op when it is, or cannot be; include/telescope_em.h)."""
+        self._ck(self._L.tsem_prepare_likelihood(self._h))
 
     def set_prev_lnl(self, lnl):
         """The lnl the next run's first iteration is compared with under use_likelihood (model.py:786)."""
@@ -493,7 +502,7 @@ class Engine(object):
         self._ck(self._L.tsem_layout_info(self._h, ptr(info)))
         return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad', 'twin_cols',
                          'G1', 'G2', 'fused', 'slow_path', 'max_subblock', 'value_bytes', 'hot_cols',
-                         'lds_bytes', 'row_order', 'geometry', 'fallbacks', 'bin_repeats', 'reproducible', 'exact_single'), info.tolist()))
+                         'lds_bytes', 'row_order', 'geometry', 'fallbacks', 'bin_repeats', 'reproducible', 'exact_single', 'lnl_fused'), info.tolist()))
 
 
 def legacy_randint(counts):

@@ -48,6 +48,7 @@ __host__ __device__ inline uint64_t ts_hash3(uint64_t seed, uint64_t row, uint64
 // LDS budget for the per-part tables (c and acc, 8 B each per column).
 constexpr int TS_LDS_TABLE_BYTES = 120 * 1024;
 constexpr int TS_MAX_KP = TS_LDS_TABLE_BYTES / 16;   // 7680 columns per part
+constexpr int TS_MAX_KP_LNL = 5120;                  // ... when a part keeps pi*theta of TWO parameter sets and the accumulators (option "use_likelihood": 24 B per column)
 constexpr int TS_MAX_KP3 = 4800;                     // ... when a part keeps THREE tables in LDS (option "reproducible", one pass: 26 B per column)
 constexpr int TS_LDS_MAX = 160 * 1024;
 constexpr int TS_ENTRY_PAD = 320;   // entries of padding behind indices[] / raw[] (k_report_rows reads 16-entry lanes past a row's end)
@@ -121,6 +122,12 @@ struct tsem_ctx {
   uint16_t* d_ebias = nullptr;      // [Kpad] per slot: biased exponent of the bound 2^E of its contributions
   uint8_t* d_ovf = nullptr;         // [Kpad] a contribution reached its slot's bound in the last pass
   double* d_red_hi = nullptr;       // [K+2] column sums of the high pieces
+  int64_t opt_lnl_fused = 0;        // option "use_likelihood" = 1: lay the matrix out so that the EM pass can sum the previous iteration's log-likelihood
+                                    //    as well (fused kernel MODE 4: three tables per part in LDS, tsem_fused.h); tsem_em_chunk then needs no lnl pass per iteration
+  bool lnl3 = false;                // the current layout allows it
+  double* d_rinv = nullptr;         // [N_amb_pad] recip0(row sum) of the last MODE 4 pass (what the next one needs of its E-step)
+  bool lag_agreed = false;          // row-sharded runs: EVERY rank can run MODE 4 (decided once per run, dropped for good after a time-out anywhere)
+  bool lag_valid = false;           // the iteration committed last still owes its lnl, and d_rinv / d_ctab_prev are what the next MODE 4 pass needs for it
   bool exact_single = false;        // reproducible: both pieces in ONE pass (three tables per part fit the LDS with <= 8 parts)
   double* d_fpartial2 = nullptr;    // [fz_teams][Kpad] the low pieces' team partials of that pass
   int16_t* d_ehist = nullptr;       // [2K] per column: exponent (+4) of its last sum, and by how many bits it fell in the last iteration

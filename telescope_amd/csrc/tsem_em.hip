@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ a,
 __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double* __restrict__ partial,
                             const int32_t* __restrict__ col_of_pc, const uint32_t* __restrict__ colmap,
                             double* __restrict__ red, int K, const uint32_t* __restrict__ sync, int P,
-                            const uint32_t* __restrict__ ctl, unsigned long long* __restrict__ fz_xchg, int64_t fz_xchg_n) {
+                            const uint32_t* __restrict__ ctl, unsigned long long* __restrict__ fz_xchg, int64_t fz_xchg_n,
+                            const double* __restrict__ lnl_part, const double* __restrict__ lnl_uni, int lnl_nu) {
   // the fused kernel's exchange ring must be zero at its next launch: cleared here, by the ~950 blocks of the
   // kernel that follows every fused pass (no launch of its own, no fence: the next fused launch is a kernel boundary away)
   if (fz_xchg) {
@@ -175,7 +176,17 @@ __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double
   }
   const int pcl = threadIdx.x % NC, slice = threadIdx.x / NC;
   const int pc = blockIdx.x * NC + pcl;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { red[K] = (sync && sync[9]) ? 1.0 : 0.0; red[K + 1] = 0.0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { red[K] = (sync && sync[9]) ? 1.0 : 0.0; if (!lnl_part) red[K + 1] = 0.0; }
+  if (lnl_part && blockIdx.x == 1 % gridDim.x) {
+    // fused kernel MODE 4: the log-likelihood of the PREVIOUS iteration rides in slot K+1 (summed over the ranks with the column
+    // sums): one partial per workgroup of the teams that formed + the unique rows' partials, fixed order
+    __shared__ double lsc[16];
+    double a = 0.0;
+    for (int t = threadIdx.x; t < G * P; t += blockDim.x) a += lnl_part[t];
+    for (int t = threadIdx.x; t < lnl_nu; t += blockDim.x) a += lnl_uni[t];
+    const double tot = block_sum(a, lsc);
+    if (threadIdx.x == 0) red[K + 1] = tot;
+  }
   const int col = pc < Kpad ? col_of_pc[pc] : -1;        // -1: padding, or a secondary slot of a split column
   double s = 0.0;
   if (col >= 0) {
@@ -205,6 +216,11 @@ struct UpdCtl {
   int use_lnl;            // convergence is decided by k_lnl_check instead (model.py:785-789)
   double* pi_first;       // non-null: also store the new parameters here (pi_init / theta_init, model.py:776-778)
   double* theta_first;
+  // lagged log-likelihood test (fused kernel MODE 4): red[K+1] is the lnl of the iteration committed LAST; if it ends the run
+  // (model.py:785-789) this pass's sums are dropped — the state stays the reference's after its last iteration
+  int lag_check;
+  double* ctld;           // [0] the lnl before that one
+  double* lnl_slot;       // where the value goes (the iteration's slot of the chunk's trace, or the carry slot)
 };
 
 // M-step closed forms (model.py:733-740) + per-block partials of diff_est (model.py:781)
@@ -231,8 +247,11 @@ __global__ __launch_bounds__(256) void k_update(UpdCtl C, int K, const double* _
   // some rank's fused pass timed out (flag summed by the all-reduce): the column sums are incomplete, so NO
   // rank commits; the last block raises stop = 2 and the host redoes the iteration (tsem_em_chunk)
   const bool failed = red[K] > 0.0;
+  // (every block reads the same two numbers; ctld[0] is rewritten by the LAST block only, after all have passed this point)
+  const double lag_lnl = (C.lag_check && !failed) ? red[K + 1] : 0.0;
+  const bool lag_stop = C.lag_check && !failed && fabs(lag_lnl - C.ctld[0]) < C.eps;
   double d = 0.0;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K && !failed; j += gridDim.x * blockDim.x) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < K && !failed && !lag_stop; j += gridDim.x * blockDim.x) {
     // exact twin columns share one accumulation (see k_colsig) as long as their
     // sums agree to rounding, i.e. their parameters are still symmetric
     const int jr = twin_rep[j];
@@ -271,7 +290,11 @@ __global__ __launch_bounds__(256) void k_update(UpdCtl C, int K, const double* _
       if (failed) {
         if (C.ctl) C.ctl[0] = 2u;
         *diff_out = -1.0;                                  // (legacy stepwise hosts: negative = not committed)
+      } else if (lag_stop) {                               // the previous iteration was the last one: nothing committed
+        *C.lnl_slot = lag_lnl; C.ctld[0] = lag_lnl;
+        C.ctl[0] = 1u;
       } else {
+        if (C.lag_check) { *C.lnl_slot = lag_lnl; C.ctld[0] = lag_lnl; }
         *diff_out = tt;
         if (C.ctl) {
           C.ctl[1] += 1u;
@@ -397,11 +420,12 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
   FusedArgs A;
   A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
   A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc;
-  const bool lnl = mode == 1;                               // mode 2 is an EM pass (exact column sums), not the lnl pass
-  A.ctab = lnl ? h->d_ctab_prev : h->d_ctab; A.ctab2 = h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = lnl ? 1 : 0;
+  const bool lnl = mode == 1;                               // modes 2, 3 (exact column sums) and 4 (+ the previous lnl) are EM passes
+  A.ctab = lnl ? h->d_ctab_prev : h->d_ctab; A.ctab2 = mode == 4 ? h->d_ctab_prev : h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = lnl ? 1 : 0;
+  A.rinv = h->d_rinv; A.lag = (mode == 4 && h->lag_valid) ? 1 : 0;
   A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg; A.sorted = h->sorted_layout ? 1 : 0;
   A.sync = h->d_xflags;
-  A.prof = mode ? nullptr : h->d_prof; A.prof_blocks = A.prof ? h->prof_steps : 0; A.dbg = (int)h->opt_dbg;
+  A.prof = (mode == 0 || mode == 4) ? h->d_prof : nullptr; A.prof_blocks = A.prof ? h->prof_steps : 0; A.dbg = (int)h->opt_dbg;
   A.ctl = h->d_ctl;
   A.ebias = h->d_ebias; A.bin = bin; A.ovf = h->d_ovf; A.partial2 = h->d_fpartial2;
 
@@ -507,13 +531,20 @@ __global__ void k_bin_finish(int K, const double* __restrict__ red_hi, double* _
   hist[j] = (int16_t)ex4; hist[K + j] = (int16_t)max(-1000, min(1000, drop));
 }
 
+// `lag`: the pass also sums the log-likelihood of the iteration committed last (fused kernel MODE 4; its value goes to slot K+1 of the
+// reduce buffer).  Only tsem_em_chunk asks for it, and only when lag_capable().
+static bool lag_capable(const tsem_ctx* h) { return h->lnl3 && h->use_fused && h->nb > 0 && !h->opt_reproducible && h->opt_precision == 0; }
+static int em_pass(tsem_ctx* h, bool lag);
 int tsem_em_pass(tsem_ctx* h) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
+  return em_pass(h, false);
+}
+
+static int em_pass(tsem_ctx* h, bool lag) {
   if (int rc = ensure_device(h)) return rc;
   if (h->opt_precision == 1) return em_pass_f32(h);
   hipEvent_t* pair = nullptr;
   if (int rc = begin_timing(h, &pair)) return rc;
-  bool fused_done = false;
   if (h->nb > 0 && h->use_fused && h->opt_reproducible) {
     // two exact passes (high and low pieces of every contribution); the high pass is repeated while a column's bound has to move:
     // the first iteration of a run takes a few repeats (the bounds start at the largest fragment weight), later ones rarely any
@@ -527,7 +558,7 @@ int tsem_em_pass(tsem_ctx* h) {
       k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
                                                               h->d_xflags, h->P, h->d_ctl,
                                                               h->P > 1 ? reinterpret_cast<unsigned long long*>(h->d_xchg) : nullptr,
-                                                              h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
+                                                              h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0, nullptr, nullptr, 0);
       // (k_colreduce cleared the exchange ring; the sync words are cleared by the memset of the next launch)
       TSEM_HIP(hipGetLastError());
       return TSEM_OK;
@@ -561,8 +592,22 @@ int tsem_em_pass(tsem_ctx* h) {
     h->em_launches += 1;
     return TSEM_OK;
   } else if (h->nb > 0 && h->use_fused) {
-    if (int rc = launch_fused(h, 0, pair)) return rc;
-    fused_done = true;
+    int nu = 0;
+    if (lag && h->lag_valid && h->N_uni > 0) {             // the unique rows' share of that log-likelihood (model.py:755-758 with Y = 0)
+      nu = (int)std::min<int64_t>(2048, (h->N_uni + 255) / 256);
+      k_lnl_unique<<<nu, 256, 0, h->stream>>>(h->N_uni, h->d_uni_col, h->d_uni_code, h->d_lut, h->d_pi_prev, h->d_pi, h->d_lnl_part + 4096);
+      TSEM_HIP(hipGetLastError());
+    }
+    if (int rc = launch_fused(h, lag ? 4 : 0, pair)) return rc;
+    if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
+    h->em_launches += 1;
+    k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                            h->d_xflags, h->P, h->d_ctl,
+                                                            h->P > 1 ? reinterpret_cast<unsigned long long*>(h->d_xchg) : nullptr,
+                                                            h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0,
+                                                            lag ? h->d_lnl_part : nullptr, h->d_lnl_part + 4096, nu);
+    TSEM_HIP(hipGetLastError());
+    return TSEM_OK;
   } else if (h->nb > 0) {
     const size_t lds2 = (size_t)(2 * h->Kp + h->R) * 8;
     const int64_t chunk = h->opt_chunk > 0 ? h->opt_chunk : h->nb;
@@ -576,14 +621,9 @@ int tsem_em_pass(tsem_ctx* h) {
   }
   if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
   h->em_launches += 1;
-  if (fused_done) {
-    k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
-                                                            h->d_xflags, h->P, h->d_ctl,
-                                                            h->P > 1 ? reinterpret_cast<unsigned long long*>(h->d_xchg) : nullptr,
-                                                            h->P > 1 ? (int64_t)h->fz_teams * FZ_XS * h->P * h->R : 0);
-  } else if (h->nb > 0) {
+  if (h->nb > 0) {
     k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
-                                                            nullptr, h->P, h->d_ctl, nullptr, 0);
+                                                            nullptr, h->P, h->d_ctl, nullptr, 0, nullptr, nullptr, 0);
   } else {
     TSEM_HIP(hipMemsetAsync(h->d_red, 0, sizeof(double) * (h->K + 2), h->stream));
   }
@@ -591,7 +631,8 @@ int tsem_em_pass(tsem_ctx* h) {
   return TSEM_OK;
 }
 
-static int launch_update(tsem_ctx* h, double* d_diff_slot, bool chunked = false, double eps = 0.0, int use_lnl = 0) {
+static int launch_update(tsem_ctx* h, double* d_diff_slot, bool chunked = false, double eps = 0.0, int use_lnl = 0,
+                         double* lag_lnl_slot = nullptr) {
   const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;   // model.py:696-697
   const double tden = h->W_amb + tpw * h->K, pden = h->W_tot + ppw * h->K;      // model.py:732,738
   const int nblk = std::min(1024, cdiv64(h->K, 256));
@@ -604,6 +645,7 @@ static int launch_update(tsem_ctx* h, double* d_diff_slot, bool chunked = false,
   UpdCtl C;
   C.ctl = chunked ? h->d_ctl : nullptr; C.eps = eps; C.use_lnl = use_lnl;
   C.pi_first = h->first_pending ? h->d_pi_first : nullptr; C.theta_first = h->first_pending ? h->d_theta_first : nullptr;
+  C.lag_check = lag_lnl_slot ? 1 : 0; C.ctld = h->d_ctld; C.lnl_slot = lag_lnl_slot;
   k_update<<<nblk, 256, 0, h->stream>>>(C, h->K, h->d_red, h->d_pisum0, tpw, tden, ppw, pden, h->d_pi, h->d_theta,
                                         h->d_pi_prev, h->d_theta_prev, h->d_colmap, h->Kp, h->d_ctab, h->d_ctab_prev,
                                         h->d_twin_rep, part, d_diff_slot, h->d_fz_aux,
@@ -688,6 +730,7 @@ int tsem_em_update(tsem_ctx* h, double* diff_est) {
   if (int rc = ensure_device(h)) return rc;
   if (int rc = launch_update(h, h->d_diffs)) return rc;
   h->first_pending = false;
+  h->lag_valid = false;
   if (diff_est) {
     TSEM_HIP(hipMemcpyAsync(diff_est, h->d_diffs, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
@@ -754,11 +797,20 @@ static int enqueue_lnl_reduce(tsem_ctx* h) {
   return TSEM_OK;
 }
 
-int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likelihood, int32_t first,
-                  int32_t* n_done, int32_t* stopped, double* diffs_out, double* lnls_out) {
+// flags: bit 0 = first chunk of a run (model.py:771-778, 786), bit 1 = last chunk of the run (flush the log-likelihood that is still
+// owed).  With `use_likelihood` and a layout built for it (option "use_likelihood", lag_capable) the lnl of iteration t is summed by the
+// EM pass of iteration t+1 (fused kernel MODE 4) and tested by that iteration's update kernel BEFORE it commits anything: a run that
+// converges in iteration t ends with the state of iteration t, like the reference's.  The value of a chunk's LAST iteration is then
+// not known when the chunk returns (lnls_out[n_done - 1] = NaN): it comes with the next chunk as *lnl_carry (which may be all that
+// chunk does: n_done = 0, stopped = 1), or is flushed by the dedicated lnl pass when bit 1 is set / by tsem_em_flush_lnl.
+int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likelihood, int32_t flags,
+                  int32_t* n_done, int32_t* stopped, double* diffs_out, double* lnls_out, double* lnl_carry) {
   if (!h || !h->have_model || n_max < 0 || n_max > TS_DIFF_RING) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
   if (int rc = ensure_ctl(h)) return rc;
+  const bool first = (flags & 1) != 0, flush = (flags & 2) != 0;
+  const double nan = std::nan("");
+  if (lnl_carry) *lnl_carry = nan;
   if (first) {
     // model.py:786 compares the first iteration's lnl with self.lnl as the previous run left it (inf on a fresh model,
     // model.py:683): tsem_set_prev_lnl / the end of tsem_em_run keep that value for the next run
@@ -766,7 +818,20 @@ int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likeli
     TSEM_HIP(hipMemcpy(h->d_ctld, &seed, sizeof(double), hipMemcpyHostToDevice));
     if (!h->d_pi_first) { TSEM_ALLOC(h->d_pi_first, h->K); TSEM_ALLOC(h->d_theta_first, h->K); }
     h->first_pending = true;
+    h->lag_valid = false;
+    if (use_likelihood && tsem_comm_on(h)) {
+      // Row-sharded: the ranks' sequences of collectives must agree, so the carried lnl is used only if EVERY rank can (a rank
+      // without ambiguous rows, or one that fell back to the two-pass kernels, cannot) — one tiny max all-reduce per run
+      int64_t cannot = lag_capable(h) ? 0 : 1;
+      if (int rc = tsem_comm_allreduce_host(h->comm, &cannot, 1, 3)) TSEM_FAIL(rc, std::string("all-reduce (lnl scheme): ") + tsem_comm_last_error());
+      h->lag_agreed = cannot == 0;
+    }
   }
+  if (!use_likelihood) h->lag_valid = false;
+  // h->lag_valid: the iteration committed last still OWES its log-likelihood, and d_rinv / d_ctab_prev are what the next MODE 4 pass
+  // needs to sum it
+  double* const d_carry = h->d_ctld + 3;                   // ... of the iteration the PREVIOUS chunk committed last
+  const bool owed_at_entry = h->lag_valid;
   int done = 0, retries = 0;
   bool stop = false, lnl_pending = false;
   // (an lnl pass that timed out in the LAST iteration of the chunk is redone before returning: its value is the
@@ -775,17 +840,22 @@ int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likeli
     // enqueue everything that is left; the device stops itself
     TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 8, h->stream));
     const int base = done, want = n_max - done;
-    if (lnl_pending) {                                     // the lnl pass of the last committed iteration timed out
-      if (int rc = enqueue_lnl_reduce(h)) return rc;
-      k_lnl_check<<<1, 1, 0, h->stream>>>(h->d_ctl, h->d_ctld, h->d_ctld + 1, epsilon, h->d_lnls + base - 1);
+    const bool lag = use_likelihood && lag_capable(h) && (!tsem_comm_on(h) || h->lag_agreed);
+    if (lnl_pending || (h->lag_valid && !lag)) {           // the lnl of the last committed iteration by the dedicated pass: its own pass
+      if (int rc = enqueue_lnl_reduce(h)) return rc;       // timed out, or the lagged scheme cannot deliver it (time-out / fall-back in between)
+      k_lnl_check<<<1, 1, 0, h->stream>>>(h->d_ctl, h->d_ctld, h->d_ctld + 1, epsilon, base > 0 ? h->d_lnls + base - 1 : d_carry);
       TSEM_HIP(hipGetLastError());
+      h->lag_valid = false;
     }
+    const bool owed_before = h->lag_valid;
     for (int i = 0; i < want; ++i) {
-      if (int rc = tsem_em_pass(h)) return rc;
+      if (int rc = em_pass(h, lag)) return rc;
       if (int rc = tsem_comm_allreduce_red(h, 0, h->K + 2)) return rc;
-      if (int rc = launch_update(h, h->d_diffs + base + i, true, epsilon, use_likelihood)) return rc;
+      double* lag_slot = (lag && h->lag_valid) ? (base + i > 0 ? h->d_lnls + base + i - 1 : d_carry) : nullptr;
+      if (int rc = launch_update(h, h->d_diffs + base + i, true, epsilon, use_likelihood, lag_slot)) return rc;
       h->first_pending = false;                            // (a failed first update is redone below with the flag restored)
-      if (use_likelihood) {
+      if (lag) h->lag_valid = true;
+      else if (use_likelihood) {
         if (int rc = enqueue_lnl_reduce(h)) return rc;
         k_lnl_check<<<1, 1, 0, h->stream>>>(h->d_ctl, h->d_ctld, h->d_ctld + 1, epsilon, h->d_lnls + base + i);
         TSEM_HIP(hipGetLastError());
@@ -796,14 +866,22 @@ int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likeli
     TSEM_HIP(hipStreamSynchronize(h->stream));
     done = base + (int)ctl[1];
     lnl_pending = false;
-    if (ctl[0] == 1u) { stop = true; break; }
+    if (ctl[0] == 1u) {                                    // converged (lagged scheme: in the iteration committed last, whose lnl is known now)
+      stop = true; h->lag_valid = false;
+      break;
+    }
     if (ctl[0] == 2u || ctl[0] == 3u) {                    // some rank's fused pass timed out: nobody committed that step
       if (++retries > 3) TSEM_FAIL(TSEM_ERR_TIMEOUT, "EM pass: repeated hand-off time-outs");
+      const bool owed = lag ? (ctl[1] > 0 || owed_before) : false;   // (before the layout may change under us)
       uint32_t mine = 0;
       if (int rc = tsem_take_fused_error(h, &mine)) return rc;
       if (mine) { if (int rc = tsem_fallback_twopass(h)) return rc; }
       if (first && done == 0 && ctl[0] == 2u) h->first_pending = true;
-      lnl_pending = ctl[0] == 3u;
+      // lagged scheme: the pass that failed has rewritten part of d_rinv, so the lnl of the last committed iteration — if it is
+      // still owed — comes from the dedicated pass at the top of the loop, and the next EM pass starts a new lag
+      h->lag_valid = false;
+      h->lag_agreed = false;                               // (every rank sees the time-out: from here on all run the lnl pass per iteration)
+      lnl_pending = ctl[0] == 3u || owed;
       continue;
     }
     if (h->use_fused && !tsem_comm_on(h)) {                     // belt and braces: an error word the flags did not carry.  (Row-sharded
@@ -812,17 +890,44 @@ int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likeli
       if (mine) TSEM_FAIL(TSEM_ERR_TIMEOUT, "fused EM kernel: hand-off watchdog fired (code " + std::to_string(mine) + ")");
     }
   }
+  if (!stop && flush && use_likelihood && h->lag_valid) {
+    // end of the run without convergence so far: the last iteration's log-likelihood by the dedicated pass, and its test
+    for (int attempt = 0;; ++attempt) {
+      TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 8, h->stream));
+      if (int rc = enqueue_lnl_reduce(h)) return rc;
+      k_lnl_check<<<1, 1, 0, h->stream>>>(h->d_ctl, h->d_ctld, h->d_ctld + 1, epsilon, done > 0 ? h->d_lnls + done - 1 : d_carry);
+      TSEM_HIP(hipGetLastError());
+      uint32_t c0 = 0;
+      TSEM_HIP(hipMemcpyAsync(&c0, h->d_ctl, 4, hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      if (c0 == 3u) {
+        if (attempt >= 2) TSEM_FAIL(TSEM_ERR_TIMEOUT, "lnl pass: repeated hand-off time-outs");
+        uint32_t mine = 0;
+        if (int rc = tsem_take_fused_error(h, &mine)) return rc;
+        if (mine) { if (int rc = tsem_fallback_twopass(h)) return rc; }
+        continue;
+      }
+      stop = c0 == 1u;
+      break;
+    }
+    h->lag_valid = false;
+  }
   if (n_done) *n_done = done;
   if (stopped) *stopped = stop ? 1 : 0;
   if (done && diffs_out) TSEM_HIP(hipMemcpy(diffs_out, h->d_diffs, sizeof(double) * done, hipMemcpyDeviceToHost));
-  if (done && lnls_out && use_likelihood) TSEM_HIP(hipMemcpy(lnls_out, h->d_lnls, sizeof(double) * done, hipMemcpyDeviceToHost));
+  if (done && lnls_out && use_likelihood) {
+    TSEM_HIP(hipMemcpy(lnls_out, h->d_lnls, sizeof(double) * done, hipMemcpyDeviceToHost));
+    if (h->lag_valid) lnls_out[done - 1] = nan;            // comes with the next chunk / the flush
+  }
+  if (lnl_carry && use_likelihood && owed_at_entry && (done > 0 || !h->lag_valid))
+    TSEM_HIP(hipMemcpy(lnl_carry, d_carry, sizeof(double), hipMemcpyDeviceToHost));
   TSEM_HIP(hipMemsetAsync(h->d_ctl, 0, 8, h->stream));     // passes launched outside a chunk must not see a stale stop flag
   return TSEM_OK;
 }
 
 int tsem_em_steps(tsem_ctx* h, int32_t n, double* diffs_out) {
   int32_t done = 0;
-  return tsem_em_chunk(h, n, 0.0, 0, 0, &done, nullptr, diffs_out, nullptr);
+  return tsem_em_chunk(h, n, 0.0, 0, 0, &done, nullptr, diffs_out, nullptr, nullptr);
 }
 
 // the final log-likelihood (model.py:800-801), all-reduced; redone on the two-pass kernels after a time-out
@@ -862,11 +967,17 @@ int tsem_em_run(tsem_ctx* h, double epsilon, int32_t max_iter, int32_t use_likel
     const int want = std::max(1, std::min(8, max_iter - inum));
     int32_t done = 0, stopped = 0;
     std::vector<double> d(want), l(want);
-    if (int rc = tsem_em_chunk(h, want, epsilon, use_likelihood, inum == 0, &done, &stopped, d.data(), l.data())) return rc;
+    double carry = 0.0;
+    const int flags = (inum == 0 ? 1 : 0) | (inum + want >= max_iter ? 2 : 0);
+    if (int rc = tsem_em_chunk(h, want, epsilon, use_likelihood, flags, &done, &stopped, d.data(), l.data(), &carry)) return rc;
+    if (use_likelihood && carry == carry && inum > 0) {    // the lnl the previous chunk's last iteration owed
+      lnl = carry;
+      if (lnls && inum - 1 < std::max(1, max_iter)) lnls[inum - 1] = carry;
+    }
     for (int i = 0; i < done; ++i) {
       if (diffs && inum + i < std::max(1, max_iter)) diffs[inum + i] = d[i];
       if (lnls && use_likelihood && inum + i < std::max(1, max_iter)) lnls[inum + i] = l[i];
-      if (use_likelihood) lnl = l[i];
+      if (use_likelihood && l[i] == l[i]) lnl = l[i];
     }
     inum += done;
     conv = stopped != 0;

@@ -70,6 +70,9 @@ constexpr unsigned FZ_SPIN_LIMIT = 2000000u;
 #define FZ_SKIP_IDLE_WAVES 1
 #endif
 constexpr int FZ_PROF_SLOTS = 16;
+#ifndef FZ_LAG_CERR
+#define FZ_LAG_CERR 0
+#endif
 
 // sync words (uint32): [0..7] per-XCD tickets, [8] registered WGs, [9] error
 constexpr int FZ_SYNC_WORDS = 16;
@@ -88,7 +91,7 @@ struct FusedArgs {
   const uint16_t* wcode;    // FMT 1: [N_amb_pad] row weight as a code, w_i = lut[max code of the row]
   const uint32_t* prc;
   const double* ctab;
-  const double* ctab2;  // lnl mode: pi*theta of the CURRENT params (ctab then holds the previous ones)
+  const double* ctab2;  // lnl mode: pi*theta of the CURRENT params (ctab then holds the previous ones); MODE 4: of the PREVIOUS params
   double* lnl_out;      // lnl mode: one partial sum per workgroup [grid]
   int sorted;           // 1: sub-blocks in row order (row sums reduced in registers), 0: strand-transposed (one atomic per entry)
   int lnl_mode;         // 0: EM pass (scatter w*z); 1: sum z(prev) * log1p(Q * c_cur)  (model.py:744-760)
@@ -103,6 +106,12 @@ struct FusedArgs {
   int bin;                // 1: the high piece (multiples of 2^(E-30)), 2: the low piece (the remainder in multiples of 2^(E-60))
   double* partial2;       // MODE 3 (both pieces in ONE pass, a second accumulator table in LDS): the low pieces' team partials
   uint8_t* ovf;           // [P*Kp] set to 1 when a contribution reached its slot's bound (the host raises E and repeats the pass)
+  // MODE 4 (`--use_likelihood`, model.py:783-789): the EM pass of iteration t+1 also sums the log-likelihood of iteration t,
+  //   lnl_t = sum z_t * log1p(Q * c_t),  z_t = (Q * c_{t-1}) * recip0(rowsum_t):
+  // Q * c_t are this pass's numerators; c_{t-1} is a third table in LDS (ctab2); recip0(rowsum_t) was stored by pass t (rinv, one
+  // double per row slot, written by member 0 of the team at the combine) and is staged through LDS a block ahead by the exchange wave.
+  double* rinv;           // [N_amb_pad] read (rows of the blocks to come) and rewritten (rows just combined) by every MODE 4 pass
+  int lag;                // 0: rinv holds nothing yet (first pass of a run): the lnl partials of this launch are zero
   int dbg;              // bit0: skip partner loads (timing experiments only; wrong results)
                         // bit5 / bit6: behave like a hand-off time-out in the EM / lnl pass (tests of the recovery path)
   unsigned long long* prof;   // optional per-step timestamps of team 0 / member 0
@@ -200,13 +209,17 @@ __device__ __forceinline__ void fz_row_sums(double* yb, bool idle, uint32_t r0, 
 // fdlibm does.  Entry 0 is (1, 0), so small x keep their relative accuracy; elsewhere the error is ~1e-16 ABSOLUTE per
 // evaluation (1 / c_i is rounded), which is what a sum of z * log1p needs.  Max relative error measured against log1p: see
 // test_fast_log1p_of_the_fused_lnl_pass.
+// CERR = false (the carrying pass, MODE 4, whose step is bound by its arithmetic): without the correction for the rounding of 1 + x —
+// an error of at most 2^-53 ABSOLUTE per evaluation, the size of the table's own (1 / c_i is rounded); relative accuracy for tiny x
+// is lost, which a SUM of z * log1p (terms of 1 ... 100 dominate) does not see.
 constexpr int FZ_LOGTAB = 64;
+template <bool CERR = true>
 __device__ __forceinline__ double fz_log1p_tab(double x, const double2* __restrict__ tab) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double u = 1.0 + x;
   const int hu = __double2hiint(u);
   const int k = (hu >> 20) - 1023;
-  const double cerr = (k > 0 ? 1.0 - (u - x) : x - (u - 1.0)) * __builtin_amdgcn_rcp(u);   // (1 + x) - u, relative to u
+  const double cerr = CERR ? (k > 0 ? 1.0 - (u - x) : x - (u - 1.0)) * __builtin_amdgcn_rcp(u) : 0.0;   // (1 + x) - u, relative to u
   const double2 t = tab[(hu >> 14) & (FZ_LOGTAB - 1)];
   const double m = __hiloint2double((hu & 0x000FFFFF) | 0x3FF00000, __double2loint(u));    // [1, 2)
   const double r = fma(m, t.x, -1.0);
@@ -225,7 +238,7 @@ struct FzRegs {            // 4 entries per thread: 12 VGPRs (FMT 1: 6 until pha
 
 struct FzX {                 // context handed to the exchange wave
   const double* lut;
-  double* y; double* s; uint32_t* offs; unsigned long long* xbase; uint32_t* err;
+  double* y; double* s; double* rp; uint32_t* offs; unsigned long long* xbase; uint32_t* err;
   int R, team, T, lane, xw;
   int64_t nblk, nsteps;
 };
@@ -256,7 +269,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     return (unsigned long long)((((k / FZ_XS) & 1) ^ 1));
   };
   if (!(A.dbg & 16)) __builtin_amdgcn_s_setprio(3);   // few instructions, all on the critical path of the step
-  struct Gen { u64x2 pv[NPART][FZ_RP]; double2 w[FZ_RP]; uint32_t wc[FZ_RP]; uint32_t off; };
+  struct Gen { u64x2 pv[NPART][FZ_RP]; double2 w[FZ_RP]; uint32_t wc[FZ_RP]; uint32_t off; double2 rpv[FZ_RP]; };
   Gen g1;
   g1.off = 0;
   struct Own { u64x2 v[FZ_RP]; };
@@ -285,6 +298,14 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
         for (int j = 0; j < FZ_RP; ++j)
           g.w[j] = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)(rlo + 2 * (lane + 64 * j)) * 8, 0, 0));
       }
+    }
+    if (MODE == 4) {                                            // 1 / rowsum of the PREVIOUS pass for the rows of block i+1 (phase 1 of the next step)
+      const int64_t kn = k + 3 + FZ_GAP;
+      const bool nv = kn > 0 && kn < nblk && A.lag != 0;        // (block 0: loaded by the prologue)
+      __amdgpu_buffer_rsrc_t rr = fz_rsrc(A.rinv, (nv ? (uint64_t)(team + kn * T) : 0) * R * 8, nv ? (unsigned)R * 8 : 0);
+#pragma unroll
+      for (int j = 0; j < FZ_RP; ++j)
+        g.rpv[j] = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(rr, (unsigned)(rlo + 2 * (lane + 64 * j)) * 8, 0, 0));
     }
     if (P > 1) {
       // Validity lives in the DESCRIPTOR (an empty resource returns zeros), never in a per-lane select of the
@@ -361,7 +382,14 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
         // made safe for zero / denormal / huge sums — a wave-uniform choice between the sequences, or frexp / ldexp around the
         // short one — the gain is within the repeat spread, and it is not a correctly rounded quotient: not taken.
         // profiles/r03_exchange_bounds.txt section 7.)
-        *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(recip0(ys0) * w.x, recip0(ys1) * w.y);
+        const double ri0 = recip0(ys0), ri1 = recip0(ys1);
+        *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(ri0 * w.x, ri1 * w.y);
+        if (MODE == 4 && PP == 0) {                       // what the NEXT pass needs of this one's E-step: one member stores it
+          __amdgpu_buffer_rsrc_t ro = fz_rsrc(A.rinv, (uint64_t)(team + k * T) * R * 8, (unsigned)R * 8);
+          fz_u32x4 sv;
+          sv.x = (unsigned)__double2loint(ri0); sv.y = (unsigned)__double2hiint(ri0); sv.z = (unsigned)__double2loint(ri1); sv.w = (unsigned)__double2hiint(ri1);
+          __builtin_amdgcn_raw_buffer_store_b128(sv, ro, (unsigned)r * 8, 0, 0);
+        }
         if (!OWNREG) *reinterpret_cast<double2*>(&y[(k & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
       }
     }
@@ -447,6 +475,13 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     issue(g1, i - 2 - FZ_GAP, i + FZ_DL + 2);
     if (pr) A.prof[i * FZ_PROF_SLOTS + 7] = clock64();
     combine(g1, own_q[1 + FZ_GAP], i - 2 - FZ_GAP, i + FZ_DL + 2);   // (geometry 3: block i-2-GAP was read 1+GAP publishes before this one's)
+    if (MODE == 4) {                                      // stage the row factors of block i+1 for the data waves' next step
+#pragma unroll
+      for (int j = 0; j < FZ_RP; ++j) {
+        const int r = rlo + 2 * (lane + 64 * j);
+        if (r < rhi) *reinterpret_cast<double2*>(&X.rp[((i + 1) & 1) * R + r]) = g1.rpv[j];
+      }
+    }
     if (pr) A.prof[i * FZ_PROF_SLOTS + 5] = clock64();
     if (A.prof && team == 0 && p == 0 && lane == 0 && X.xw == 1 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 9] = clock64();
     __syncthreads();
@@ -464,10 +499,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   const int Kp = A.Kp, R = A.R;
   double* c = reinterpret_cast<double*>(smem);
   double* acc = c + Kp;
-  double* const acc2 = acc + Kp;                   // MODE 3: the low pieces' accumulators [Kp]
-  double* y = acc + (MODE == 3 ? 2 : 1) * Kp;      // y[FZ_YR][R]  partial row sums (ring)
+  constexpr bool EXACT = MODE == 2 || MODE == 3;   // option "reproducible"
+  constexpr bool LAG = MODE == 4;                  // EM pass + the log-likelihood of the previous iteration
+  double* const acc2 = acc + Kp;                   // MODE 3: the low pieces' accumulators [Kp];  MODE 4: pi*theta of the previous parameters
+  double* const cprev = acc2;
+  double* y = acc + ((MODE == 3 || LAG) ? 2 : 1) * Kp;   // y[FZ_YR][R]  partial row sums (ring)
   double* s = y + FZ_YR * R;                       // s[2][R]      w_i / rowsum_i   (ring)
-  int* ibox = reinterpret_cast<int*>(s + 2 * R);   // [0]=ticket [1..8]=xcd counts
+  double* const rpS = s + 2 * R;                   // MODE 4: rp[2][R]  1 / rowsum_i of the previous pass (ring)
+  int* ibox = reinterpret_cast<int*>(s + (LAG ? 4 : 2) * R);   // [0]=ticket [1..8]=xcd counts
   const int tid = threadIdx.x;
   uint32_t* const sync = A.sync;
   uint32_t* const err = sync + 9;
@@ -495,7 +534,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   for (int t = tid; t < Kp; t += FZ_NT) acc[t] = 0.0;   // (lnl mode: overwritten with ctab2 below)
   if (MODE == 3) for (int t = tid; t < Kp; t += FZ_NT) acc2[t] = 0.0;
   for (int t = tid; t < FZ_YR * R; t += FZ_NT) y[t] = 0.0;
-  for (int t = tid; t < 2 * R; t += FZ_NT) s[t] = 0.0;
+  for (int t = tid; t < (LAG ? 4 : 2) * R; t += FZ_NT) s[t] = 0.0;
   uint32_t* offs = reinterpret_cast<uint32_t*>(ibox + 16);   // [8][2] sub-block quad ranges (ring), LDS
   double* dum = reinterpret_cast<double*>(ibox + 32);        // [64] one slot per lane: where idle lanes send their (zero) atomics
   double* lutS = dum + 64;                                   // FMT 1: score table [lut_len]
@@ -505,7 +544,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   uint16_t* const eS = reinterpret_cast<uint16_t*>(lutS + A.lut_len);   // MODE 2: [Kp] the slots' exponent bounds
   // MODE 1: [FZ_LOGTAB] (1 / c_i, log c_i) for fz_log1p_tab, in the same place (the two modes never share a launch)
   double2* const logtab = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(lutS + A.lut_len) + 15) & ~(uintptr_t)15);
-  if (MODE == 1 && tid < FZ_LOGTAB) {
+  if ((MODE == 1 || LAG) && tid < FZ_LOGTAB) {
     const double ci = 1.0 + (double)tid * (1.0 / FZ_LOGTAB);
     logtab[tid] = make_double2(1.0 / ci, ts_log1p_pos((double)tid * (1.0 / FZ_LOGTAB)));
   }
@@ -516,7 +555,9 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   for (int t = tid; t < Kp; t += FZ_NT) c[t] = A.ctab[p * Kp + t];
   if (MODE == 1)
     for (int t = tid; t < Kp; t += FZ_NT) acc[t] = A.ctab2[p * Kp + t];
-  if (MODE >= 2)
+  if (LAG)
+    for (int t = tid; t < Kp; t += FZ_NT) cprev[t] = A.ctab2[p * Kp + t];
+  if (EXACT)
     for (int t = tid; t < Kp; t += FZ_NT) eS[t] = A.ebias[p * Kp + t];
   if (tid == 0) {
     unsigned spins = 0;
@@ -574,6 +615,8 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     const int64_t k = tid >> 1;
     if (k < nblk) offs[tid] = A.sb_q32[(team + k * T) * P + p + (tid & 1)];
   }
+  if (LAG && A.lag && nblk > 0)
+    for (int t = tid; t < R; t += FZ_NT) rpS[t] = A.rinv[(int64_t)team * R + t];
   __syncthreads();
   if (sprof) { sprof[4] = wall_clock64(); sprof[7] = ((unsigned long long)xcc << 48) | ((unsigned long long)team << 32) | ((unsigned long long)p << 16) | (unsigned long long)nblk; }
 
@@ -585,7 +628,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     // ============================ exchange wave ===============================
     // dispatched on the member index so every register array is statically indexed
     FzX X;
-    X.lut = lutS; X.y = y; X.s = s; X.offs = offs; X.xbase = xbase; X.err = err; X.R = R; X.team = team; X.T = T;
+    X.lut = lutS; X.y = y; X.s = s; X.rp = rpS; X.offs = offs; X.xbase = xbase; X.err = err; X.R = R; X.team = team; X.T = T;
     X.nblk = nblk; X.nsteps = nsteps; X.lane = (tid - FZ_DT) & 63; X.xw = (tid - FZ_DT) >> 6;
     switch (p) {
       case 0: fz_xchg<P, 0, MODE, FMT, GEO>(A, X); break;
@@ -717,7 +760,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       // step has a floor of LDS instruction ISSUE (~22 wave-instructions per data wave, ~8 clk each even with every lane
       // masked); idle waves used to pay it in full.  (Wave-uniform branch around LDS operations only: the
       // streaming loads below stay unconditional.)
-      const bool wave_idle = FZ_SKIP_IDLE_WAVES && GEO >= 2 &&   // (only the short-row geometry leaves whole waves idle; elsewhere the branch costs 1.5 %)
+      const bool wave_idle = FZ_SKIP_IDLE_WAVES && GEO >= 2 && !LAG &&   // (only the short-row geometry leaves whole waves idle; elsewhere the branch costs 1.5 %; MODE 4: it costs registers the log1p needs)
                              (__builtin_amdgcn_ballot_w64(!idle) | __builtin_amdgcn_ballot_w64(!idle2)) == 0ull;
       if (wave_idle) {
         rp.rc.x = 0xFFFFFFFFu;
@@ -769,7 +812,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
         const uint32_t j0 = idle2 ? dj : (a0 & 0xFFFFu), j1 = idle2 ? dj : (a1 & 0xFFFFu);
         const uint32_t j2 = idle2 ? dj : (a2 & 0xFFFFu), j3 = idle2 ? dj : (a3 & 0xFFFFu);
 #endif
-        if (MODE >= 2) {
+        if (EXACT) {
           // Exact accumulation (Demmel-Nguyen style pre-rounding on a per-slot grid): v = hi + lo + rest with hi a multiple of
           // 2^(E-30) and lo a multiple of 2^(E-60); the sums of the hi pieces (and of the lo pieces) of up to 2^23 contributions
           // below 2^E are exact in fp64, hence the same whatever order the LDS serves the atomics in.  MODE 2: one piece per
@@ -800,6 +843,39 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
         lds_add(&acc[j1], rs.v0.y * s1);
         lds_add(&acc[j2], rs.v1.x * s2);
         lds_add(&acc[j3], rs.v1.y * s3);
+        }
+      }
+      if (LAG) {
+        // log-likelihood of the PREVIOUS iteration (model.py:744-760): z = (Q c_prev) * recip0(rowsum_prev), times log1p(Q c) — the
+        // numerators this pass has just formed.  Padding has Q = 0 -> z = 0 (no `z != 0` branch: log1p of a finite product is
+        // finite).  AFTER the scatter of block i-LAG, whose register set and row factors are dead by now, and one entry after the
+        // other: the kernel sits at 128 VGPRs (1024 threads), and a spill in this loop is a scratch access in the in-order memory
+        // pipe behind the stream; score codes are looked up again instead of keeping Q alive across the row sums.  `idle` lanes
+        // have marked rc.x by now: their Q is 0, and lane-private garbage in rc.x >> 16 must not index LDS -> masked.
+        const double* rb = rpS + (i & 1) * R;
+        const uint32_t e0 = idle ? 0u : rp.rc.x, e1 = rp.rc.y, e2 = rp.rc.z, e3 = rp.rc.w;
+        // all gathers of the four entries first (one LDS round trip), then the four evaluations, each PINNED where it is written:
+        // left alone, the compiler sinks the arithmetic below the barrier (nothing but `lsum` at the very end needs it), keeps the
+        // twelve gathered values alive into the next step and spills the streaming loads' destinations
+        auto term = [&](double q, double cp, double rf, double m) {
+          lsum = fma((q * cp) * rf, fz_log1p_tab<FZ_LAG_CERR != 0>(m, logtab), lsum);
+          asm volatile("" : "+v"(lsum));
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        if (FMT == 1) {
+          const double g0 = lutS[rp.cd.x & 0xFFFFu], g1 = lutS[rp.cd.x >> 16], g2 = lutS[rp.cd.y & 0xFFFFu], g3 = lutS[rp.cd.y >> 16];
+          const double p0 = cprev[e0 & 0xFFFF], p1 = cprev[e1 & 0xFFFF], p2 = cprev[e2 & 0xFFFF], p3 = cprev[e3 & 0xFFFF];
+          const double f0 = rb[e0 >> 16], f1 = rb[e1 >> 16], f2 = rb[e2 >> 16], f3 = rb[e3 >> 16];
+          term(g0, p0, f0, m0); term(g1, p1, f1, m1); term(g2, p2, f2, m2); term(g3, p3, f3, m3);
+        } else {                                          // fp64 entries keep Q alive (8 VGPRs): two entries per round trip
+          {
+            const double p0 = cprev[e0 & 0xFFFF], p1 = cprev[e1 & 0xFFFF], f0 = rb[e0 >> 16], f1 = rb[e1 >> 16];
+            term(q0.x, p0, f0, m0); term(q0.y, p1, f1, m1);
+          }
+          {
+            const double p2 = cprev[e2 & 0xFFFF], p3 = cprev[e3 & 0xFFFF], f2 = rb[e2 >> 16], f3 = rb[e3 >> 16];
+            term(q1.x, p2, f2, m2); term(q1.y, p3, f3, m3);
+          }
         }
       }
       }
@@ -848,7 +924,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   }
   __syncthreads();
   if (sprof) sprof[5] = wall_clock64();
-  if (MODE == 1) {                                        // one partial per workgroup, summed by k_sum_parts
+  if (MODE == 1 || LAG) {                                 // one partial per workgroup, summed by k_sum_parts / k_colreduce
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
     double* wsum = y;                                     // the y ring is idle now
     if ((tid & 63) == 0) wsum[tid >> 6] = lsum;
@@ -858,7 +934,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       for (int w = 0; w < FZ_NT / 64; ++w) t += wsum[w];
       A.lnl_out[team * P + p] = t;
     }
-    return;
+    if (MODE == 1) return;
   }
 #ifdef FZ_EXPERIMENT
   if ((A.dbg & 4096) && A.prof && tid == 0) {             // per-member loop time (cycles) and blocks: prof[(team*P+p)*2 ..]

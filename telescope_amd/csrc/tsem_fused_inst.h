@@ -7,6 +7,14 @@
 
 typedef void (*fz_fn)(FusedArgs);
 template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
+  if (mode == 4) {                                         // EM pass + the previous iteration's log-likelihood: needs the score table in LDS
+#ifdef TSEM_NO_LAG
+    return nullptr;
+#else
+    if constexpr (GEO != 3) { if (fmt == 1) return k_em_fused<P, 4, 1, GEO>; }   // (fp64 entries / geometry 3: the log1p finds no registers)
+    return nullptr;
+#endif
+  }
   if (mode >= 2) {                                         // exact (binned) column sums: needs the score table in LDS (formats 1, 2)
 #ifdef TSEM_NO_REPRO
     return nullptr;

@@ -86,7 +86,7 @@ extern "C" {
 void tsem_free_layout(tsem_ctx* h) {
   dfree(h->d_ebias); dfree(h->d_ovf); dfree(h->d_red_hi); dfree(h->d_binflag); dfree(h->d_ehist);
   dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_rid16); dfree(h->d_col_of_id); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_pcode); dfree(h->d_prc);
-  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fz_aux); h->fz_clean = false; dfree(h->d_fpartial); dfree(h->d_fpartial2); dfree(h->d_amb_w); dfree(h->d_sb_q32);
+  dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fz_aux); h->fz_clean = false; dfree(h->d_fpartial); dfree(h->d_fpartial2); dfree(h->d_amb_w); dfree(h->d_sb_q32); dfree(h->d_rinv); h->lag_valid = false;
   h->fused_launched = false;
 }
 void tsem_free_matrix(tsem_ctx* h) {
@@ -181,6 +181,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "report_dbg") h->opt_report_dbg = v;
   else if (k == "report_lanes") h->opt_report_lanes = v;     // capacity (lanes per row x entries per lane) of k_report_rows: 8 .. 256 (0 = from the row lengths)
   else if (k == "issue_early") h->opt_issue = v;       // (kept for old scripts; the exchange has one order now)
+  else if (k == "use_likelihood") h->opt_lnl_fused = v;      // before the matrix is laid out (tsem_set_model), or followed by tsem_prepare_likelihood
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, TS_PROF_WORDS * 8) != hipSuccess) return TSEM_ERR_NOMEM; }
     if (h->d_prof) (void)hipMemset(h->d_prof, 0, TS_PROF_WORDS * 8);
@@ -486,7 +487,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[17] = h->sorted_layout ? 1 : 0; info[18] = h->geo; info[19] = h->n_fallbacks;
   info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->len_gt[5] ? 2 : 1) : 0;     // 2: some row has more than 256 entries, see telescope_em.h
   info[22] = h->exact_single ? 1 : 0;                      // reproducible: both pieces in one pass
-  info[23] = 0;
+  info[23] = h->lnl3 ? 1 : 0;                              // the layout lets the EM pass carry the previous iteration's log-likelihood (option "use_likelihood")
   return TSEM_OK;
 }
 

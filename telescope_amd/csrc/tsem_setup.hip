@@ -634,6 +634,14 @@ int tsem_bin_reset(tsem_ctx* h) {
 
 
 
+// option "use_likelihood": can a part keep three tables (pi*theta of the current and of the previous parameters, the accumulators)
+// in LDS with at most 8 parts?  Score codes only (fp64 entries leave the log1p no registers), not together with the exact sums.
+static bool lnl3_possible(const tsem_ctx* h) {
+  const int K = h->K;
+  return !h->opt_reproducible && h->em_kernel != TSEM_EMK_TWOPASS && fz_wants_codes(h) && h->opt_precision == 0 &&
+         (h->opt_P > 0 ? (K + (int)h->opt_P - 1) / (int)h->opt_P + 64 <= TS_MAX_KP_LNL : (K + TS_MAX_KP_LNL - 64 - 1) / (TS_MAX_KP_LNL - 64) <= FZ_MAX_P);
+}
+
 int tsem_choose_geometry(tsem_ctx* h) {
   const int K = h->K;
   const int64_t na = h->N_amb, nu = h->N_uni;
@@ -653,7 +661,10 @@ int tsem_choose_geometry(tsem_ctx* h) {
       const bool long_enough = p3 <= 4 || h->opt_P > 0 || ml * fz_rmax(2) >= 0.62 * 1.05 * fz_cap(1) * p3;
       if (p3 >= 1 && p3 <= FZ_MAX_P && (K + p3 - 1) / p3 + 64 <= TS_MAX_KP3 && long_enough) h->exact_single = true;
     }
-    const int max_kp = h->exact_single ? TS_MAX_KP3 - 64 : TS_MAX_KP;
+    // option "use_likelihood": three tables per part too (pi*theta of the current and of the previous parameters, the accumulators) —
+    // score codes only (fp64 entries leave the log1p no registers), not together with the exact sums (four tables)
+    h->lnl3 = h->opt_lnl_fused && lnl3_possible(h);
+    const int max_kp = h->exact_single ? TS_MAX_KP3 - 64 : (h->lnl3 ? TS_MAX_KP_LNL - 64 : TS_MAX_KP);
     int P = h->opt_P > 0 ? (int)h->opt_P : (K + max_kp - 1) / max_kp;
     if (P < 1) P = 1;
     if (h->opt_P <= 0 && h->em_kernel != TSEM_EMK_TWOPASS && P < FZ_MAX_P && na > 0) {
@@ -671,7 +682,7 @@ int tsem_choose_geometry(tsem_ctx* h) {
     int Kp = (K + P - 1) / P;
     if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
     // spare accumulator slots per part for very popular columns (build_layout splits them)
-    h->hot_extra = h->opt_hot_split ? std::min(64, (h->exact_single ? TS_MAX_KP3 : TS_MAX_KP) - Kp) : 0;
+    h->hot_extra = h->opt_hot_split ? std::min(64, (h->exact_single ? TS_MAX_KP3 : (h->lnl3 ? TS_MAX_KP_LNL : TS_MAX_KP)) - Kp) : 0;
     Kp += h->hot_extra;
     h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
     h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
@@ -696,12 +707,12 @@ int tsem_choose_geometry(tsem_ctx* h) {
       // rows so short that 768 of them cannot fill the tile either: geometry 3 (32 B of LDS per row slot instead of 48)
       // (profiles/r03_sweep_short.txt: 8 / 10 / 12 entries per row 1.27 / 1.31 / 1.39 -> 1.18 / 1.23 / 1.34 ms, 14 equal, 16 and more slower:
       //  the exchange of a step grows with its row slots)
-      if (P <= 4 && h->geo == 2 && 1.07 * fz_cap(2) * P / std::max(2.0, mean_len) > 1.4 * fz_rmax(2)) h->geo = 3;
-      if (h->opt_geo >= 0 && P <= 4) h->geo = (h->opt_geo == 2 || h->opt_geo == 3) ? (int)h->opt_geo : 0;
+      if (P <= 4 && h->geo == 2 && !h->lnl3 && 1.07 * fz_cap(2) * P / std::max(2.0, mean_len) > 1.4 * fz_rmax(2)) h->geo = 3;   // (MODE 4 has no geometry 3: registers)
+      if (h->opt_geo >= 0 && P <= 4) h->geo = (h->opt_geo == 2 || (h->opt_geo == 3 && !h->lnl3)) ? (int)h->opt_geo : 0;
       if (h->opt_geo >= 0 && P > 4) h->geo = h->opt_geo == 2 ? 2 : 1;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
-      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - (h->exact_single ? 3 : 2) * Kp * 8 - lut_bytes - std::max(h->opt_reproducible ? Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16)) / ((fz_yr(h->geo) + 2) * 8));
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - ((h->exact_single || h->lnl3) ? 3 : 2) * Kp * 8 - lut_bytes - std::max(h->opt_reproducible ? Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16)) / ((fz_yr(h->geo) + (h->lnl3 ? 4 : 2)) * 8));
       rmax = std::min(rmax, FILL_MAX_RP / P);                // (k_sb_fill_sorted keeps R x P counters in LDS)
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
@@ -1122,6 +1133,13 @@ int tsem_build_layout(tsem_ctx* h) {
       for (int mode = 0; mode < 2; ++mode)
         TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h), h->geo),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      if (h->lnl3 && !(h->fmt_code && fz_kernel(P, 4, fz_fmt(h), h->geo))) h->lnl3 = false;   // (not score codes after all: the per-iteration lnl pass stays)
+      h->lag_valid = false;
+      if (h->lnl3) {
+        TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, 4, fz_fmt(h), h->geo), hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        TSEM_ALLOC(h->d_rinv, h->N_amb_pad);
+        TSEM_HIP(hipMemsetAsync(h->d_rinv, 0, sizeof(double) * h->N_amb_pad, h->stream));
+      }
       if (h->opt_reproducible) {
         if (h->exact_single && !fz_kernel(P, 3, fz_fmt(h), h->geo)) h->exact_single = false;   // (not score codes after all: fz_lds_bytes then counts two tables again)
         if (h->exact_single) TSEM_ALLOC(h->d_fpartial2, (int64_t)h->fz_teams * h->Kpad);
@@ -1217,9 +1235,30 @@ int tsem_make_ctabs(tsem_ctx* h) {
   return TSEM_OK;
 }
 
+// em(use_likelihood=True) on a model that was laid out without option "use_likelihood": rebuild the blocked layout with three
+// tables per part, so that the EM pass can sum the previous iteration's log-likelihood (fused kernel MODE 4).  A no-op when the layout
+// has it already, or cannot have it (two-pass kernels, fp64 entries, option "reproducible", more than 8 x 5056 columns): the
+// per-iteration lnl pass then stays.
+int tsem_prepare_likelihood(tsem_ctx* h) {
+  if (!h || !h->have_model) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (h->lnl3 || !h->use_fused || h->nb == 0 || !lnl3_possible(h)) return TSEM_OK;
+  h->opt_lnl_fused = 1;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  if (int rc = tsem_choose_geometry(h)) return rc;
+  if (int rc = tsem_build_layout(h)) return rc;
+  TSEM_ALLOC(h->d_ctab, h->Kpad); TSEM_ALLOC(h->d_ctab_prev, h->Kpad);
+  TSEM_HIP(hipMemsetAsync(h->d_ctab, 0, sizeof(double) * h->Kpad, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_ctab_prev, 0, sizeof(double) * h->Kpad, h->stream));
+  if (int rc = tsem_make_ctabs(h)) return rc;
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return TSEM_OK;
+}
+
 int tsem_set_params(tsem_ctx* h, const double* pi, const double* theta) {
   if (!h || !h->have_model || !pi || !theta) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
+  h->lag_valid = false;
   h->em_prev = h->em_cur; h->em_cur = false;               // arbitrary values (possibly 0): no shortcut in tsem_reassign
   const int K = h->K;
   TSEM_HIP(hipMemcpyAsync(h->d_pi_prev, h->d_pi, sizeof(double) * K, hipMemcpyDeviceToDevice, h->stream));

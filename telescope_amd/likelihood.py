@@ -169,6 +169,8 @@ class TelescopeLikelihood(object):
         self.max_iter = opts.max_iter
         self.pi_prior = opts.pi_prior                                # model.py:686-687
         self.theta_prior = opts.theta_prior
+        if getattr(opts, 'use_likelihood', False):                   # (telescope_assign.py:439 passes it to em(): lay the matrix out for it now)
+            self._eng.set_option('use_likelihood', 1)
 
         self._setup_model()
 
@@ -187,6 +189,8 @@ class TelescopeLikelihood(object):
         engine.set_lut(self._lut)
         self.epsilon, self.max_iter = opts.em_epsilon, opts.max_iter
         self.pi_prior, self.theta_prior = opts.pi_prior, opts.theta_prior
+        if getattr(opts, 'use_likelihood', False):
+            engine.set_option('use_likelihood', 1)
         self._setup_model()
         return self
 
@@ -321,14 +325,25 @@ class TelescopeLikelihood(object):
             eng.set_option('kernel_timing', 0)  # per-pass HIP events are for benchmarks (Engine.kernel_stats), not for em()
         if chunked:
             eng.set_prev_lnl(self.lnl)          # model.py:786: the first lnl is compared with what the last run left (inf at first)
+            if use_likelihood:
+                eng.prepare_likelihood()        # the EM pass of iteration t+1 sums the lnl of iteration t (no lnl pass per iteration)
+        owed = None                             # (iteration, diff) whose lnl comes with the next chunk
         while not (converged or reached_max):
             xtime = perf_counter()
             if chunked:
                 want = max(1, min(EM_CHUNK, self.max_iter - inum))
-                diffs, lnls, converged = eng.em_chunk(want, self.epsilon, use_likelihood, first=(inum == 0))
+                diffs, lnls, converged = eng.em_chunk(want, self.epsilon, use_likelihood, first=(inum == 0),
+                                                      last=(inum + want >= self.max_iter))
+                if owed is not None:
+                    self.lnl = float(eng.lnl_carry)
+                    lg.log(loglev, msgL.format(owed[0], self.lnl, owed[1]))
+                    owed = None
                 for i, diff_est in enumerate(diffs):
                     inum += 1
                     if use_likelihood:
+                        if lnls[i] != lnls[i]:                 # NaN: the chunk's last iteration, summed by the next chunk's first pass
+                            owed = (inum, diff_est)
+                            continue
                         self.lnl = float(lnls[i])
                         lg.log(loglev, msgL.format(inum, self.lnl, diff_est))
                     else:

@@ -1,0 +1,137 @@
+"""Round 4, `-m gpu`: the log-likelihood carried by the EM pass (`--use_likelihood`, model.py:783-789; fused kernel MODE 4),
+row statistics against the goldens, per-barcode sums at scale.  Everything goes through the C ABI (telescope_amd/_lib.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, Opts, case_matrix, case_names, load_case
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def _synthetic_tl(rows, cols, d, dist, seed=42, uniq=0.0, options=(), opts=None):
+    from telescope_amd import _lib, synthetic
+    from telescope_amd.likelihood import TelescopeLikelihood
+    eng = _lib.Engine(0)
+    for k, v in options:
+        eng.set_option(k, v)
+    eng.generate(0, rows, cols, synthetic.poisson_cdf_u32(d), seed, synthetic.DIST_CODE[dist], uniq)
+    return TelescopeLikelihood.from_engine(eng, opts or Opts(max_iter=5, em_epsilon=0.0))
+
+
+# ---- the lagged log-likelihood ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('name', [n for n in case_names() if n.endswith('_lnl')])
+def test_use_likelihood_goldens_run_on_the_carrying_pass(gpu_device, name):
+    """The `--use_likelihood` goldens (captured from the reference): same iteration count, lnl, parameters — with the layout that
+    lets the EM pass of iteration t+1 sum the lnl of iteration t, whether it was asked for at construction (`opts.use_likelihood`,
+    as telescope_assign.py:434-439 has it) or only at `em(use_likelihood=True)` (the layout is rebuilt then)."""
+    from telescope_amd.likelihood import TelescopeLikelihood
+    c = load_case(name)
+    raw = case_matrix(c)
+    for hint in (True, False):
+        o = Opts(c)
+        if hint:
+            o.use_likelihood = True
+        tl = TelescopeLikelihood(raw, o, device=0)
+        assert tl._eng.layout_info()['lnl_fused'] == (1 if hint else 0)
+        tl.em(use_likelihood=True)
+        info = tl._eng.layout_info()
+        assert info['lnl_fused'] == 1 and info['fused'] == 1, info
+        assert tl.n_iter == int(c['n_iter']) and tl.converged == bool(c['converged']), (tl.n_iter, int(c['n_iter']))
+        assert abs(tl.lnl - float(c['lnl'])) <= RTOL * abs(float(c['lnl']))
+        assert np.allclose(tl.pi, c['pi'], rtol=RTOL, atol=1e-300) and np.allclose(tl.theta, c['theta'], rtol=RTOL, atol=1e-300)
+        assert np.allclose(tl.pi_init, c['pi_init'], rtol=RTOL, atol=1e-300)
+        # z is the E-step before the LAST M-step (model.py:795): the pass that found the run converged committed nothing
+        assert np.array_equal(tl.reassign_colsums('exclude'), np.asarray(c['ra_exclude_0_colsum']).astype(np.int64))
+
+
+@pytest.mark.parametrize('rows,cols,d,chunks', [(1_000_000, 30_000, 20, (4, 3)), (300_000, 12_000, 9, (1, 1, 5)), (400_000, 38_000, 40, (7,))])
+def test_lnl_trace_against_the_c_oracle(gpu_device, rows, cols, d, chunks):
+    """BASELINE config 2 (and a short-row / a wide matrix) under `--use_likelihood`, fixed iterations: the log-likelihood of EVERY
+    iteration to 1e-9 against oracle/em_fused.c, through tsem_em_chunk itself in chunks of several sizes (the last value of a chunk
+    arrives as the next chunk's carry, the last of the run is flushed by the dedicated pass)."""
+    from oracle import em_fused as oc
+    total = sum(chunks)
+    tl = _synthetic_tl(rows, cols, d, 'zipf', uniq=0.05, options=(('use_likelihood', 1),), opts=Opts(max_iter=total, em_epsilon=0.0))
+    eng = tl._eng
+    assert eng.layout_info()['lnl_fused'] == 1
+    got, diffs, done = [], [], 0
+    for ci, n in enumerate(chunks):
+        d_, l_, stopped = eng.em_chunk(n, 0.0, True, first=(ci == 0), last=(ci == len(chunks) - 1))
+        assert not stopped and len(d_) == n
+        if ci > 0:
+            assert math.isnan(got[-1]) and not math.isnan(eng.lnl_carry)
+            got[-1] = eng.lnl_carry
+        else:
+            assert math.isnan(eng.lnl_carry)
+        got.extend(float(v) for v in l_)
+        diffs.extend(float(v) for v in d_)
+        assert math.isnan(got[-1]) == (ci < len(chunks) - 1)
+    ip, ix, rw = eng.export_csr()
+    ref = oc.em_fused_arrays(ip, ix, rw, cols, 0, 200000, 0.0, total, use_likelihood=True)
+    assert np.allclose(got, ref['lnls'], rtol=RTOL, atol=0), (got, ref['lnls'])
+    assert np.allclose(diffs, ref['diffs'], rtol=1e-7, atol=1e-15)
+    pi, theta = eng.get_params()
+    assert np.allclose(pi, ref['pi'], rtol=RTOL, atol=0) and np.allclose(theta, ref['theta'], rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize('rows,d,eps', [(300_000, 20, 3.0), (150_000, 12, 0.5)])
+def test_use_likelihood_converges_in_the_oracles_iteration(gpu_device, rows, d, eps):
+    """The |lnl_t - lnl_(t-1)| < epsilon test (model.py:785-789) is evaluated by the update kernel of iteration t+1 before it commits:
+    the run stops after the oracle's iteration, far below the cap, with that iteration's parameters."""
+    from oracle import em_fused as oc
+    tl = _synthetic_tl(rows, 30_000, d, 'zipf', uniq=0.05, opts=Opts(max_iter=400, em_epsilon=eps))
+    tl.em(use_likelihood=True)
+    assert tl._eng.layout_info()['lnl_fused'] == 1
+    ip, ix, rw = tl._eng.export_csr()
+    ref = oc.em_fused_arrays(ip, ix, rw, 30_000, 0, 200000, eps, 400, use_likelihood=True)
+    assert ref['converged'] and 3 < ref['n_iter'] < 300
+    assert tl.converged and tl.n_iter == ref['n_iter'], (tl.n_iter, ref['n_iter'])
+    assert abs(tl.lnl - ref['lnl']) <= RTOL * abs(ref['lnl'])
+    assert np.allclose(tl.pi, ref['pi'], rtol=RTOL, atol=0) and np.allclose(tl.theta, ref['theta'], rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize('when', [0, 3])
+def test_time_out_under_the_lagged_scheme(gpu_device, when):
+    """A hand-off time-out of the carrying pass (fused_dbg bit 5) in the first iteration of a run or in the middle: nobody commits,
+    the layout is rebuilt for the two-pass kernels, the lnl that was owed comes from the dedicated pass — trace and result as without."""
+    from oracle import em_fused as oc
+    tl = _synthetic_tl(200_000, 9_000, 14, 'zipf', uniq=0.05, options=(('use_likelihood', 1),), opts=Opts(max_iter=7, em_epsilon=0.0))
+    eng = tl._eng
+    got = []
+    if when:
+        _, l_, _ = eng.em_chunk(when, 0.0, True, first=True)
+        got.extend(float(v) for v in l_)
+    eng.set_option('fused_dbg', 32)
+    _, l_, stopped = eng.em_chunk(7 - when, 0.0, True, first=(when == 0), last=True)
+    if when:
+        got[-1] = eng.lnl_carry
+    got.extend(float(v) for v in l_)
+    info = eng.layout_info()
+    assert info['fallbacks'] == 1 and info['fused'] == 0 and not stopped
+    ip, ix, rw = eng.export_csr()
+    ref = oc.em_fused_arrays(ip, ix, rw, 9_000, 0, 200000, 0.0, 7, use_likelihood=True)
+    assert np.allclose(got, ref['lnls'], rtol=RTOL, atol=0), (got, ref['lnls'])
+    pi, _ = eng.get_params()
+    assert np.allclose(pi, ref['pi'], rtol=RTOL, atol=0)
+
+
+def test_second_run_under_the_lagged_scheme(gpu_device):
+    """A second em(use_likelihood=True) on the same model: its first lnl is compared with the one the first run ended on (model.py:786)."""
+    from oracle.telescope_oracle import OracleModel
+    c = load_case('bundled_lnl')
+    raw = case_matrix(c)
+    from telescope_amd.likelihood import TelescopeLikelihood
+    o = Opts(c)
+    o.max_iter = 6
+    tl = TelescopeLikelihood(raw, o, device=0)
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    for _ in range(2):
+        tl.em(use_likelihood=True)
+        om.em(o.em_epsilon, o.max_iter, use_likelihood=True)
+        assert tl.n_iter == om.n_iter and tl.converged == om.converged
+        assert abs(tl.lnl - om.lnl) <= RTOL * abs(om.lnl) and np.allclose(tl.pi, om.pi, rtol=RTOL, atol=1e-300)
