@@ -292,9 +292,15 @@ int  tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const
 int  tsem_legacy_randint(uint32_t* key624, int32_t* pos, const int32_t* counts, int64_t n, int32_t* out);
 /* the same assignment summed per GROUP of rows: scTelescope.output_report's per-barcode count matrix
  * `_assignments[_rows, :].sum(0)` for every barcode (model.py:611-625).  group_of_row[i] in
- * [0, n_groups) or -1 (row in no group); out is row-major [n_groups][K], caller-allocated. */
+ * [0, n_groups) or -1 (row in no group); out is row-major [n_groups][K], caller-allocated.
+ * tsem_set_groups copies the map to the device once (range-checked there) — the six methods of a report
+ * then pass group_of_row = NULL; a non-NULL map is set first.  The device computes the groups in tiles
+ * of at most 1 GB of output (option "group_tile_bytes"), one pass over the matrix per tile: n_groups x K
+ * doubles only have to fit the caller's `out`.  exclude / average / conf (conf_prob > 0.5) stream the
+ * 4-byte id + score-code arrays like tsem_report_colsums; the other methods take the generic row pass. */
+int  tsem_set_groups(tsem_ctx* h, const int32_t* group_of_row /* N, or NULL to drop */, int32_t n_groups);
 int  tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks,
-                          const int32_t* group_of_row, int32_t n_groups, double* out);
+                          const int32_t* group_of_row /* N, or NULL: the map of tsem_set_groups */, int32_t n_groups, double* out);
 
 /* ---- csr_matrix_plus primitives on arbitrary fp64 CSR (sparse_plus.py) ---- */
 int  tsem_csr_norm_rows(int device, int64_t n_rows, const int64_t* indptr,

@@ -157,6 +157,7 @@ def lib():
     L.tsem_reassign_rows.argtypes = [vp, C.c_int, C.c_double, C.c_int, vp, vp, i64, vp]
     L.tsem_reassign.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, vp]
     L.tsem_reassign_groups.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, C.c_int32, vp]
+    L.tsem_set_groups.argtypes = [vp, vp, C.c_int32]
     L.tsem_csr_norm_rows.argtypes = [C.c_int, i64, vp, vp, vp]
     L.tsem_csr_binmax_rows.argtypes = [C.c_int, i64, i32, vp, vp, vp]
     L.tsem_csr_scale.argtypes = [C.c_int, C.c_int, i64, i32, vp, vp, vp]
@@ -460,12 +461,27 @@ class Engine(object):
                                        ptr(mask)))
         return cs, mask
 
-    def reassign_groups(self, method, thresh, which, group_of_row, n_groups, picks=None):
-        n, k, _ = self.dims()
+    def set_groups(self, group_of_row, n_groups):
+        """Row -> group map of the per-group sums, copied to the device once (None drops it)."""
+        if group_of_row is None:
+            self._ck(self._L.tsem_set_groups(self._h, None, 0))
+            return
+        n, _, _ = self.dims()
         grp = np.ascontiguousarray(group_of_row, dtype=np.int32)
         if grp.shape != (n,):
             raise ValueError('group_of_row must have one entry per row')
-        out = np.zeros((int(n_groups), k))
+        self._ck(self._L.tsem_set_groups(self._h, ptr(grp), int(n_groups)))
+
+    def reassign_groups(self, method, thresh, which, group_of_row, n_groups, picks=None, out=None):
+        """[n_groups][K] sums of the assignment over the rows of each group; `group_of_row` None = the map of `set_groups`."""
+        n, k, _ = self.dims()
+        grp = None
+        if group_of_row is not None:
+            grp = np.ascontiguousarray(group_of_row, dtype=np.int32)
+            if grp.shape != (n,):
+                raise ValueError('group_of_row must have one entry per row')
+        if out is None:
+            out = np.zeros((int(n_groups), k))
         if picks is not None:
             picks = np.ascontiguousarray(picks, dtype=np.int32)
         self._ck(self._L.tsem_reassign_groups(self._h, RA_CODE[method], float(thresh), which, ptr(picks), ptr(grp),

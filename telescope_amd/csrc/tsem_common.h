@@ -170,6 +170,10 @@ struct tsem_ctx {
   int32_t* d_tie_rows = nullptr;    // rows with several best hits, in row order, and their counts: left by the last
   int32_t* d_tie_cnt = nullptr;     // tsem_report_colsums for tsem_report_ties / tsem_reassign_rows
   int64_t n_ties = 0;
+  int32_t* d_group = nullptr;       // [N] row -> group of the per-group sums (tsem_set_groups), -1 = none
+  int32_t n_groups = 0;
+  void* d_gtile = nullptr; size_t gtile_bytes = 0;   // one tile of per-group sums (by column | by id), kept between calls
+  int64_t opt_group_tile = 0;       // bytes of per-group output computed per pass over the matrix (0 = 1 GB)
   int32_t *d_rep_nb = nullptr, *d_rep_rows = nullptr;   // [N] scratch of tsem_report_colsums, kept between calls
   unsigned long long* d_rep_n = nullptr;
   void* d_rep_tmp = nullptr; size_t rep_tmp_bytes = 0;

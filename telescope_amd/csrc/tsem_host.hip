@@ -100,6 +100,8 @@ void tsem_free_matrix(tsem_ctx* h) {
   dfree(h->d_ctl); dfree(h->d_ctld); dfree(h->d_lnls); dfree(h->d_pi_first); dfree(h->d_theta_first); dfree(h->d_user_z);
   dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;
   dfree(h->d_rep_nb); dfree(h->d_rep_rows); dfree(h->d_rep_n);
+  dfree(h->d_group); h->n_groups = 0;
+  if (h->d_gtile) { (void)hipFree(h->d_gtile); h->d_gtile = nullptr; h->gtile_bytes = 0; }
   if (h->d_rep_tmp) { (void)hipFree(h->d_rep_tmp); h->d_rep_tmp = nullptr; h->rep_tmp_bytes = 0; }
   h->first_pending = false;
   h->d_red = nullptr;
@@ -181,6 +183,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "report_dbg") h->opt_report_dbg = v;
   else if (k == "report_lanes") h->opt_report_lanes = v;     // capacity (lanes per row x entries per lane) of k_report_rows: 8 .. 256 (0 = from the row lengths)
   else if (k == "issue_early") h->opt_issue = v;       // (kept for old scripts; the exchange has one order now)
+  else if (k == "group_tile_bytes") h->opt_group_tile = v;   // per-group sums: bytes of output (groups x K doubles) computed per pass over the matrix
   else if (k == "use_likelihood") h->opt_lnl_fused = v;      // before the matrix is laid out (tsem_set_model), or followed by tsem_prepare_likelihood
   else if (k == "fused_prof") {
     if (v && !h->d_prof) { if (hipMalloc((void**)&h->d_prof, TS_PROF_WORDS * 8) != hipSuccess) return TSEM_ERR_NOMEM; }

@@ -84,6 +84,15 @@ static int dalloc(tsem_ctx* h, T** p, size_t n) {
 template <typename T>
 static void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
+// Device memory freed when the scope ends: the temporaries of a call, on every return path.
+struct DevTmp {
+  void* p = nullptr;
+  ~DevTmp() { if (p) (void)hipFree(p); }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+#define TSEM_TMP(tmp, bytes) do { if (hipMalloc(&(tmp).p, std::max<size_t>(1, (size_t)(bytes))) != hipSuccess) { \
+    (tmp).p = nullptr; TSEM_FAIL(TSEM_ERR_NOMEM, "hipMalloc(" + std::to_string((size_t)(bytes)) + " B) failed"); } } while (0)
+
 static inline int cdiv64(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // TSEM_TRACE=1: host wall clock of the set-up phases on stderr (each lap synchronises the stream; a diagnostic, not a product path)

@@ -41,7 +41,8 @@ struct RowPassArgs {
   double* zout;          // EXPORT_Z / mask
   int32_t* nbest;
   double* colsums;
-  const int32_t* group;  // REASSIGN: optional row -> group map; colsums is then [n_groups][K]
+  const int32_t* group;  // REASSIGN: optional row -> group map; colsums is then [g1 - g0][K], rows of other groups (or -1) are skipped
+  int32_t g0 = 0, g1 = 0x7FFFFFFF;
   const int32_t* rowlist; int64_t nlist;   // REASSIGN: optional list of rows to visit (picks[] is then indexed by list position)
   // REPORT: conf, exclude and average in ONE pass -> colsums[0..K), [K..2K), [2K..3K); best-hit counts -> nbest
   // REASSIGN without groups: the Hs most popular slots of every column part are summed in LDS per
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
         continue;
       }
       const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[A.rowlist ? idx : row] : 0;
-      const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
+      const int64_t grp_off = A.group ? ((A.group[row] < A.g0 || A.group[row] >= A.g1) ? -1 : (int64_t)(A.group[row] - A.g0) * A.K) : 0;
       int base = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       continue;
     }
     const int pick = (method == TSEM_RA_CHOOSE && A.picks && nb > 1) ? A.picks[A.rowlist ? idx : row] : 0;
-    const int64_t grp_off = A.group ? (A.group[row] < 0 ? -1 : (int64_t)A.group[row] * A.K) : 0;
+    const int64_t grp_off = A.group ? ((A.group[row] < A.g0 || A.group[row] >= A.g1) ? -1 : (int64_t)(A.group[row] - A.g0) * A.K) : 0;
     int base = 0;
     for (int64_t k0 = s; k0 < e; k0 += RP_SUB) {
       int64_t k = k0 + lane;
@@ -323,6 +324,12 @@ struct ReportArgs {
   int HC, Hs;                          // LDS slots: pi*theta of ids < HC; accumulators of ids < Hs
   int32_t* defer_rows; unsigned long long* defer_n;   // rows left to k_report_slow
   int dbg;                             // timing experiments (wrong results): 1 drop the emits that miss the LDS slots, 2 the row-count stores, 4 the ties
+  // per-GROUP sums (GM != 0; the per-barcode count matrix of scTelescope.output_report, model.py:611-625): rows of the groups
+  // [g0, g1) add into a tile [g1 - g0][IDN] in HBM, by id — 32-bit counters for `exclude` (GM 1), doubles for `average` (GM 2) and
+  // `conf` (GM 3); other rows are skipped (their length is taken as 0).  No LDS accumulators: (group, column) pairs do not repeat
+  // within a workgroup the way columns do.
+  const int32_t* group = nullptr; int32_t g0 = 0, g1 = 0;
+  uint32_t* t_cnt = nullptr; double* t_val = nullptr;
 };
 // 16- / 8-byte loads at the natural alignment of their ELEMENTS (a row starts at any entry): plain vector types with
 // a reduced alignment, so the compiler emits one global_load_dwordx4 / dwordx2 (the target allows unaligned access)
@@ -355,9 +362,11 @@ template <int G> __device__ __forceinline__ int rr_sum_i(int v) {
   return v;
 }
 
-struct ReportEmit {                                        // where a row's values go (both report kernels), by id
+template <int GM>
+struct ReportEmit {                                        // where a row's values go (both report kernels), by id; GM != 0: into the row's group (goff)
   const ReportArgs& A; double* hotF; uint32_t* hot1; uint32_t* hot2; int Hs; double* hotL;
-  __device__ __forceinline__ void conf(uint32_t id, double v) const {
+  __device__ __forceinline__ void conf(uint32_t id, double v, int64_t goff) const {
+    if (GM != 0) { if (GM == 3) unsafeAtomicAdd(&A.t_val[goff + id], v); return; }
     if (A.g_conf_lo) {
       double hi, lo;
       exact_split01(v, hi, lo);
@@ -368,11 +377,17 @@ struct ReportEmit {                                        // where a row's valu
     if ((int)id < Hs) lds_add(&hotF[id], v);
     else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_conf[id], v);
   }
-  __device__ __forceinline__ void one(uint32_t id) const {           // the row's only best hit
+  __device__ __forceinline__ void one(uint32_t id, int64_t goff) const {           // the row's only best hit
+    if (GM != 0) {
+      if (GM == 1) atomicAdd(&A.t_cnt[goff + id], 1u);
+      if (GM == 2) unsafeAtomicAdd(&A.t_val[goff + id], 1.0);
+      return;
+    }
     if ((int)id < Hs) atomicAdd(&hot1[id], 1u);
     else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_n1[id], 1.0);
   }
-  __device__ __forceinline__ void tie(uint32_t id, int nb, double share) const {   // one of nb > 1 best hits
+  __device__ __forceinline__ void tie(uint32_t id, int nb, double share, int64_t goff) const {   // one of nb > 1 best hits
+    if (GM != 0) { if (GM == 2) unsafeAtomicAdd(&A.t_val[goff + id], share); return; }
     if (nb == 2) {
       if ((int)id < Hs) atomicAdd(&hot2[id], 1u);
       else if (!(A.dbg & 1)) unsafeAtomicAdd(&A.g_n2[id], 1.0);
@@ -390,7 +405,7 @@ struct ReportEmit {                                        // where a row's valu
 // threads per workgroup: the pass over the final z needs ~92 VGPRs (pi*theta gathers in flight) and spills under the 128 of a 1024-thread
 // workgroup (15.6 vs 5.3 ms); the pass over the initial z needs 68 and gains from 16 waves per CU instead of 8 (7.8 -> 6.9 ms with its tie list)
 constexpr int rr_nt(bool init) { return init ? 1024 : 512; }
-template <int G, int E, bool INIT>
+template <int G, int E, bool INIT, int GM = 0>
 __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
   static_assert(E == 8 || E == 16, "entries per lane");
   extern __shared__ double rr_lds[];   // [lut_len] score table | [HC] pi*theta | [Hs] conf (f64) | [Hs] single winners | [Hs] two-way ties (u32)
@@ -405,18 +420,23 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
   if (!INIT) for (int t = threadIdx.x; t < A.HC; t += blockDim.x) cH[t] = A.cnat2[t];
   for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) { hotF[t] = 0.0; hot1[t] = 0u; hot2[t] = 0u; }
   __syncthreads();
-  const ReportEmit EM{A, hotF, hot1, hot2, A.Hs, hotL};
+  const ReportEmit<GM> EM{A, hotF, hot1, hot2, A.Hs, hotL};
   const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
   const int64_t stride = (int64_t)gridDim.x * ngrp;
   const int64_t nit = (A.N + stride - 1) / stride;
   const bool one_winner = A.thresh > 0.51;                // an entry with z >= thresh is then the row's unique best hit
-  struct Ip { int64_t s; int len; };
+  struct Ip { int64_t s; int len; int64_t goff; };
   struct Ent { rr_u32x4_a2 id[E / 8]; rr_u32x4_a2 cd[E / 8]; };   // 8 ids / 8 codes per 16-byte word
   auto load_ip = [&](int64_t it) -> Ip {
     const int64_t row = it * stride + (int64_t)blockIdx.x * ngrp + grp;
     const int64_t rc = row < A.N ? row : A.N - 1;        // clamped, never branched around
     const rr_i64x2_a8 se = *reinterpret_cast<const rr_i64x2_a8*>(A.indptr + rc);   // indptr[rc], indptr[rc + 1]
-    Ip r; r.s = se.x; r.len = row < A.N ? (int)min<int64_t>(se.y - se.x, 0x7FFFFFFF) : 0;
+    Ip r; r.s = se.x; r.len = row < A.N ? (int)min<int64_t>(se.y - se.x, 0x7FFFFFFF) : 0; r.goff = 0;
+    if (GM != 0) {                                         // rows outside this tile's groups count as empty
+      const int32_t g = A.group[rc];
+      if (g < A.g0 || g >= A.g1) r.len = 0;
+      r.goff = (int64_t)(g - A.g0) * A.IDN;
+    }
     return r;
   };
   auto load_ent = [&](const Ip& p) -> Ent {
@@ -472,6 +492,14 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
       nm = in ? fmax(nm, n[j]) : nm;
     }
     const double r = recip0(rr_sum<G>(s));
+    if (GM == 4) {                                         // `all` per group (model.py:860-862): one for every entry with z > 0
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+        if (in && n[j] * r > 0.0) atomicAdd(&A.t_cnt[p.goff + half(t.id, j)], 1u);
+      }
+      return;
+    }
     nm = rr_max<G>(nm);
     const bool any = nm >= 0.0;
     const double zmax = any ? nm * r : -1.0;               // = max_j fl(n_j r): rounding is monotone
@@ -484,20 +512,21 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
       wid = b ? half(t.id, j) : wid;
     }
     const int nb = rr_sum_i<G>(nbl);
-    if (gl == 0 && row < A.N && !(A.dbg & 2)) A.nbest[row] = any ? nb : 0;
+    const int64_t goff = p.goff;
+    if (GM == 0 && gl == 0 && row < A.N && !(A.dbg & 2)) A.nbest[row] = any ? nb : 0;
     if (one_winner) {
       if (nbl != 0 && nb == 1) {                           // this lane holds the row's only best hit
-        EM.one(wid);
-        if (zmax >= A.thresh) { const double vc = zmax * recip0(zmax); if (vc != 0.0) EM.conf(wid, vc); }   // vsum = the winner's z
+        EM.one(wid, goff);
+        if (zmax >= A.thresh) { const double vc = zmax * recip0(zmax); if (vc != 0.0) EM.conf(wid, vc, goff); }   // vsum = the winner's z
       }
       if (__builtin_amdgcn_ballot_w64(nb > 1) != 0ull && !(A.dbg & 4)) {   // tied rows
-        if (nbl == 1 && nb == 2) EM.tie(wid, 2, 0.5);      // (the usual tie: two best hits, this lane holds one of them)
+        if (nbl == 1 && nb == 2) EM.tie(wid, 2, 0.5, goff);      // (the usual tie: two best hits, this lane holds one of them)
         if (__builtin_amdgcn_ballot_w64(nb > 1 && !(nbl == 1 && nb == 2) && nbl != 0) != 0ull) {
           const double share = 1.0 * recip0((double)nb);
 #pragma unroll
           for (int j = 0; j < E; ++j) {
             const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
-            if (nb > 1 && !(nbl == 1 && nb == 2) && in && n[j] * r == zmax) EM.tie(half(t.id, j), nb, share);
+            if (nb > 1 && !(nbl == 1 && nb == 2) && in && n[j] * r == zmax) EM.tie(half(t.id, j), nb, share, goff);
           }
         }
       }
@@ -516,8 +545,8 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
         const double z = n[j] * r;
         if (!in || !(z == zmax || z >= A.thresh)) continue;
         const uint32_t id = half(t.id, j);
-        if (z >= A.thresh) { const double vc = z * rv; if (vc != 0.0) EM.conf(id, vc); }
-        if (z == zmax) { if (nb == 1) EM.one(id); else EM.tie(id, nb, share); }
+        if (z >= A.thresh) { const double vc = z * rv; if (vc != 0.0) EM.conf(id, vc, goff); }
+        if (z == zmax) { if (nb == 1) EM.one(id, goff); else EM.tie(id, nb, share, goff); }
       }
     }
   };
@@ -542,6 +571,7 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
       ip0 = ip1; ip1 = ip2; e0 = e1;
     }
   }
+  if (GM != 0) return;
   __syncthreads();
   for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) {
     const double v = hotF[t];
@@ -554,10 +584,10 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
 }
 
 // the rows k_report_rows left: any length, sweeps of 16 entries, one 16-lane group per row
-template <bool INIT>
+template <bool INIT, int GM = 0>
 __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
   constexpr int G = 16;
-  const ReportEmit EM{A, nullptr, nullptr, nullptr, 0, nullptr};  // (no LDS slots here: a handful of rows)
+  const ReportEmit<GM> EM{A, nullptr, nullptr, nullptr, 0, nullptr};  // (no LDS slots here: a handful of rows)
   const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
   const int64_t nd = (int64_t)*A.defer_n;
   for (int64_t d = (int64_t)blockIdx.x * ngrp + grp; d < nd; d += (int64_t)gridDim.x * ngrp) {
@@ -565,6 +595,7 @@ __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
     const int64_t s = A.indptr[row];
     const int len = (int)(A.indptr[row + 1] - s);
     const uint32_t coff = len > 1 ? 0u : (uint32_t)A.IDN;
+    const int64_t goff = GM != 0 ? (int64_t)(A.group[row] - A.g0) * A.IDN : 0;   // (only rows of the tile's groups are deferred)
     auto numer = [&](int k) -> double {
       double x = A.lut[A.raw[s + k]];
       if (!INIT) x = x * A.cnat2[A.rid[s + k] + coff];
@@ -573,6 +604,10 @@ __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
     double y = 0.0;
     for (int k = gl; k < len; k += G) y += numer(k);
     const double r = recip0(sg_sum<G>(y));
+    if (GM == 4) {
+      for (int k = gl; k < len; k += G) { const double n = numer(k); if ((INIT || n != 0.0) && n * r > 0.0) atomicAdd(&A.t_cnt[goff + A.rid[s + k]], 1u); }
+      continue;
+    }
     double zmax = -1.0, vs = 0.0; int cnt = 0;
     for (int k = gl; k < len; k += G) {
       const double n = numer(k);
@@ -583,7 +618,7 @@ __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
     int nb = 0;
     for (int k = gl; k < len; k += G) { const double n = numer(k); if ((INIT || n != 0.0) && n * r == zmax) ++nb; }
     nb = sg_sum_i<G>(nb);
-    if (gl == 0) A.nbest[row] = cnt ? nb : 0;
+    if (GM == 0 && gl == 0) A.nbest[row] = cnt ? nb : 0;
     const double share = 1.0 * recip0((double)nb);
     for (int k = gl; k < len; k += G) {
       const double n = numer(k);
@@ -591,10 +626,41 @@ __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
       const double z = n * r;
       if (!(z == zmax || z >= A.thresh)) continue;
       const uint32_t id = A.rid[s + k];
-      if (z >= A.thresh) { const double vc = z * recip0(vsum); if (vc != 0.0) EM.conf(id, vc); }
-      if (z == zmax) { if (nb == 1) EM.one(id); else EM.tie(id, nb, share); }
+      if (z >= A.thresh) { const double vc = z * recip0(vsum); if (vc != 0.0) EM.conf(id, vc, goff); }
+      if (z == zmax) { if (nb == 1) EM.one(id, goff); else EM.tie(id, nb, share, goff); }
     }
   }
+}
+// a tile of per-group sums by id -> [groups][K] doubles by column
+__global__ __launch_bounds__(256) void k_group_finish(int64_t n, int IDN, int K, const int32_t* __restrict__ col_of_id,
+                                                      const uint32_t* __restrict__ t_cnt, const double* __restrict__ t_val, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t g = i / IDN;
+  const int j = col_of_id[(int)(i - g * IDN)];
+  if (j >= 0) out[g * K + j] = t_cnt ? (double)t_cnt[i] : t_val[i];
+}
+// `unique` per group (model.py:857-859: ceil(z) of the single-entry rows): nothing to normalise, one row per thread
+__global__ __launch_bounds__(256) void k_group_unique(int64_t N, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const uint16_t* __restrict__ raw, const double* __restrict__ lut, const double* __restrict__ pi /* null: initial z */,
+    const int32_t* __restrict__ group, int32_t g0, int32_t g1, int K, double* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  const int32_t g = group[row];
+  if (g < g0 || g >= g1) return;
+  const int64_t s = indptr[row];
+  if (indptr[row + 1] - s != 1) return;
+  const int col = indices[s];
+  double n = lut[raw[s]];
+  if (pi) n = n * pi[col];                                 // unique rows use pi alone (model.py:714)
+  if (!pi || n != 0.0) {                                   // z's pattern: every stored entry of the initial z, the non-zero products else
+    const double v = ceil(n * recip0(n));
+    if (v != 0.0) unsafeAtomicAdd(&out[(int64_t)(g - g0) * K + col], v);
+  }
+}
+__global__ void k_check_groups(int64_t N, const int32_t* __restrict__ grp, int32_t n_groups, uint32_t* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N && grp[i] >= n_groups) atomicOr(bad, 1u);
 }
 // by id -> by column: out[0..K) = conf, out[K..2K) = exclude, out[2K..3K) = average = n1 + n2 / 2 + the wider ties' shares
 __global__ void k_report_finish(int IDN, int K, const int32_t* __restrict__ col_of_id, const double* __restrict__ g_conf,
@@ -1081,37 +1147,137 @@ int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const 
   return TSEM_OK;
 }
 
+// The row -> group map of the per-group sums (tsem_reassign_groups): copied to the device ONCE and kept until the next call / the
+// next matrix (-1 = the row belongs to no group); range-checked on the device.  group_of_row == NULL drops it.
+int tsem_set_groups(tsem_ctx* h, const int32_t* group_of_row, int32_t n_groups) {
+  if (!h || !h->d_indptr || n_groups < 0) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  if (!group_of_row) { dfree(h->d_group); h->n_groups = 0; return TSEM_OK; }
+  TSEM_ALLOC(h->d_group, h->N);
+  h->n_groups = 0;
+  if (h->N) {
+    DevTmp bad;
+    TSEM_TMP(bad, 4);
+    TSEM_HIP(hipMemsetAsync(bad.p, 0, 4, h->stream));
+    TSEM_HIP(hipMemcpyAsync(h->d_group, group_of_row, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+    k_check_groups<<<cdiv64(h->N, 256), 256, 0, h->stream>>>(h->N, h->d_group, n_groups, bad.as<uint32_t>());
+    TSEM_HIP(hipGetLastError());
+    uint32_t b = 0;
+    TSEM_HIP(hipMemcpyAsync(&b, bad.p, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (b) { dfree(h->d_group); TSEM_FAIL(TSEM_ERR_ARG, "group_of_row entry out of range"); }
+  }
+  h->n_groups = n_groups;
+  return TSEM_OK;
+}
+
+// Per-group column sums of the assignment matrix (scTelescope.output_report, model.py:611-625: row g of the result is
+// reassign(method)[rows of group g, :].sum(0)).  The groups are processed in TILES of at most `group_tile_bytes` (1 GB) of output
+// on the device — n_groups x K doubles need not fit anywhere but in the caller's `out` — one pass over the matrix per tile:
+//   exclude | average | conf (conf_prob > 0.5) of the model's z: the streaming report kernel (k_report_rows, 4 B per entry), the
+//     row's winner added to its group's line of the tile by a global atomic (32-bit counters for `exclude`);
+//   unique | all | choose, a caller-assigned z, conf_prob <= 0.5, option "reproducible": the generic row pass over the CSR.
 int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks,
                          const int32_t* group_of_row, int32_t n_groups, double* out) {
-  if (!h || !h->d_indptr || !group_of_row || !out || n_groups < 0) return TSEM_ERR_ARG;
+  if (!h || !h->d_indptr || !out || n_groups < 0) return TSEM_ERR_ARG;
   if (method < TSEM_RA_EXCLUDE || method > TSEM_RA_ALL) TSEM_FAIL(TSEM_ERR_ARG, "bad reassign method");
   if (int rc = ensure_device(h)) return rc;
-  for (int64_t i = 0; i < h->N; ++i)
-    if (group_of_row[i] >= n_groups) TSEM_FAIL(TSEM_ERR_ARG, "group_of_row entry out of range");
+  if (group_of_row) { if (int rc = tsem_set_groups(h, group_of_row, n_groups)) return rc; }
+  else if (!h->d_group || h->n_groups != n_groups) TSEM_FAIL(TSEM_ERR_ARG, "tsem_reassign_groups: no group map (tsem_set_groups) for this number of groups");
   RowPassArgs A;
   if (int rc = rowpass_args(h, which, A)) return rc;
   A.method = method; A.thresh = thresh;
-  const int64_t n_out = (int64_t)n_groups * h->K;
-  double* d_out = nullptr;
-  int32_t *d_picks = nullptr, *d_grp = nullptr;
-  TSEM_ALLOC(d_out, n_out);
-  TSEM_ALLOC(d_grp, h->N);
-  TSEM_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * std::max<int64_t>(1, n_out), h->stream));
-  if (h->N) TSEM_HIP(hipMemcpyAsync(d_grp, group_of_row, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
-  if (method == TSEM_RA_CHOOSE && picks) {
-    TSEM_ALLOC(d_picks, h->N);
-    if (h->N) TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+  const int K = h->K, IDN = h->Kpad;
+  if (n_groups == 0 || K == 0) return TSEM_OK;
+  const int64_t budget = h->opt_group_tile > 0 ? h->opt_group_tile : ((int64_t)1 << 30);
+  const int tile = (int)std::max<int64_t>(1, std::min<int64_t>(n_groups, budget / ((int64_t)K * 8)));
+  const bool stream_ok = (method == TSEM_RA_EXCLUDE || method == TSEM_RA_AVERAGE || method == TSEM_RA_ALL || (method == TSEM_RA_CONF && thresh > 0.51)) &&
+                         h->opt_report_kernel != 0 && which != TSEM_Z_USER && h->d_rid16 && h->d_col_of_id && A.lut_len > 0 &&
+                         !h->opt_reproducible && h->N > 0;
+  // scratch kept between calls: the tile by column (what the caller gets) and, for the streaming kernel, the tile by id
+  const size_t out_bytes = (size_t)tile * K * 8, id_bytes = stream_ok ? (size_t)tile * IDN * 8 : 0;
+  if (h->gtile_bytes < out_bytes + id_bytes || !h->d_gtile) {
+    if (h->d_gtile) (void)hipFree(h->d_gtile);
+    h->d_gtile = nullptr; h->gtile_bytes = 0;
+    if (hipMalloc(&h->d_gtile, out_bytes + id_bytes) != hipSuccess) TSEM_FAIL(TSEM_ERR_NOMEM, "hipMalloc failed (per-group tile)");
+    h->gtile_bytes = out_bytes + id_bytes;
   }
-  A.colsums = d_out; A.picks = d_picks; A.group = d_grp;
-  double* d_lo = nullptr;
-  if (int rc = rowpass_lo_begin(h, A, n_out, &d_lo)) return rc;
-  if (h->N && n_out) k_rowpass<RP_REASSIGN><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
-  TSEM_HIP(hipGetLastError());
-  if (int rc = rowpass_lo_end(h, d_out, d_lo, n_out)) return rc;
-  if (n_out) TSEM_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
-  TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_out); (void)hipFree(d_grp);
-  if (d_picks) (void)hipFree(d_picks);
+  double* const d_out = static_cast<double*>(h->d_gtile);
+  void* const d_id = static_cast<char*>(h->d_gtile) + out_bytes;
+  DevTmp t_picks, t_c2, t_lo;
+  if (method == TSEM_RA_CHOOSE && picks) {
+    TSEM_TMP(t_picks, sizeof(int32_t) * h->N);
+    if (h->N) TSEM_HIP(hipMemcpyAsync(t_picks.p, picks, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+  }
+  ReportArgs R;
+  void (*rk)(ReportArgs) = nullptr;
+  void (*rs)(ReportArgs) = nullptr;
+  const bool init = A.pi == nullptr;
+  const int gm = method == TSEM_RA_EXCLUDE ? 1 : (method == TSEM_RA_AVERAGE ? 2 : (method == TSEM_RA_ALL ? 4 : 3));
+  size_t lds = 0;
+  if (stream_ok) {
+    R.N = h->N; R.nnz = h->nnz; R.K = K; R.IDN = IDN; R.indptr = h->d_indptr; R.rid = h->d_rid16; R.raw = h->d_raw;
+    R.lut = h->d_lut; R.lut_len = A.lut_len; R.cnat2 = nullptr; R.thresh = method == TSEM_RA_CONF ? thresh : 0.9; R.nbest = nullptr;
+    R.g_conf = R.g_n1 = R.g_n2 = R.g_avgt = nullptr; R.dbg = 0;
+    if (!init) {
+      TSEM_TMP(t_c2, sizeof(double) * 2 * IDN);
+      k_cnat2_id<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, h->d_col_of_id, A.pi, A.theta, t_c2.as<double>());
+      R.cnat2 = t_c2.as<double>();
+    }
+    const int lds_avail = TS_LDS_MAX - 2048 - R.lut_len * 8;
+    R.Hs = 0;
+    R.HC = init ? 0 : std::max(0, std::min(IDN, lds_avail / 8));
+    lds = (size_t)R.lut_len * 8 + (size_t)R.HC * 8;
+    int cap = 256;                                         // G x E: the smallest capacity that fewer than 0.5 % of the rows exceed
+    if (h->opt_report_lanes > 0) cap = (int)h->opt_report_lanes;
+    else if (h->have_rowstats)
+      for (int q = 0; q < 6; ++q)
+        if ((double)h->len_gt[q] <= 0.005 * (double)h->N) { cap = 8 << q; break; }
+#define RKG(G_, E_) (gm == 1 ? (init ? k_report_rows<G_, E_, true, 1> : k_report_rows<G_, E_, false, 1>) : \
+                     gm == 2 ? (init ? k_report_rows<G_, E_, true, 2> : k_report_rows<G_, E_, false, 2>) : \
+                     gm == 4 ? (init ? k_report_rows<G_, E_, true, 4> : k_report_rows<G_, E_, false, 4>) : \
+                               (init ? k_report_rows<G_, E_, true, 3> : k_report_rows<G_, E_, false, 3>))
+    if (cap <= 8) rk = RKG(1, 8); else if (cap <= 16) rk = RKG(1, 16); else if (cap <= 32) rk = RKG(2, 16);
+    else if (cap <= 64) rk = RKG(4, 16); else if (cap <= 128) rk = RKG(8, 16); else rk = RKG(16, 16);
+#undef RKG
+    rs = gm == 1 ? (init ? k_report_slow<true, 1> : k_report_slow<false, 1>) :
+         gm == 2 ? (init ? k_report_slow<true, 2> : k_report_slow<false, 2>) :
+         gm == 4 ? (init ? k_report_slow<true, 4> : k_report_slow<false, 4>) : (init ? k_report_slow<true, 3> : k_report_slow<false, 3>);
+    TSEM_HIP(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+    if (!h->d_rep_nb) { TSEM_ALLOC(h->d_rep_nb, h->N); TSEM_ALLOC(h->d_rep_rows, h->N); TSEM_ALLOC(h->d_rep_n, 1); }
+    R.defer_rows = h->d_rep_rows; R.defer_n = h->d_rep_n; R.group = h->d_group;
+    dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;   // (d_rep_rows was the last report's tie list)
+  } else if (h->opt_reproducible) {
+    TSEM_TMP(t_lo, out_bytes);
+  }
+  for (int g0 = 0; g0 < n_groups; g0 += tile) {
+    const int g1 = std::min(n_groups, g0 + tile);
+    const int64_t n_out = (int64_t)(g1 - g0) * K;
+    TSEM_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * n_out, h->stream));
+    if (stream_ok) {
+      const int64_t n_id = (int64_t)(g1 - g0) * IDN;
+      TSEM_HIP(hipMemsetAsync(d_id, 0, ((gm == 1 || gm == 4) ? 4 : 8) * (size_t)n_id, h->stream));
+      TSEM_HIP(hipMemsetAsync(R.defer_n, 0, sizeof(unsigned long long), h->stream));
+      R.g0 = g0; R.g1 = g1; R.t_cnt = (gm == 1 || gm == 4) ? static_cast<uint32_t*>(d_id) : nullptr; R.t_val = (gm == 1 || gm == 4) ? nullptr : static_cast<double*>(d_id);
+      rk<<<h->n_cu, rr_nt(init), lds, h->stream>>>(R);
+      TSEM_HIP(hipGetLastError());
+      rs<<<h->n_cu * 2, 256, 0, h->stream>>>(R);
+      TSEM_HIP(hipGetLastError());
+      k_group_finish<<<cdiv64(n_id, 256), 256, 0, h->stream>>>(n_id, IDN, K, h->d_col_of_id, R.t_cnt, R.t_val, d_out);
+      TSEM_HIP(hipGetLastError());
+    } else if (h->N && method == TSEM_RA_UNIQUE && which != TSEM_Z_USER && !h->opt_reproducible) {
+      k_group_unique<<<cdiv64(h->N, 256), 256, 0, h->stream>>>(h->N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, A.pi, h->d_group, g0, g1, K, d_out);
+      TSEM_HIP(hipGetLastError());
+    } else if (h->N) {
+      A.colsums = d_out; A.picks = t_picks.as<int32_t>(); A.group = h->d_group; A.g0 = g0; A.g1 = g1;
+      if (t_lo.p) { TSEM_HIP(hipMemsetAsync(t_lo.p, 0, sizeof(double) * n_out, h->stream)); A.colsums_lo = t_lo.as<double>(); }
+      k_rowpass<RP_REASSIGN><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+      TSEM_HIP(hipGetLastError());
+      if (t_lo.p) { k_add_lo<<<cdiv64(n_out, 256), 256, 0, h->stream>>>(n_out, d_out, t_lo.as<double>()); TSEM_HIP(hipGetLastError()); }
+    }
+    TSEM_HIP(hipMemcpyAsync(out + (int64_t)g0 * K, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+  }
   return TSEM_OK;
 }
 

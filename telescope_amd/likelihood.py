@@ -495,31 +495,52 @@ class TelescopeLikelihood(object):
             raise ValueError('Argument "method" should be one of (exclude, choose, average, conf, unique, all)')
         which = self._which(initial)
         picks = self._picks(which) if method == 'choose' else None
-        groups = [np.asarray(list(g), dtype=np.int64) for g in group_rows]
-        out = np.zeros((len(groups), self.K))
-        lo = 0
-        # one pass per "layer": every row belongs to at most one group within a layer
-        pending = [(gi, g - lo) for gi, g in enumerate(groups)]
-        pending = [(gi, g[(g >= 0) & (g < self.N)]) for gi, g in pending]
-        while any(len(g) for _, g in pending):
-            grp = np.full(self.N, -1, np.int32)
-            rest = []
-            for gi, g in pending:
-                if not len(g):
-                    rest.append((gi, g))
-                    continue
-                free = grp[g] < 0
-                first = np.zeros(len(g), bool)
-                first[np.unique(g, return_index=True)[1]] = True   # one listing per row and layer
-                take = free & first
-                grp[g[take]] = gi
-                rest.append((gi, g[~take]))
-            out += self._eng.reassign_groups(method, thresh, which, grp, len(groups), self._dense_picks(picks))
-            pending = rest
+        layers, n_groups = self._group_layers(group_rows)
+        out = np.zeros((n_groups, self.K))
+        for li, grp in enumerate(layers):
+            # the map of a layer goes to the device once and serves every method asked of it (a report asks for up to six)
+            key = (id(group_rows), n_groups, li)
+            if getattr(self, '_groups_on_device', None) != key:
+                self._eng.set_groups(grp, n_groups)
+                self._groups_on_device = key
+            if li == 0:
+                self._eng.reassign_groups(method, thresh, which, None, n_groups, self._dense_picks(picks), out=out)
+            else:
+                out += self._eng.reassign_groups(method, thresh, which, None, n_groups, self._dense_picks(picks))
         out = self.comm.sum_array(out.ravel()).reshape(out.shape)
         if _MASK_DTYPE[method] != np.float64:
             out = np.rint(out).astype(np.int64)
         return out
+
+    def _group_layers(self, group_rows):
+        """Row -> group maps for `reassign_group_sums`, one per LAYER: within a layer every row belongs to at most one group; the
+        k-th listing of a row (over all groups, duplicates inside a group included) goes to layer k.  Built once per `group_rows`
+        object (vectorised: one stable sort of the listings)."""
+        cached = getattr(self, '_group_layer_cache', None)
+        if cached is not None and cached[0] is group_rows:
+            return cached[1], cached[2]
+        groups = [np.asarray(list(g) if not isinstance(g, np.ndarray) else g, dtype=np.int64) for g in group_rows]
+        n_groups = len(groups)
+        lens = np.array([len(g) for g in groups], dtype=np.int64)
+        rows = np.concatenate(groups) if n_groups and lens.sum() else np.zeros(0, np.int64)
+        gid = np.repeat(np.arange(n_groups, dtype=np.int32), lens)
+        keep = (rows >= 0) & (rows < self.N)
+        rows, gid = rows[keep], gid[keep]
+        order = np.argsort(rows, kind='stable')
+        rs, gs = rows[order], gid[order]
+        first = np.ones(len(rs), bool)
+        first[1:] = rs[1:] != rs[:-1]
+        start = np.maximum.accumulate(np.where(first, np.arange(len(rs)), 0)) if len(rs) else np.zeros(0, np.int64)
+        rank = np.arange(len(rs)) - start                       # 0 for a row's first listing, 1 for its second, ...
+        layers = []
+        for l in range(int(rank.max()) + 1 if len(rank) else 1):
+            grp = np.full(self.N, -1, np.int32)
+            sel = rank == l
+            grp[rs[sel]] = gs[sel]
+            layers.append(grp)
+        self._group_layer_cache = (group_rows, layers, n_groups)
+        self._groups_on_device = None
+        return layers, n_groups
 
     def reassign(self, method, thresh=0.9, initial=False):
         """model.py:808-865 — the assignment matrix.  Returned as an `Assignment`: `.sum(0)` (all the

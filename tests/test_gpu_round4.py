@@ -135,3 +135,56 @@ def test_second_run_under_the_lagged_scheme(gpu_device):
         om.em(o.em_epsilon, o.max_iter, use_likelihood=True)
         assert tl.n_iter == om.n_iter and tl.converged == om.converged
         assert abs(tl.lnl - om.lnl) <= RTOL * abs(om.lnl) and np.allclose(tl.pi, om.pi, rtol=RTOL, atol=1e-300)
+
+
+# ---- per-barcode sums at the scale BASELINE config 5 names -------------------------------------------------------------------
+
+def test_per_barcode_sums_at_config5_scale(gpu_device):
+    """`scTelescope.output_report`'s per-barcode count matrix (model.py:611-625) on a pooled single-cell style shard: 5M fragments x
+    50k loci x ~100 per row, 2000 barcodes (an 800 MB count matrix).  `exclude` / `unique` / `all` bit for bit against fancy
+    indexing on the ORACLE's assignment matrix over a 200k-row sub-sample, `conf` / `average` to rounding; at full size the
+    barcodes' lines add up to the ungrouped column sums (every fragment has exactly one barcode) — integer methods exactly."""
+    import scipy.sparse as sp
+    from oracle.telescope_oracle import OracleModel
+    from telescope_amd._lib import Z_PREV
+    rows, cols, n_groups, sub = 5_000_000, 50_000, 2000, 200_000
+    tl = _synthetic_tl(rows, cols, 100, 'zipf', uniq=0.05, opts=Opts(max_iter=3, em_epsilon=0.0))
+    tl.em()
+    eng = tl._eng
+    rng = np.random.RandomState(11)
+    bc = rng.randint(0, n_groups, rows).astype(np.int32)
+    # (a) the sub-sample: barcodes of the first `sub` rows only
+    bc_sub = np.full(rows, -1, np.int32)
+    bc_sub[:sub] = bc[:sub]
+    ip, ix, rw = eng.export_csr()
+    raw_sub = sp.csr_matrix((rw[:ip[sub]], ix[:ip[sub]], ip[:sub + 1]), shape=(sub, cols))
+    pp, tp = eng.get_params(Z_PREV)
+    om = OracleModel(raw_sub, 0, 200000, max_score=tl.max_score)
+    om.z = om.estep(pp, tp)                                # z of the last E-step (model.py:795), rows are independent given pi, theta
+    member = sp.csr_matrix((np.ones(sub), (bc[:sub], np.arange(sub))), shape=(n_groups, sub))
+    for method in ('exclude', 'unique', 'all', 'conf', 'average'):
+        eng.set_groups(bc_sub, n_groups)
+        got = eng.reassign_groups(method, 0.9, Z_PREV, None, n_groups)
+        want = np.asarray((member @ sp.csr_matrix(om.reassign(method, 0.9)).astype(np.float64)).todense())
+        if method in ('conf', 'average'):
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-12), method
+        else:
+            assert np.array_equal(got, want), method
+    # (b) full size: one pass per method over all barcodes; the lines add up to the ungrouped sums
+    eng.set_groups(bc, n_groups)
+    out = np.zeros((n_groups, cols))
+    for method in ('exclude', 'unique', 'all', 'average', 'conf'):
+        eng.reassign_groups(method, 0.9, Z_PREV, None, n_groups, out=out)
+        total = out.sum(0)
+        ref = tl.reassign_colsums(method, 0.9)
+        if method in ('conf', 'average'):
+            assert np.allclose(total, ref, rtol=1e-9, atol=1e-9), method
+        else:
+            assert np.array_equal(total.astype(np.int64), ref), method
+    # (c) the same in tiles of 100 MB (8 passes over the matrix): the caller's matrix need not fit a device buffer
+    eng.set_option('group_tile_bytes', 100 << 20)
+    tiled = eng.reassign_groups('exclude', 0.9, Z_PREV, None, n_groups)
+    eng.reassign_groups('exclude', 0.9, Z_PREV, None, n_groups, out=out)
+    assert np.array_equal(tiled, out)
+    with pytest.raises(Exception):
+        eng.set_groups(np.full(rows, n_groups, np.int32), n_groups)      # out of range: refused (checked on the device)
