@@ -67,7 +67,10 @@ def parse():
     ap.add_argument('--parts', type=int, default=0, help='column parts per team (0 = fewest that fit LDS)')
     ap.add_argument('--hot-split', type=int, default=1, help='0: one accumulator slot per column (experiments)')
     ap.add_argument('--cpu-sample-rows', type=int, default=400_000)
-    ap.add_argument('--cpu-iters', type=int, default=2)
+    ap.add_argument('--cpu-iters', type=int, default=3, help='EM iterations timed on the CPU samples (SURVEY 8(d): T = 3)')
+    ap.add_argument('--cpu-large-rows', type=int, default=5_000_000,
+                    help='second CPU timing sample: this many rows at the workload\'s own entries per row (SURVEY 8(d): 5M x 40 when the '
+                         'host has the RAM, ~25 GB peak); 0 skips it.  The first sample is BASELINE config 2 (1M rows x ~20 per row)')
     ap.add_argument('--cpu-fused-rows', type=int, default=4_000_000,
                     help='sample rows for the all-cores C baseline (oracle/em_fused.c); 0 skips it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -97,6 +100,40 @@ def cpu_baseline(args, dist_code, cdf):
     import scipy.sparse as sp
     n = min(args.cpu_sample_rows, args.rows)
     T = args.cpu_iters
+
+    def time_oracle(rows, nnz_row):
+        """T EM iterations (estep + mstep, model.py:773-774) of the oracle on `rows` rows x ~nnz_row entries per row of the same
+        generator (same columns, distribution, seed): seconds per iteration, stored entries, set-up seconds."""
+        e = Engine(0)
+        e.generate(0, rows, args.cols, synthetic.poisson_cdf_u32(nnz_row), args.seed, dist_code, args.uniq_frac)
+        ip_, ix_, rw_ = e.export_csr()
+        e.close()
+        ts = time.perf_counter()
+        m = OracleModel(sp.csr_matrix((rw_, ix_, ip_), shape=(rows, args.cols)), 0, 200000)
+        ts = time.perf_counter() - ts
+        t0_ = time.perf_counter()
+        for _ in range(T):
+            z_ = m.estep(m.pi, m.theta)
+            m.pi, m.theta = m.mstep(z_)
+        dt_ = time.perf_counter() - t0_
+        return dict(rows=rows, nnz_row=nnz_row, nnz=int(ip_[-1]), iters=T, sec_per_iter=dt_ / T, nnz_per_sec=int(ip_[-1]) * T / dt_,
+                    setup_s=ts)
+
+    from telescope_amd import synthetic
+    timings = [time_oracle(min(1_000_000, args.rows), 20.0)]            # BASELINE config 2: 1M x 30k x ~20
+    if args.cpu_large_rows > 0:
+        try:
+            import psutil
+            free_gb = psutil.virtual_memory().available / 2 ** 30
+        except Exception:   # noqa: BLE001
+            free_gb = 0.0
+        need_gb = 140e-9 * args.cpu_large_rows * args.nnz_row + 4.0       # ~124 B per stored entry at the peak (SURVEY 8(d)) + slack
+        if free_gb >= need_gb and args.rows >= args.cpu_large_rows:
+            timings.append(time_oracle(args.cpu_large_rows, args.nnz_row))
+        else:
+            timings.append(dict(rows=args.cpu_large_rows, nnz_row=args.nnz_row, skipped='%.0f GB of host memory free, %.0f GB needed'
+                                % (free_gb, need_gb)))
+    best = [t for t in timings if 'nnz_per_sec' in t][-1]                # extrapolate from the LARGEST sample that ran
     eng = Engine(0)
     eng.generate(0, n, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
     ip, ix, rw = eng.export_csr()
@@ -104,16 +141,14 @@ def cpu_baseline(args, dist_code, cdf):
     tl.em()
     raw = sp.csr_matrix((rw, ix, ip), shape=(n, args.cols))
     om = OracleModel(raw, 0, 200000)
-    t0 = time.perf_counter()
     for _ in range(T):                      # the EM loop proper: estep + mstep (model.py:773-774)
         z = om.estep(om.pi, om.theta)
         pi, theta = om.mstep(z)
         om.z, om.pi, om.theta = z, pi, theta
-    dt = time.perf_counter() - t0
     # z is from the E-step before the last M-step, like model.py:795-801
     lnl_ref = om.calculate_lnl(om.z, om.pi, om.theta)
     nnz = int(ip[-1])
-    rate = nnz * T / dt
+    rate, dt = best['nnz_per_sec'], best['sec_per_iter'] * T
     # per-locus final counts (output_report, model.py:435-457) on the sample: the integer mode must agree
     # exactly, the confidence-weighted one to rounding
     np.random.seed(args.seed)
@@ -151,7 +186,7 @@ def cpu_baseline(args, dist_code, cdf):
                            sample_nnz=int(ipf[-1]), cores=os.cpu_count(), lnl=float(r5['lnl']))
         except Exception as e:   # noqa: BLE001 — the extra baseline must never break the bench line
             fused_c = dict(error=repr(e))
-    return dict(nnz_per_sec=rate, sec_per_iter=dt / T, sample_nnz=nnz, sample_rows=n, iters=T, fused_c=fused_c,
+    return dict(nnz_per_sec=rate, sec_per_iter=dt / T, sample_nnz=best['nnz'], sample_rows=n, iters=T, fused_c=fused_c, timings=timings, best=best,
                 lnl_ref=float(lnl_ref), lnl_gpu=float(tl.lnl),
                 lnl_rel_delta=abs(tl.lnl - lnl_ref) / abs(lnl_ref),
                 pi_max_rel_delta=float(np.max(np.abs(tl.pi - om.pi) / np.maximum(om.pi, 1e-300))),
@@ -267,34 +302,22 @@ def main():
     t_setup = time.perf_counter()
     eng.generate(r0, r1, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
     tl = TelescopeLikelihood.from_engine(eng, Opts(args.steps), comm)
+    tl.keep_kernel_timing = True        # em() leaves the per-pass HIP events on: roofline.kernel_ms comes from the timed region
     eng.synchronize()
     t_setup = time.perf_counter() - t_setup
     _, _, nnz_local = eng.dims()
 
+    import logging
+
     def run(n):
-        # exactly what TelescopeLikelihood.em() runs per chunk of iterations (likelihood.py): pass, in-library
-        # RCCL all-reduce (N > 1 / --force-comm), update and the device-side convergence test (never true at
-        # em_epsilon = 0), one host synchronisation per call
-        if comm is not None and not comm.in_library:
-            # fall-back transport (the library communicator could not be created, distributed.py): what em() then runs —
-            # one torch.distributed all-reduce of the engine's reduce buffer and one host round trip per iteration
-            from telescope_amd._lib import EngineError, ERR_TIMEOUT
-            timeouts = 0
-            done = 0
-            while done < n:
-                eng.em_pass()
-                comm.allreduce_device(eng, 0, args.cols + 1)
-                try:
-                    eng.em_update()
-                except EngineError as exc:      # some rank's persistent kernel timed out: nobody committed (slot K of the sums);
-                    timeouts += 1               # that rank switches to the two-pass kernels, every rank redoes the iteration
-                    if exc.code != ERR_TIMEOUT or timeouts > 3:
-                        raise
-                    eng.recover_timeout()
-                    continue
-                done += 1
-            return
-        eng.em_chunk(n, 0.0, False)
+        # `TelescopeLikelihood.em()` itself (likelihood.py), n iterations at em_epsilon = 0: chunks of EM_CHUNK = 8 iterations per host
+        # synchronisation — pass, in-library RCCL all-reduce (N > 1 / --force-comm), update, the device-side convergence test (never
+        # true at epsilon 0) — or, on the fall-back transport, one torch.distributed all-reduce and one host round trip per
+        # iteration with the time-out recovery.  Only the log-likelihood pass AFTER the loop (model.py:800-801) is left out: a step
+        # is one EM iteration; `whole_em_call` below times the call with it.
+        tl.max_iter, tl.epsilon = n, 0.0
+        tl.em(loglev=logging.DEBUG, final_lnl=False)
+        assert tl.n_iter == n, (tl.n_iter, n)
 
     def fence():
         eng.synchronize()
@@ -327,10 +350,30 @@ def main():
     wts = np.arange(1, args.cols + 1, dtype=np.float64) / args.cols
     check = dict(iterations=args.warmup + args.steps, pi_sum=float(pi_now.sum()), pi_weighted=float(np.dot(pi_now, wts)),
                  theta_weighted=float(np.dot(theta_now, wts)))
+    whole = None
+    if world == 1:
+        # the same call as a user makes it: `steps` iterations and the final log-likelihood pass (model.py:800-801)
+        eng.set_option('kernel_timing', 0)
+        tl.keep_kernel_timing = False
+        fence()
+        t1 = time.perf_counter()
+        tl.em(loglev=logging.DEBUG)
+        fence()
+        whole = dict(iterations=int(tl.n_iter), ms=(time.perf_counter() - t1) * 1e3, lnl=float(tl.lnl),
+                     note='tl.em() with max_iter = steps, em_epsilon = 0, incl. the log-likelihood pass after the loop; '
+                          'no per-pass HIP events')
     info = eng.layout_info()
     traffic = _pmc_traffic(total_rows, args, world, info.get('value_bytes', 8)) if info.get('fused') else None
     k_ms = ks['em_ms'] / max(1, ks['em_launches'])
     achieved = ks['algo_bytes_per_pass'] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # the nominal AND the measured-stream peak.  A pure streaming read of an 8 GB scratch buffer on this GPU, in this
+    # run (tsem_debug_stream_read: 16-byte non-temporal loads, eight in flight per thread, best of three launches)
+    try:
+        from telescope_amd._lib import stream_read_gbs
+        peak_measured = stream_read_gbs(local, 8 << 30, 3)
+    except Exception as e:   # noqa: BLE001 — e.g. no room for the scratch buffer beside a very large workload
+        peak_measured = None
+        print('bench.py: stream probe failed: %r' % (e,), file=sys.stderr)
     out = {
         'metric': 'EM iterations/sec on fragment x locus CSR (nnz/sec alongside)',
         'value': args.steps / elapsed, 'unit': 'iter/s',
@@ -339,6 +382,8 @@ def main():
         'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'nnz_per_sec': nnz_total * args.steps / elapsed,
         'check': check,
+        'timed_call': 'TelescopeLikelihood.em(final_lnl=False): chunks of 8 iterations per host synchronisation',
+        'whole_em_call': whole,
         'config': {
             'workload': 'synthetic %dM fragments x %dk loci, ~%g nnz/row, %s columns, fp64 arithmetic, '
                         'pi_prior=0 theta_prior=200000, em_epsilon=0 (fixed iterations)'
@@ -356,6 +401,9 @@ def main():
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC, profiles/pmc_traffic.json)',
+            'peak_nominal': HBM_PEAK_GBS, 'peak_measured': peak_measured,
+            'frac_of_measured': (achieved / peak_measured) if peak_measured else None,
+            'peak_measured_how': 'pure streaming read of 8 GB in this run (tsem_debug_stream_read), GB/s',
             'kernel': 'EM pass k_em_fused (rank 0 shard)', 'kernel_ms': k_ms, 'kernel_launches_timed': ks['em_launches'],
             'limiter': ('LDS atomics/gathers (2-byte score codes halve the HBM bytes)'
                         if info.get('value_bytes') == 2 else
@@ -375,11 +423,14 @@ def main():
         info2 = eng2.layout_info()
         if info2.get('value_bytes') == 2:
             eng2.set_option('kernel_timing', args.kernel_timing)
-            eng2.em_chunk(max(1, args.warmup), 0.0, False)
+            tl2.keep_kernel_timing = True
+            tl2.max_iter, tl2.epsilon = max(1, args.warmup), 0.0
+            tl2.em(loglev=logging.DEBUG, final_lnl=False)
             eng2.kernel_stats(reset=True)
             eng2.synchronize()
+            tl2.max_iter = args.steps
             t0 = time.perf_counter()
-            eng2.em_chunk(args.steps, 0.0, False)
+            tl2.em(loglev=logging.DEBUG, final_lnl=False)
             eng2.synchronize()
             el2 = time.perf_counter() - t0
             ks2 = eng2.kernel_stats()
@@ -392,6 +443,7 @@ def main():
                 'roofline': {'bound': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a2 / HBM_PEAK_GBS,
                              'kernel_ms': k2, 'algo_bytes_per_launch': ks2['algo_bytes_per_pass'],
                              'traffic': _pmc_traffic(total_rows, args, world, 2),
+                             'peak_measured': peak_measured, 'frac_of_measured': (a2 / peak_measured) if peak_measured else None,
                              'limiter': 'LDS (random ds_add_f64 scatter + gathers), not HBM: half the bytes of the headline layout'},
             }
         eng2.close()
@@ -400,12 +452,13 @@ def main():
         cb = cpu_baseline(args, dist_code, cdf)
         out['cpu_baseline'] = {
             'value': cb['nnz_per_sec'] / nnz_total, 'unit': 'iter/s', 'cores': 1, 'kind': 'port',
-            'sample': 'oracle/telescope_oracle.py (scipy.sparse operator sequence of the reference, '
-                      'single-threaded like scipy) timed for %d EM iterations on the first %d rows '
-                      '(%d nnz) of the same synthetic matrix: %.3f s/iter = %.3g nnz/s; value = that '
-                      'rate / workload nnz (linear extrapolation); host has %d cores'
-                      % (cb['iters'], cb['sample_rows'], cb['sample_nnz'], cb['sec_per_iter'],
+            'sample': 'oracle/telescope_oracle.py (scipy.sparse operator sequence of the reference, single-threaded like scipy) '
+                      'timed for T = %d EM iterations on %s; value = the rate of the LARGEST sample (%d rows x ~%g per row, %d nnz: '
+                      '%.3f s/iter = %.3g nnz/s) / workload nnz (linear extrapolation); 1 core used of %d'
+                      % (cb['iters'], ' and '.join('%d rows x ~%g per row' % (t['rows'], t['nnz_row']) for t in cb['timings']),
+                         cb['best']['rows'], cb['best']['nnz_row'], cb['best']['nnz'], cb['best']['sec_per_iter'],
                          cb['nnz_per_sec'], os.cpu_count()),
+            'samples': cb['timings'],
             'nnz_per_sec': cb['nnz_per_sec'],
         }
         out['speedup_vs_cpu'] = out['nnz_per_sec'] / cb['nnz_per_sec']

@@ -86,7 +86,9 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *                  column's grid has to move (tsem_layout_info[20] counts them); the rows keep their entry order ("deconflict"
  *                  is off), so that a row's partial sum is one run ending in at most two atomics.  That holds for rows of up to
  *                  256 entries; with longer rows tsem_layout_info[21] reports 2 instead of 1 and the last bit of such a row's
- *                  sum may depend on timing.  Needs the fused kernel and a score table of <= 2048 entries; column sums are
+ *                  sum may depend on timing.  3: a pass gave up moving a column's grid after 40 repeats — its sums are not
+ *                  guaranteed exact (never seen; reported instead of hidden).  A hand-off time-out in this mode redoes the pass on the
+ *                  fused kernel (the two-pass kernels have no exact sums); repeated time-outs end the run with TSEM_ERR_TIMEOUT on every rank.  Needs the fused kernel and a score table of <= 2048 entries; column sums are
  *                  within (entries of the column) x 2^-41 of exact, typically one fp64 rounding.  The float-valued sums of
  *                  tsem_reassign / _rows / _groups / tsem_report_colsums (conf, average) are accumulated exactly as well
  *                  (two atomics per value).  1: both pieces in ONE pass over THREE tables per part when they fit the LDS (score
@@ -138,6 +140,9 @@ int  tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* r
  *   layout and resets pi = theta = 1/K (model.py:667,673).  */
 int  tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0,
                    uint64_t* col_count, uint64_t* col_hash);
+/* Y[N] (model.py:679) and weights[N] = w_i (model.py:690) of the local rows as tsem_rowstats left them on the
+ * device (either pointer may be NULL): the reference's `tl.Y` / `tl._weights`. */
+int  tsem_export_rowinfo(tsem_ctx* h, uint8_t* Y, double* weights);
 int  tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0,
                     const uint64_t* col_count, const uint64_t* col_hash,
                     double pi_prior, double theta_prior);
@@ -327,6 +332,9 @@ int  tsem_debug_fused_startup(tsem_ctx* h, uint64_t* out4096);
 int64_t tsem_debug_subblock(tsem_ctx* h, int64_t block, int32_t part, uint32_t* out, int64_t cap);
 /* y[i] = the device log1p the lnl passes use (finite x >= 0), for accuracy tests against libm */
 int  tsem_debug_log1p(int device, int32_t n, const double* x, double* y);
+/* GB/s of a pure streaming read (16-byte non-temporal loads, 8 in flight per thread) over a scratch buffer of `bytes`,
+ * best of `reps` launches: the measured-stream peak quoted beside the nominal HBM peak */
+int  tsem_debug_stream_read(int device, int64_t bytes, int32_t reps, double* gbs);
 /* the same for the table-driven log1p of the fused lnl pass (64-entry table in LDS, ~1e-16 absolute error per evaluation) */
 int  tsem_debug_log1p_tab(int device, int32_t n, const double* x, double* y);
 

@@ -174,3 +174,86 @@ int oracle_exclude_counts(int64_t N, int32_t K, const int64_t* indptr, const int
   }
   return 0;
 }
+
+/* The column sums Telescope.output_report takes from ONE z (model.py:432-457): reassign('conf', thresh), ('exclude') and
+ * ('average') summed over the rows, with z = estep(pi, theta) (entries whose numerator is exactly 0 are not in z's pattern,
+ * model.py:720) or, initial != 0, z = Q.norm(1) (model.py:837: the stored pattern, zeros included).
+ *   conf     model.py:851-856  v = z where z >= thresh else 0;  v.norm(1) = v * recip0(rowsum v)
+ *   exclude  model.py:839-842  binmax(1) (sparse_plus.py:117-129: data == row maximum, the maximum taken over the FULL row of
+ *                              K columns, i.e. at least 0 when the pattern does not fill the row), rows with exactly one best hit
+ *   average  model.py:847-850  binmax(1).norm(1): 1 / (number of best hits) per best hit
+ * Thread-private accumulators added in thread order: the same bits for the same thread count.  Returns 0, -1 without memory. */
+int oracle_report_sums(int64_t N, int32_t K, const int64_t* indptr, const int32_t* indices, const uint16_t* raw,
+                       const double* lut, const double* pi, const double* theta, int32_t initial, double thresh,
+                       int32_t nthreads, double* conf, int64_t* exclude, double* average) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  const int T = omp_get_max_threads();
+#else
+  const int T = 1;
+#endif
+  double* ac = (double*)calloc((size_t)T * K, sizeof(double));
+  double* aa = (double*)calloc((size_t)T * K, sizeof(double));
+  int64_t* ae = (int64_t*)calloc((size_t)T * K, sizeof(int64_t));
+  if (!ac || !aa || !ae) { free(ac); free(aa); free(ae); return -1; }
+#pragma omp parallel
+  {
+#ifdef _OPENMP
+    const size_t t0 = (size_t)omp_get_thread_num() * K;
+#else
+    const size_t t0 = 0;
+#endif
+    double *c_ = ac + t0, *a_ = aa + t0;
+    int64_t* e_ = ae + t0;
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+      const int64_t s = indptr[i], e = indptr[i + 1];
+      const int amb = (e - s) > 1;
+      double sum = 0.0;
+      for (int64_t k = s; k < e; ++k) {
+        const int32_t j = indices[k];
+        sum += lut[raw[k]] * (initial ? 1.0 : (amb ? pi[j] * theta[j] : pi[j]));
+      }
+      const double r = recip0(sum);
+      /* pass 1: row maximum over the pattern (and the implicit zeros of a row shorter than K), confident mass */
+      int64_t npat = 0;
+      double zmax = -INFINITY, csum = 0.0;
+      for (int64_t k = s; k < e; ++k) {
+        const int32_t j = indices[k];
+        const double n = lut[raw[k]] * (initial ? 1.0 : (amb ? pi[j] * theta[j] : pi[j]));
+        if (!initial && n == 0.0) continue;
+        const double z = n * r;
+        ++npat;
+        if (z > zmax) zmax = z;
+        if (z >= thresh) csum += z;
+      }
+      if (npat < K && zmax < 0.0) zmax = 0.0;
+      if (npat == 0) continue;
+      const double cr = recip0(csum);
+      int nbest = 0;
+      for (int64_t k = s; k < e; ++k) {
+        const int32_t j = indices[k];
+        const double n = lut[raw[k]] * (initial ? 1.0 : (amb ? pi[j] * theta[j] : pi[j]));
+        if (!initial && n == 0.0) continue;
+        if (n * r == zmax) ++nbest;
+      }
+      for (int64_t k = s; k < e; ++k) {
+        const int32_t j = indices[k];
+        const double n = lut[raw[k]] * (initial ? 1.0 : (amb ? pi[j] * theta[j] : pi[j]));
+        if (!initial && n == 0.0) continue;
+        const double z = n * r;
+        if (z >= thresh) c_[j] += z * cr;
+        if (z == zmax) { a_[j] += 1.0 / (double)nbest; if (nbest == 1) e_[j] += 1; }
+      }
+    }
+  }
+  for (int j = 0; j < K; ++j) {
+    double c = 0.0, a = 0.0; int64_t x = 0;
+    for (int t = 0; t < T; ++t) { c += ac[(size_t)t * K + j]; a += aa[(size_t)t * K + j]; x += ae[(size_t)t * K + j]; }
+    if (conf) conf[j] = c;
+    if (average) average[j] = a;
+    if (exclude) exclude[j] = x;
+  }
+  free(ac); free(aa); free(ae);
+  return 0;
+}

@@ -30,6 +30,8 @@ def lib():
                                        vp, vp, vp, vp, vp, vp, vp]
         L.oracle_exclude_counts.restype = C.c_int
         L.oracle_exclude_counts.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+        L.oracle_report_sums.restype = C.c_int
+        L.oracle_report_sums.argtypes = [C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_int32, dbl, C.c_int32, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -58,6 +60,24 @@ def exclude_counts(indptr, indices, data, k, pi, theta, max_score=None):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     lib().oracle_exclude_counts(len(indptr) - 1, int(k), p(indptr), p(indices), p(data), p(lut), p(pi), p(theta), p(counts))
     return counts
+
+
+def report_sums(indptr, indices, data, k, pi, theta, thresh=0.9, initial=False, max_score=None, nthreads=0):
+    """(conf, exclude, average): the column sums of reassign('conf', thresh) / ('exclude') / ('average') for
+    z = estep(pi, theta), or z = Q.norm(1) with initial=True (oracle_report_sums in em_fused.c)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    data = np.ascontiguousarray(data, dtype=np.uint16)
+    lut = np.ascontiguousarray(score_lut(int(max_score if max_score is not None else data.max())))
+    pi = np.ascontiguousarray(pi, dtype=np.float64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    conf, excl, avg = np.zeros(k), np.zeros(k, np.int64), np.zeros(k)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().oracle_report_sums(len(indptr) - 1, int(k), p(indptr), p(indices), p(data), p(lut), p(pi), p(theta),
+                                  1 if initial else 0, float(thresh), int(nthreads), p(conf), p(excl), p(avg))
+    if rc:
+        raise MemoryError('oracle_report_sums')
+    return conf, excl, avg
 
 
 def em_fused_arrays(indptr, indices, data, k, pi_prior=0, theta_prior=200000, epsilon=1e-7, max_iter=100, nthreads=0,

@@ -48,12 +48,30 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
     common = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
               '-I' + os.path.join(ROOT, 'include'), '-I' + csrc] + list(extra_flags)
 
+    import re
+
+    def includes(path, seen):
+        """Quoted #include closure of one source file (the library's own headers)."""
+        for name in re.findall(r'^\s*#include\s+"([^"]+)"', open(path).read(), re.M):
+            for d in (os.path.dirname(path), csrc, os.path.join(ROOT, 'include')):
+                q = os.path.join(d, name)
+                if os.path.exists(q) and q not in seen:
+                    seen.add(q)
+                    includes(q, seen)
+        return seen
+
     def compile_unit(src):
         obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '.o')
+        stamp = obj + '.flags'
+        flags = ' '.join(common)
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == flags and \
+                all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + sorted(includes(src, set()))):
+            return obj                                   # this unit's object is newer than everything it is made from
         cmd = common + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        open(stamp, 'w').write(flags)
         return obj
     with ThreadPoolExecutor(max_workers=len(units)) as ex:
         objs = list(ex.map(compile_unit, units))
@@ -112,6 +130,7 @@ def lib():
     L.tsem_dims.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]
     L.tsem_export_csr.argtypes = [vp, vp, vp, vp]
     L.tsem_rowstats.argtypes = [vp, vp, vp, vp, vp]
+    L.tsem_export_rowinfo.argtypes = [vp, vp, vp]
     L.tsem_set_model.argtypes = [vp, vp, vp, vp, vp, dbl, dbl]
     L.tsem_set_params.argtypes = [vp, vp, vp]
     L.tsem_get_params.argtypes = [vp, C.c_int, vp, vp]
@@ -167,6 +186,7 @@ def lib():
     L.tsem_debug_fused_startup.argtypes = [vp, vp]
     L.tsem_debug_log1p.argtypes = [C.c_int, C.c_int32, vp, vp]
     L.tsem_debug_log1p_tab.argtypes = [C.c_int, C.c_int32, vp, vp]
+    L.tsem_debug_stream_read.argtypes = [C.c_int, i64, i32, C.POINTER(dbl)]
     L.tsem_debug_subblock.argtypes = [vp, C.c_int64, C.c_int32, vp, C.c_int64]
     for name in exported_symbols():
         fn = getattr(L, name)
@@ -270,6 +290,13 @@ class Engine(object):
         cnt, hsh = np.zeros(k, np.uint64), np.zeros(k, np.uint64)
         self._ck(self._L.tsem_rowstats(self._h, ptr(stats), ptr(pisum0), ptr(cnt), ptr(hsh)))
         return stats, pisum0, cnt, hsh
+
+    def row_info(self):
+        """(Y uint8[N], weights f64[N]) of the local rows as the device holds them (model.py:679,690)."""
+        n, _, _ = self.dims()
+        y, w = np.zeros(n, np.uint8), np.zeros(n)
+        self._ck(self._L.tsem_export_rowinfo(self._h, ptr(y), ptr(w)))
+        return y, w
 
     def set_model(self, stats, pisum0, col_count, col_hash, pi_prior, theta_prior):
         stats = np.ascontiguousarray(stats, dtype=np.float64)
@@ -620,6 +647,15 @@ def debug_log1p(x, device=0, table=False):
     if rc != OK:
         raise EngineError('tsem_debug_log1p failed (%d)' % rc)
     return y
+
+
+def stream_read_gbs(device=0, nbytes=8 << 30, reps=3):
+    """GB/s a pure streaming read reaches on this GPU (tsem_debug_stream_read)."""
+    g = C.c_double()
+    rc = lib().tsem_debug_stream_read(device, int(nbytes), int(reps), C.byref(g))
+    if rc:
+        raise EngineError('tsem_debug_stream_read failed (%d)' % rc)
+    return g.value
 
 
 def csr_norm_rows(indptr, data, device=0):

@@ -79,8 +79,11 @@ struct tsem_ctx {
   int32_t* d_uni_col = nullptr;     // [N_uni]
   uint16_t* d_uni_code = nullptr;   // [N_uni]
   uint32_t* d_maxcode = nullptr;    // [1]
+  uint16_t* d_row_code = nullptr;   // [N] per CSR row: its largest raw score (w_i = lut[code], model.py:690); tsem_rowstats, kept for tsem_export_rowinfo
+  uint8_t* d_row_cls = nullptr;     // [N] 0 empty row, 1 unique (Y_i = 0), 2 ambiguous (Y_i = 1, model.py:679)
   int32_t max_code = -1;            // largest raw score of the resident matrix (-1: not taken yet); tsem_max_score
   bool have_rowstats = false;
+  bool bin_inexact = false;         // option "reproducible": a pass gave up moving a column's grid after 40 repeats (its sums are not exact)
 
   // ---- model scalars (GLOBAL after set_model) ----
   double W_tot = 0, W_amb = 0, w_max = 0, pi_prior = 0, theta_prior = 0;

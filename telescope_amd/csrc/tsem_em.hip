@@ -511,8 +511,9 @@ __global__ void k_bin_check(int K, const double* __restrict__ red, const uint32_
 __global__ void k_bin_finish(int K, const double* __restrict__ red_hi, double* __restrict__ red, const uint32_t* __restrict__ colmap, int Kp,
                              uint16_t* __restrict__ ebias, uint8_t* __restrict__ ovf, int16_t* __restrict__ hist) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j == 0) red[K] = fmax(red[K], red_hi[K]);             // a time-out of either pass
-  if (j >= K) return;
+  const double bad = fmax(red[K], red_hi[K]);               // a time-out of either pass: the sums mean nothing, the update kernel refuses
+  if (j == 0) red[K] = bad;                                 // them — and the bounds / the drop history must not learn from them
+  if (j >= K || bad > 0.0) return;
   const double S = red_hi[j] + red[j];
   red[j] = S;
   int copies;
@@ -581,7 +582,11 @@ static int em_pass(tsem_ctx* h, bool lag) {
       uint32_t redo = 0;
       TSEM_HIP(hipMemcpyAsync(&redo, h->d_binflag, 4, hipMemcpyDeviceToHost, h->stream));
       TSEM_HIP(hipStreamSynchronize(h->stream));
-      if (!redo || attempt >= 40) break;                     // (40 x 24 bits: from the largest weight down to the smallest normal number)
+      if (!redo) break;
+      if (attempt >= 40) {                                   // (40 x 24 bits: from the largest weight down to the smallest normal number)
+        h->bin_inexact = true;                               // the sums of this pass are NOT guaranteed exact: tsem_layout_info[21] says so
+        break;
+      }
       h->n_bin_repeats += 1;
     }
     TSEM_HIP(hipMemcpyAsync(h->d_red_hi, h->d_red, sizeof(double) * (h->K + 2), hipMemcpyDeviceToDevice, h->stream));
@@ -695,6 +700,16 @@ int tsem_fallback_twopass(tsem_ctx* h) {
   TSEM_HIP(hipStreamSynchronize(h->stream));
   uint32_t e = 0;
   (void)tsem_take_fused_error(h, &e);
+  if (h->opt_reproducible) {
+    // the exact sums exist only in the fused kernel: keep the layout and let the caller redo the pass on it (every rank of a
+    // row-sharded run sees the time-out through slot K and counts the same retries, so repeated time-outs end the run on
+    // all of them together with TSEM_ERR_TIMEOUT — nobody is left in a collective, nothing is half torn down)
+    h->opt_dbg &= ~(int64_t)(32 | 64);
+    h->n_fallbacks += 1;
+    fprintf(stderr, "libtelescope_em: the persistent EM kernel missed a hand-off (watchdog code %u); option `reproducible` keeps the "
+                    "fused kernel: redoing the pass\n", e);
+    return TSEM_OK;
+  }
   h->em_kernel = TSEM_EMK_TWOPASS;
   h->opt_format = 1;                                       // the two-pass kernels read fp64 entries
   h->opt_dbg &= ~(int64_t)(32 | 64);

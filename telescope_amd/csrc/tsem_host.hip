@@ -92,7 +92,7 @@ void tsem_free_layout(tsem_ctx* h) {
 void tsem_free_matrix(tsem_ctx* h) {
   dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_raw); dfree(h->d_lut);
   dfree(h->d_amb_row); dfree(h->d_amb_wcode); dfree(h->d_amb_wcode_c); dfree(h->d_slot_row); dfree(h->d_uni_col); dfree(h->d_uni_code);
-  dfree(h->d_pisum0); dfree(h->d_twin_rep); dfree(h->d_ucount); dfree(h->d_colcount);
+  dfree(h->d_pisum0); dfree(h->d_twin_rep); dfree(h->d_ucount); dfree(h->d_colcount); dfree(h->d_row_code); dfree(h->d_row_cls);
   tsem_free_layout(h);
   dfree(h->d_pi); dfree(h->d_theta); dfree(h->d_pi_prev); dfree(h->d_theta_prev);
   dfree(h->d_ctab); dfree(h->d_ctab_prev); dfree(h->d_red_own); dfree(h->d_tmp_pi); dfree(h->d_tmp_theta);
@@ -470,6 +470,50 @@ int tsem_debug_log1p_tab(int device, int32_t n, const double* x, double* y) {
   return e == hipSuccess ? TSEM_OK : TSEM_ERR_HIP;
 }
 
+// What a pure streaming read reaches on this GPU: grid-stride, eight 16-byte non-temporal loads in flight per thread (the
+// best plain variant of tools/ubench/stream.hip), sum into a register, no store.  The "measured-stream peak" beside the
+// nominal 8 TB/s in bench.py's roofline block.
+typedef unsigned int sp_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void k_stream_probe(const sp_u32x4* __restrict__ p, int64_t n16, uint32_t* __restrict__ out) {
+  sp_u32x4 acc = {0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    sp_u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; i < n16; i += stride) acc += __builtin_nontemporal_load(p + i);
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = acc.x;      // (never true for the memset pattern: keeps the loads alive)
+}
+/* best of `reps` timed launches over a scratch buffer of `bytes` (allocated and freed here); *gbs = bytes / time */
+int tsem_debug_stream_read(int device, int64_t bytes, int32_t reps, double* gbs) {
+  if (!gbs || bytes < (1 << 20) || reps < 1) return TSEM_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return TSEM_ERR_HIP;
+  DevTmp buf, out;
+  if (hipMalloc(&buf.p, (size_t)bytes) != hipSuccess) { buf.p = nullptr; return TSEM_ERR_NOMEM; }
+  if (hipMalloc(&out.p, 64) != hipSuccess) { out.p = nullptr; return TSEM_ERR_NOMEM; }
+  if (hipMemset(buf.p, 1, (size_t)bytes) != hipSuccess) return TSEM_ERR_HIP;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return TSEM_ERR_HIP;
+  const int64_t n16 = bytes / 16;
+  float best = 1e30f;
+  for (int r = 0; r <= reps; ++r) {                          // launch 0 warms up
+    (void)hipEventRecord(a, nullptr);
+    k_stream_probe<<<4096, 1024>>>(buf.as<sp_u32x4>(), n16, out.as<uint32_t>());
+    (void)hipEventRecord(b, nullptr);
+    if (hipEventSynchronize(b) != hipSuccess) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); return TSEM_ERR_HIP; }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    if (r && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  *gbs = (double)(n16 * 16) / ((double)best * 1e-3) / 1e9;
+  return TSEM_OK;
+}
+
 /* debug: the packed (local row << 16 | local column) words of sub-block (block, part); returns their number */
 int64_t tsem_debug_subblock(tsem_ctx* h, int64_t block, int32_t part, uint32_t* out, int64_t cap) {
   if (!h || !h->d_prc || !h->d_sb_off || block < 0 || block >= h->nb || part < 0 || part >= h->P) return TSEM_ERR_ARG;
@@ -488,7 +532,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[12] = h->last_slow_path; info[13] = h->max_subblock; info[14] = h->fmt_code ? 2 : 8; info[15] = h->n_hot_cols;
   info[16] = h->use_fused ? (int64_t)fz_lds_bytes(h, fz_fmt(h) != 0) : 0;   // dynamic LDS per workgroup of the fused kernel
   info[17] = h->sorted_layout ? 1 : 0; info[18] = h->geo; info[19] = h->n_fallbacks;
-  info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->len_gt[5] ? 2 : 1) : 0;     // 2: some row has more than 256 entries, see telescope_em.h
+  info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->bin_inexact ? 3 : (h->len_gt[5] ? 2 : 1)) : 0;     // 2: some row has more than 256 entries, see telescope_em.h
   info[22] = h->exact_single ? 1 : 0;                      // reproducible: both pieces in one pass
   info[23] = h->lnl3 ? 1 : 0;                              // the layout lets the EM pass carry the previous iteration's log-likelihood (option "use_likelihood")
   return TSEM_OK;

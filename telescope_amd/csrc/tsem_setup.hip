@@ -744,23 +744,24 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   if (int rc = ensure_device(h)) return rc;
   const int64_t N = h->N;
   const int K = h->K;
-  uint16_t* d_code = nullptr; uint8_t* d_cls = nullptr; double* d_wpart = nullptr;
-  int32_t *d_fa = nullptr, *d_fu = nullptr;
-  TSEM_ALLOC(d_code, N); TSEM_ALLOC(d_cls, N);
+  DevTmp t_wpart, t_fa, t_fu, t_pis, t_lg;                   // freed on every return path
+  TSEM_ALLOC(h->d_row_code, N); TSEM_ALLOC(h->d_row_cls, N);   // (kept: 3 B per row; tsem_export_rowinfo)
+  uint16_t* const d_code = h->d_row_code; uint8_t* const d_cls = h->d_row_cls;
   const int grid = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (N + 15) / 16));
-  TSEM_ALLOC(d_wpart, 2 * grid);
+  TSEM_TMP(t_wpart, sizeof(double) * 2 * grid);
+  double* const d_wpart = t_wpart.as<double>();
   TSEM_ALLOC(h->d_pisum0, K);
   TSEM_ALLOC(h->d_ucount, K + 1);
   TSEM_HIP(hipMemsetAsync(h->d_ucount, 0, sizeof(uint32_t) * (K + 1), h->stream));
-  double* d_pis_lv = nullptr;
-  TSEM_ALLOC(d_pis_lv, (size_t)PIS_LEVELS * K);
+  TSEM_TMP(t_pis, sizeof(double) * PIS_LEVELS * K);
+  double* const d_pis_lv = t_pis.as<double>();
   TSEM_HIP(hipMemsetAsync(d_pis_lv, 0, sizeof(double) * PIS_LEVELS * K, h->stream));
   int pis_e2 = 0;
   (void)std::frexp(h->lut_host[h->lut_len - 1] > 0 ? h->lut_host[h->lut_len - 1] : 1.0, &pis_e2);   // Q < 2^e2 (the table is increasing)
   TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
   TSEM_HIP(hipMemsetAsync(d_wpart, 0, sizeof(double) * 2 * grid, h->stream));
-  unsigned long long* d_lg = nullptr;
-  TSEM_ALLOC(d_lg, 8);
+  TSEM_TMP(t_lg, 64);
+  unsigned long long* const d_lg = t_lg.as<unsigned long long>();
   TSEM_HIP(hipMemsetAsync(d_lg, 0, 64, h->stream));
   if (N) {
     const double mean_len = (double)h->nnz / (double)N;    // lanes per row x 16 entries >= ~1.5 mean row lengths
@@ -784,8 +785,11 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
 
   // column signatures (popularity + twin detection)
   if (col_count && col_hash) {
-    unsigned long long *d_cnt = nullptr, *d_hash = nullptr;
-    TSEM_ALLOC(d_cnt, K); TSEM_ALLOC(d_hash, K);
+    DevTmp t_hash;
+    TSEM_TMP(t_hash, sizeof(unsigned long long) * K);
+    unsigned long long* const d_hash = t_hash.as<unsigned long long>();
+    TSEM_ALLOC(h->d_colcount, K);                          // LOCAL stored entries per column: reassign('all', initial) of this rank
+    unsigned long long* const d_cnt = h->d_colcount;
     TSEM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * K, h->stream));
     TSEM_HIP(hipMemsetAsync(d_hash, 0, sizeof(unsigned long long) * K, h->stream));
     if (N) {
@@ -806,12 +810,10 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     TSEM_HIP(hipMemcpyAsync(col_count, d_cnt, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipMemcpyAsync(col_hash, d_hash, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
-    dfree(h->d_colcount);
-    h->d_colcount = d_cnt;                                 // LOCAL stored entries per column: reassign('all', initial) of this rank
-    (void)hipFree(d_hash);
   }
   // compact ambiguous and unique rows
-  TSEM_ALLOC(d_fa, N + 1); TSEM_ALLOC(d_fu, N + 1);
+  TSEM_TMP(t_fa, 4 * (size_t)(N + 1)); TSEM_TMP(t_fu, 4 * (size_t)(N + 1));
+  int32_t* const d_fa = t_fa.as<int32_t>(); int32_t* const d_fu = t_fu.as<int32_t>();
   int32_t na = 0, nu = 0;
   TSEM_HIP(hipMemsetAsync(d_fa + N, 0, 4, h->stream));
   TSEM_HIP(hipMemsetAsync(d_fu + N, 0, 4, h->stream));
@@ -819,14 +821,14 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     k_class_flags<<<cdiv64(N, 256), 256, 0, h->stream>>>(N, d_cls, d_fa, d_fu);
     size_t tb = 0;
     TSEM_HIP(rocprim::exclusive_scan(nullptr, tb, d_fa, d_fa, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(), h->stream));
-    void* tmp = nullptr;
-    TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+    DevTmp t_scan;
+    TSEM_TMP(t_scan, tb);
+    void* const tmp = t_scan.p;
     TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_fa, d_fa, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(), h->stream));
     TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_fu, d_fu, (int32_t)0, (size_t)(N + 1), rocprim::plus<int32_t>(), h->stream));
     TSEM_HIP(hipMemcpyAsync(&na, d_fa + N, 4, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipMemcpyAsync(&nu, d_fu + N, 4, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
-    (void)hipFree(tmp);
   }
   h->N_amb = na; h->N_uni = nu;
   if (int rc = tsem_choose_geometry(h)) return rc;
@@ -840,8 +842,26 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
                                                          h->d_uni_code);
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_code); (void)hipFree(d_cls); (void)hipFree(d_wpart); (void)hipFree(d_fa); (void)hipFree(d_fu); (void)hipFree(d_lg); (void)hipFree(d_pis_lv);
   h->have_rowstats = true;
+  return TSEM_OK;
+}
+
+/* Y (model.py:679: 1 where the row has several stored entries) and the row weights w_i = max_j Q_ij (model.py:690) of the
+ * local rows, as tsem_rowstats left them on the device — the per-row inputs of every EM pass. */
+int tsem_export_rowinfo(tsem_ctx* h, uint8_t* Y, double* weights) {
+  if (!h || !h->have_rowstats || !h->d_row_code || !h->d_row_cls) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  const int64_t N = h->N;
+  std::vector<uint8_t> cls((size_t)N);
+  std::vector<uint16_t> code((size_t)N);
+  if (N) {
+    TSEM_HIP(hipMemcpy(cls.data(), h->d_row_cls, (size_t)N, hipMemcpyDeviceToHost));
+    TSEM_HIP(hipMemcpy(code.data(), h->d_row_code, 2 * (size_t)N, hipMemcpyDeviceToHost));
+  }
+  for (int64_t i = 0; i < N; ++i) {
+    if (Y) Y[i] = cls[i] == 2 ? 1 : 0;
+    if (weights) weights[i] = cls[i] ? h->lut_host[code[i]] : 0.0;
+  }
   return TSEM_OK;
 }
 

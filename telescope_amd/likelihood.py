@@ -226,9 +226,14 @@ class TelescopeLikelihood(object):
 
     @property
     def Y(self):
-        """model.py:679 — N x 1 uint8 ambiguity indicator."""
-        r = self._need_raw()
-        return (np.diff(r.indptr) > 1).astype(np.uint8).reshape(-1, 1)
+        """model.py:679 — N x 1 uint8 ambiguity indicator, as the device holds it (tsem_export_rowinfo)."""
+        return self._eng.row_info()[0].reshape(-1, 1)
+
+    @property
+    def _weights(self):
+        """model.py:690 — `Q.max(1)`: the N x 1 sparse column of row weights w_i, read back from the device."""
+        w = self._eng.row_info()[1]
+        return sp.coo_matrix(w.reshape(-1, 1))
 
     @property
     def z(self):
@@ -303,8 +308,9 @@ class TelescopeLikelihood(object):
         return cur
 
     # ---- EM loop ---------------------------------------------------------------------
-    def em(self, use_likelihood=False, loglev=lg.WARNING, save_memory=True):
-        """model.py:762-806 — same control flow, log lines and final state.
+    def em(self, use_likelihood=False, loglev=lg.WARNING, save_memory=True, final_lnl=True):
+        """model.py:762-806 — same control flow, log lines and final state.  (`final_lnl=False`, not in the reference: skip the
+        log-likelihood pass after the loop, model.py:800-801 — bench.py times the EM iterations proper with it.)
 
         One fused E+M device pass per iteration.  The engine runs CHUNKS of iterations without a host
         round trip (`Engine.em_chunk`): pass, all-reduce of the per-locus column sums over the library's
@@ -382,7 +388,7 @@ class TelescopeLikelihood(object):
         self._z, self._z_which = None, Z_PREV   # z of the last E-step, exported on demand
         self._report_cache = {}
         _con = 'converged' if converged else 'terminated'
-        if not use_likelihood:
+        if not use_likelihood and final_lnl:
             self.lnl = eng.final_lnl() if chunked else self._device_lnl()
         self.n_iter, self.converged = inum, converged
         lg.log(loglev, 'EM {:s} after {:d} iterations.'.format(_con, inum))

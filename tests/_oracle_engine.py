@@ -52,6 +52,10 @@ class OracleShardEngine(object):
         return self.raw.indptr.astype(np.int64), self.raw.indices.astype(np.int32), self.raw.data.astype(np.uint16)
 
     # --- model ---
+    def row_info(self):
+        w = np.asarray(self.om.weights.todense()).ravel() if self.N else np.zeros(0)
+        return self.om.Y.ravel().astype(np.uint8), w
+
     def rowstats(self):
         om = self.om
         w = np.asarray(om.weights.todense()).ravel() if self.N else np.zeros(0)

@@ -372,6 +372,10 @@ def test_config4_full_size_against_the_c_oracle(gpu_device, fmt):
     pp, tp = tl._eng.get_params(Z_PREV)
     want = oc.exclude_counts(ip, ix, rw, k, pp, tp, max_score=tl.max_score)
     assert np.array_equal(tl.reassign_colsums('exclude'), want)
+    conf, excl, avg = oc.report_sums(ip, ix, rw, k, pp, tp, 0.9, False, max_score=tl.max_score)    # conf / average at full size too
+    assert np.array_equal(excl, want)
+    assert np.allclose(tl.reassign_colsums('conf', 0.9), conf, rtol=RTOL, atol=1e-9)
+    assert np.allclose(tl.reassign_colsums('average'), avg, rtol=RTOL, atol=1e-9)
 
 
 # ---------------------------------------------------------------------------------------------------

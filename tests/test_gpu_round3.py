@@ -163,6 +163,14 @@ def test_full_size_configs_against_the_c_oracle(gpu_device, rows, cols, d, fmt):
     want = oc.exclude_counts(ip, ix, rw, cols, pp, tp, max_score=tl.max_score)
     assert np.array_equal(tl.reassign_colsums('exclude'), want)
     assert np.array_equal(tl.reassign_colsums('exclude'), tl._eng.reassign('exclude', 0.9, Z_PREV)[0].astype(np.int64))   # both report kernels
+    # the other two sums output_report takes from a z (model.py:432-457), final AND initial z, against oracle_report_sums: the
+    # integer counts bit for bit, conf / average to summation order (1e-9: up to 1e6 terms per locus)
+    for initial, prm in ((False, (pp, tp)), (True, (tl.pi, tl.theta))):
+        conf, excl, avg = oc.report_sums(ip, ix, rw, cols, prm[0], prm[1], 0.9, initial, max_score=tl.max_score)
+        assert np.array_equal(tl.reassign_colsums('exclude', initial=initial), excl)
+        assert np.allclose(tl.reassign_colsums('conf', 0.9, initial=initial), conf, rtol=RTOL, atol=1e-9)
+        assert np.allclose(tl.reassign_colsums('average', initial=initial), avg, rtol=RTOL, atol=1e-9)
+        assert abs(avg.sum() - (rows - 0)) <= 1e-6 * rows            # every row with a pattern hands out exactly one unit
 
 
 @pytest.mark.parametrize('rows,d,eps', [(1_000_000, 20, 1e-5), (2_000_000, 40, 2e-6)])

@@ -137,6 +137,65 @@ def test_second_run_under_the_lagged_scheme(gpu_device):
         assert abs(tl.lnl - om.lnl) <= RTOL * abs(om.lnl) and np.allclose(tl.pi, om.pi, rtol=RTOL, atol=1e-300)
 
 
+# ---- option `reproducible`: a hand-off time-out keeps the fused kernel ------------------------------------
+
+@pytest.mark.parametrize('bit', [32, 64])
+def test_reproducible_mode_redoes_a_timed_out_pass_on_the_fused_kernel(gpu_device, bit):
+    """The exact sums exist only in the fused kernel, so a hand-off time-out (fused_dbg bit 5: EM pass, bit 6: lnl pass) must not
+    send a `reproducible` handle to the two-pass kernels — round 3 tried, failed inside the layout build and left the context
+    half torn down.  Now the pass is redone on the same layout: nobody commits the failed pass, the run ends in the SAME BITS as
+    a run without the time-out."""
+    import scipy.sparse as sp
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+    c = load_case('mid_zipf_20k')
+    raw = case_matrix(c)
+    runs = []
+    for dbg in (0, bit):
+        eng = _lib.Engine(0)
+        eng.set_option('reproducible', 1)
+        if dbg:
+            eng.set_option('fused_dbg', dbg)
+        eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), raw.shape[1], score_lut(int(raw.data.max())))
+        tl = TelescopeLikelihood.from_engine(eng, Opts(c))
+        tl._raw = sp.csr_matrix(raw)
+        tl.em()
+        info = eng.layout_info()
+        assert info['fused'] == 1 and info['reproducible'] == 1          # still the fused kernel, still exact
+        assert info['fallbacks'] == (1 if dbg else 0)
+        runs.append((tl.n_iter, tl.lnl, tl.pi.copy(), tl.theta.copy(), tl.reassign_colsums('conf', 0.9)))
+    a, b = runs
+    assert a[0] == b[0] == int(c['n_iter'])
+    assert a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert abs(a[1] - float(c['lnl'])) <= RTOL * abs(float(c['lnl']))
+
+
+# ---- the constructor's products against the goldens (model.py:635-700) -------------------------------------------------------
+
+@pytest.mark.parametrize('name', case_names(full_only=True))
+def test_constructor_products_against_the_goldens(gpu_device, name):
+    """What `TelescopeLikelihood.__init__` leaves behind (model.py:640-699), read back from the DEVICE and compared with what the
+    reference's constructor held when the golden case was recorded (tools/make_golden.py): max_score, Q.data and the per-row Y
+    and weights bit for bit (Q comes from a table built with the reference's numpy expression, w is a maximum, Y a count); the
+    sums W_tot, W_amb, pisum0 and the prior weights to summation order (1e-12; the device sums in another order than scipy)."""
+    from telescope_amd.likelihood import TelescopeLikelihood
+    c = load_case(name)
+    raw = case_matrix(c)
+    tl = TelescopeLikelihood(raw, Opts(c))
+    assert tl.max_score == int(c['max_score'])
+    assert np.array_equal(tl.Q.data, c['Q_data']) and np.array_equal(tl.Q.indices, raw.indices)
+    y, w = tl._eng.row_info()                                       # tsem_export_rowinfo: the k_rowstats outputs every EM pass reads
+    assert y.dtype == np.uint8 and np.array_equal(y, c['Y'])
+    assert np.array_equal(tl.Y, c['Y'].reshape(-1, 1)) and tl.Y.shape == (raw.shape[0], 1)
+    assert np.array_equal(w, c['weights'])
+    assert np.array_equal(np.asarray(tl._weights.todense()).ravel(), c['weights'])
+    for got, key in ((tl._total_wt, 'total_wt'), (tl._ambig_wt, 'ambig_wt'), (tl._pi_prior_wt, 'pi_prior_wt'),
+                     (tl._theta_prior_wt, 'theta_prior_wt')):
+        assert abs(got - float(c[key])) <= 1e-12 * abs(float(c[key])), key
+    assert np.allclose(tl._pisum0, c['pisum0'], rtol=1e-12, atol=0)
+    assert np.array_equal(tl._pisum0 == 0, c['pisum0'] == 0)        # columns without a unique fragment stay exactly 0
+
+
 # ---- per-barcode sums at the scale BASELINE config 5 names -------------------------------------------------------------------
 
 def test_per_barcode_sums_at_config5_scale(gpu_device):

@@ -145,3 +145,27 @@ def test_c_restatement_matches_reference_goldens(name):
     r1 = em_fused(case_matrix(c), float(c['pi_prior']), float(c['theta_prior']), float(c['em_epsilon']), int(c['max_iter']), nthreads=1,
                   use_likelihood=ul)
     assert np.allclose(r1['pi'], r['pi'], rtol=1e-12, atol=0) and r1['n_iter'] == r['n_iter']
+
+
+@pytest.mark.parametrize('name', [n for n in case_names(full_only=True)])
+def test_c_report_sums_match_reference_goldens(name):
+    """oracle_report_sums (em_fused.c: the conf / exclude / average column sums of one z) against the reference's own
+    `reassign(...).sum(0)` vectors, for the final z (posteriors of the parameters BEFORE the last M-step, model.py:795) and for
+    the initial one (Q.norm(1), model.py:837): integer counts bit for bit, float sums to summation order."""
+    from oracle.em_fused import report_sums
+    c = load_case(name)
+    raw = case_matrix(c)
+    o = Opts(c)
+    om = orc.OracleModel(raw, o.pi_prior, o.theta_prior)
+    if int(c['n_iter']) > 1:
+        om.em(0.0, int(c['n_iter']) - 1, bool(c['use_likelihood']))       # the parameters the last E-step saw
+    for initial in (0, 1):
+        conf, excl, avg = report_sums(raw.indptr, raw.indices, raw.data, raw.shape[1], om.pi, om.theta, 0.9, bool(initial),
+                                      max_score=int(c['max_score']))
+        assert np.array_equal(excl, c['ra_exclude_%d_colsum' % initial])
+        assert np.allclose(conf, c['ra_conf_%d_colsum' % initial], rtol=1e-10, atol=1e-13)
+        assert np.allclose(avg, c['ra_average_%d_colsum' % initial], rtol=1e-12, atol=0)
+    if 'ra_conf03_0_colsum' in c:                                          # a threshold below 0.5: several confident entries per row
+        conf, _, _ = report_sums(raw.indptr, raw.indices, raw.data, raw.shape[1], om.pi, om.theta, 0.3, False,
+                                 max_score=int(c['max_score']))
+        assert np.allclose(conf, c['ra_conf03_0_colsum'], rtol=1e-10, atol=1e-13)

@@ -49,8 +49,7 @@ def test_resume_writes_reference_reports(gpu_device, tmp_path, mode):
     for suffix in ('run_stats.tsv', 'TE_counts.tsv'):
         got = open(os.path.join(str(tmp_path), 'run-' + suffix)).read()
         want = open(os.path.join(GOLD, 'resume_%s-%s' % (mode, suffix))).read()
-        if got != want:   # rows of equal final_prop may come in any order (unstable sort, model.py:449)
-            assert sorted(got.splitlines()) == sorted(want.splitlines()), suffix
+        assert got == want, suffix      # byte for byte, the row order of the sort on final_prop (model.py:449) included
 
 
 @pytest.mark.gpu
@@ -71,8 +70,7 @@ def test_resume_reproducible_writes_the_same_bytes_twice(gpu_device, tmp_path, m
     assert outs[0] == outs[1]
     for sfx, got in outs[0].items():
         want = open(os.path.join(GOLD, 'resume_%s-%s' % (mode, sfx))).read()
-        if got != want:
-            assert sorted(got.splitlines()) == sorted(want.splitlines()), sfx
+        assert got == want, sfx
 
 
 @pytest.mark.gpu
@@ -95,8 +93,7 @@ def test_resume_row_sharded_over_two_rank_processes(gpu_device, tmp_path, mode, 
     for suffix in ('run_stats.tsv', 'TE_counts.tsv'):
         got = open(os.path.join(str(tmp_path), 'run-' + suffix)).read()
         want = open(os.path.join(GOLD, 'resume_%s-%s' % (mode, suffix))).read()
-        if got != want:   # rows of equal final_prop may come in any order (unstable sort, model.py:449)
-            assert sorted(got.splitlines()) == sorted(want.splitlines()), suffix
+        assert got == want, suffix      # byte for byte, the row order of the sort on final_prop (model.py:449) included
 
 
 def test_loader_reproduces_bundled_matrix():
@@ -147,4 +144,4 @@ def test_assign_end_to_end(gpu_device, tmp_path):
     assert got == open(os.path.join(GOLD, 'resume_exclude-TE_counts.tsv')).read()
     got = open(os.path.join(str(tmp_path), 'run-run_stats.tsv')).read().replace('1.0.3.1-mi355x', '1.0.3.1')
     want = open(os.path.join(GOLD, 'resume_exclude-run_stats.tsv')).read()
-    assert sorted(got.splitlines()) == sorted(want.splitlines())
+    assert got == want
