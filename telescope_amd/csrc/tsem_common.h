@@ -91,6 +91,7 @@ struct tsem_ctx {
   uint32_t* d_ucount = nullptr;            // [K+1] unique rows with a positive score per column (local); [K]: some stored score is 0
   unsigned long long* d_colcount = nullptr;   // [K] stored entries per column (local rows)
   bool em_cur = false, em_prev = false;    // current / previous pi, theta come from tsem_set_model or the M-step, not from tsem_set_params
+  int64_t opt_split = -1;                  // split layout: -1 when K needs it, 1 forced (tests), 0 never
   int64_t opt_issue = -1;                  // fused kernel, exchange wave: partner loads before the combine (1), after it (0), -1 auto
   int64_t opt_rowpass_wgs = 2;             // workgroups per CU of the reassign row pass (modes other than `all`)
   int64_t opt_report_kernel = 1;           // tsem_report_colsums runs k_report_rows (0: the generic k_rowpass<RP_REPORT>)
@@ -128,6 +129,8 @@ struct tsem_ctx {
   int64_t opt_lnl_fused = 0;        // option "use_likelihood" = 1: lay the matrix out so that the EM pass can sum the previous iteration's log-likelihood
                                     //    as well (fused kernel MODE 4: three tables per part in LDS, tsem_fused.h); tsem_em_chunk then needs no lnl pass per iteration
   bool lnl3 = false;                // the current layout allows it
+  bool split = false;               // SPLIT layout (K > 8 x 7680 on the fused path): parts of up to 15 424 columns, one LDS table per pass — a row-sum pass and a
+                                    // scatter pass per iteration (tsem_fused.h MODE 5 / 7), the log-likelihood over column halves (MODE 8)
   double* d_rinv = nullptr;         // [N_amb_pad] recip0(row sum) of the last MODE 4 pass (what the next one needs of its E-step)
   bool lag_agreed = false;          // row-sharded runs: EVERY rank can run MODE 4 (decided once per run, dropped for good after a time-out anywhere)
   bool lag_valid = false;           // the iteration committed last still owes its lnl, and d_rinv / d_ctab_prev are what the next MODE 4 pass needs for it

@@ -2,6 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// The column map: colmap[j] = part << CM_PS | log2(copies) << CM_LS | first accumulator slot of column j in its part.
+// (14 slot bits since round 4: a part of the SPLIT layout holds up to 15 424 columns — one table per pass, tsem_fused.h modes 5 / 7.)
+constexpr int CM_LS = 14, CM_PS = 17;
+constexpr unsigned CM_SM = (1u << CM_LS) - 1u;
+
 // log1p(x) for finite x >= 0 (the lnl passes evaluate it once per stored entry: 2*10^9 times per
 // pass at config 4, where the library routine's generality made the pass compute-bound).  The
 // classic argument reduction 1+x = 2^k (1+f), sqrt(2)/2 < 1+f < sqrt(2), log(1+f) = f - f^2/2 +

@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double
                             const int32_t* __restrict__ col_of_pc, const uint32_t* __restrict__ colmap,
                             double* __restrict__ red, int K, const uint32_t* __restrict__ sync, int P,
                             const uint32_t* __restrict__ ctl, unsigned long long* __restrict__ fz_xchg, int64_t fz_xchg_n,
-                            const double* __restrict__ lnl_part, const double* __restrict__ lnl_uni, int lnl_nu) {
+                            const double* __restrict__ lnl_part, const double* __restrict__ lnl_uni, int lnl_nu,
+                            const double* __restrict__ cmul = nullptr /* split layout: the partials are sums of Q s, times pi*theta of the slot */,
+                            const uint32_t* __restrict__ errlog = nullptr /* split layout: the error word k_keep_err saved of the row-sum pass */) {
   // the fused kernel's exchange ring must be zero at its next launch: cleared here, by the ~950 blocks of the
   // kernel that follows every fused pass (no launch of its own, no fence: the next fused launch is a kernel boundary away)
   if (fz_xchg) {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double
   }
   const int pcl = threadIdx.x % NC, slice = threadIdx.x / NC;
   const int pc = blockIdx.x * NC + pcl;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { red[K] = (sync && sync[9]) ? 1.0 : 0.0; if (!lnl_part) red[K + 1] = 0.0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { red[K] = ((sync && sync[9]) || (errlog && errlog[0])) ? 1.0 : 0.0; if (!lnl_part) red[K + 1] = 0.0; }
   if (lnl_part && blockIdx.x == 1 % gridDim.x) {
     // fused kernel MODE 4: the log-likelihood of the PREVIOUS iteration rides in slot K+1 (summed over the ranks with the column
     // sums): one partial per workgroup of the teams that formed + the unique rows' partials, fixed order
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double
   const int col = pc < Kpad ? col_of_pc[pc] : -1;        // -1: padding, or a secondary slot of a split column
   double s = 0.0;
   if (col >= 0) {
-    const int copies = 1 << ((colmap[col] >> 13) & 7u);
+    const int copies = 1 << ((colmap[col] >> CM_LS) & 7u);
     if (copies == 1) {
 #pragma unroll 8
       for (int g = slice; g < G; g += NS) s += partial[(int64_t)g * Kpad + pc];
@@ -201,8 +203,11 @@ __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double
   }
   part[slice][pcl] = s;
   __syncthreads();
-  if (slice == 0 && col >= 0)                            // fixed order -> deterministic given the partials
-    red[col] = ((part[0][pcl] + part[1][pcl]) + (part[2][pcl] + part[3][pcl])) + ((part[4][pcl] + part[5][pcl]) + (part[6][pcl] + part[7][pcl]));
+  if (slice == 0 && col >= 0) {                          // fixed order -> deterministic given the partials
+    const double t = ((part[0][pcl] + part[1][pcl]) + (part[2][pcl] + part[3][pcl])) + ((part[4][pcl] + part[5][pcl]) + (part[6][pcl] + part[7][pcl]));
+    // split layout: sum_i (Q_ij c_j) s_i = c_j sum_i Q_ij s_i (a column whose pi*theta is exactly 0 holds nothing, as in the reference)
+    red[col] = cmul ? (cmul[pc] == 0.0 ? 0.0 : cmul[pc] * t) : t;
+  }
 }
 
 __global__ void k_keep_err(const uint32_t* sync, uint32_t* errlog) { errlog[0] |= sync[9]; errlog[1] = sync[10]; }
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256) void k_update(UpdCtl C, int K, const double* _
     pi[j] = ph; theta[j] = th;
     if (C.pi_first) { C.pi_first[j] = ph; C.theta_first[j] = th; }
     const uint32_t cm = colmap[j];
-    const int pc = (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu), copies = 1 << ((cm >> 13) & 7u);
+    const int pc = (int)(cm >> CM_PS) * Kp + (int)(cm & CM_SM), copies = 1 << ((cm >> CM_LS) & 7u);
     const double cold = ctab[pc], cnew = ph * th;
     for (int c = 0; c < copies; ++c) { ctab_prev[pc + c] = cold; ctab[pc + c] = cnew; }
   }
@@ -317,9 +322,10 @@ __global__ void k_lnl_check(uint32_t* ctl, double* ctld, const double* __restric
   ctld[0] = l;
 }
 // lnl partial + error flag of this rank into the two lnl reduce slots
-__global__ void k_lnl_slots(const double* __restrict__ red_lnl, const uint32_t* __restrict__ sync, double* __restrict__ lred) {
+__global__ void k_lnl_slots(const double* __restrict__ red_lnl, const uint32_t* __restrict__ sync, double* __restrict__ lred,
+                            const uint32_t* __restrict__ errlog = nullptr /* split layout: error words of the earlier launches of the pass */) {
   lred[0] = *red_lnl;
-  lred[1] = (sync && sync[9]) ? 1.0 : 0.0;
+  lred[1] = ((sync && sync[9]) || (errlog && errlog[0])) ? 1.0 : 0.0;
 }
 
 static_assert(FZ_SYNC_WORDS == 16, "k_update clears 16 sync words");
@@ -416,13 +422,17 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
     if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * FZ_XS * h->P * h->R, h->stream));
   }
   h->fz_clean = false;
-  if (mode == 1) TSEM_HIP(hipMemsetAsync(h->d_lnl_part, 0, sizeof(double) * (size_t)h->fz_grid, h->stream));   // teams that do not form write nothing
+  if (mode == 1 || mode == 8)                              // teams that do not form write nothing
+    TSEM_HIP(hipMemsetAsync(h->d_lnl_part + (mode == 8 ? (size_t)bin * h->fz_grid : 0), 0, sizeof(double) * (size_t)h->fz_grid, h->stream));
   FusedArgs A;
   A.P = h->P; A.Kp = h->Kp; A.R = h->R; A.nb = h->nb; A.N_amb_pad = h->N_amb_pad;
   A.sb_off = h->d_sb_off; A.sb_q32 = h->d_sb_q32; A.pval = h->d_pval; A.prc = h->d_prc;
   const bool lnl = mode == 1;                               // modes 2, 3 (exact column sums) and 4 (+ the previous lnl) are EM passes
   A.ctab = lnl ? h->d_ctab_prev : h->d_ctab; A.ctab2 = mode == 4 ? h->d_ctab_prev : h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = lnl ? 1 : 0;
   A.rinv = h->d_rinv; A.lag = (mode == 4 && h->lag_valid) ? 1 : 0;
+  A.Kh = (h->Kp + 1) / 2; A.koff = 0;
+  if (mode == 5 && bin == 1) { A.ctab = h->d_ctab_prev; A.lnl_mode = 1; }           // split layout, lnl: unweighted recip0 of the PREVIOUS parameters' row sums
+  if (mode == 8) { A.ctab = h->d_ctab_prev; A.ctab2 = h->d_ctab; A.koff = bin * A.Kh; A.lnl_out = h->d_lnl_part + (size_t)bin * h->fz_grid; }
   A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg; A.sorted = h->sorted_layout ? 1 : 0;
   A.sync = h->d_xflags;
   A.prof = (mode == 0 || mode == 4) ? h->d_prof : nullptr; A.prof_blocks = A.prof ? h->prof_steps : 0; A.dbg = (int)h->opt_dbg;
@@ -431,7 +441,7 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
 
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
   const size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
-  if (lnl && h->fz_grid > 4096) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
+  if ((lnl || mode == 8) && h->fz_grid > 2048) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
   fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h), h->geo);
   if (!fn) TSEM_FAIL(TSEM_ERR_ARG, mode >= 2 ? "reproducible mode needs the fused kernel with a score table of at most 2048 entries"
                                                : "fused kernel supports at most 8 column parts");
@@ -474,8 +484,8 @@ static int em_pass_f32(tsem_ctx* h) {
 // Worst-case relative error of a column sum: (entries of the column) x 2^-(57 - BIN_SLACK); typically the fp64 rounding of S.
 constexpr int BIN_SLACK = 16;
 __device__ __forceinline__ int bin_slot(uint32_t cm, int Kp, int* copies) {
-  *copies = 1 << ((cm >> 13) & 7u);
-  return (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu);
+  *copies = 1 << ((cm >> CM_LS) & 7u);
+  return (int)(cm >> CM_PS) * Kp + (int)(cm & CM_SM);
 }
 __global__ void k_bin_check(int K, const double* __restrict__ red, const uint32_t* __restrict__ colmap, int Kp,
                             const unsigned long long* __restrict__ colcount, const uint32_t* __restrict__ ucount,
@@ -602,6 +612,24 @@ static int em_pass(tsem_ctx* h, bool lag) {
       nu = (int)std::min<int64_t>(2048, (h->N_uni + 255) / 256);
       k_lnl_unique<<<nu, 256, 0, h->stream>>>(h->N_uni, h->d_uni_col, h->d_uni_code, h->d_lut, h->d_pi_prev, h->d_pi, h->d_lnl_part + 4096);
       TSEM_HIP(hipGetLastError());
+    }
+    if (h->split) {
+      // two light passes, one LDS table each: the row factors w_i * recip0(rowsum_i) through HBM (8 B per row), then
+      // acc[j] += Q_ij s_i; k_colreduce multiplies by pi_j theta_j.  The error word of the first launch is kept by k_keep_err.
+      if (!h->d_fz_aux) {
+        TSEM_ALLOC(h->d_fz_aux, 4);
+        TSEM_HIP(hipMemsetAsync(h->d_fz_aux, 0, sizeof(uint32_t) * 4, h->stream));
+      }
+      if (int rc = launch_fused(h, 5, pair)) return rc;
+      if (int rc = launch_fused(h, 7, nullptr)) return rc;
+      if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
+      h->em_launches += 1;
+      k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
+                                                              h->d_xflags, h->P, h->d_ctl,
+                                                              reinterpret_cast<unsigned long long*>(h->d_xchg), (int64_t)h->fz_teams * FZ_XS * h->P * h->R,
+                                                              nullptr, nullptr, 0, h->d_ctab, h->d_fz_aux + 2);
+      TSEM_HIP(hipGetLastError());
+      return TSEM_OK;
     }
     if (int rc = launch_fused(h, lag ? 4 : 0, pair)) return rc;
     if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
@@ -759,7 +787,17 @@ int tsem_em_update(tsem_ctx* h, double* diff_est) {
 
 static int launch_lnl(tsem_ctx* h) {
   int na = 0, nu = 0;
-  if (h->nb > 0 && h->use_fused) {
+  if (h->nb > 0 && h->use_fused && h->split) {
+    // the previous parameters' row factors (unweighted) through HBM, then sum z log1p(Q c) over the two halves of every part's columns
+    if (!h->d_fz_aux) {
+      TSEM_ALLOC(h->d_fz_aux, 4);
+      TSEM_HIP(hipMemsetAsync(h->d_fz_aux, 0, sizeof(uint32_t) * 4, h->stream));
+    }
+    if (int rc = launch_fused(h, 5, nullptr, 1)) return rc;
+    if (int rc = launch_fused(h, 8, nullptr, 0)) return rc;
+    if (int rc = launch_fused(h, 8, nullptr, 1)) return rc;
+    na = 2 * h->fz_grid;
+  } else if (h->nb > 0 && h->use_fused) {
     if (int rc = launch_fused(h, 1, nullptr)) return rc;
     na = h->fz_grid;
   } else if (h->nb > 0) {
@@ -806,7 +844,8 @@ static int ensure_ctl(tsem_ctx* h) {
 // the lnl of the iteration just committed, all-reduced, into d_ctld[1] (value) / d_ctld[2] (error flag)
 static int enqueue_lnl_reduce(tsem_ctx* h) {
   if (int rc = launch_lnl(h)) return rc;
-  k_lnl_slots<<<1, 1, 0, h->stream>>>(h->d_red + h->K, (h->use_fused && h->nb > 0) ? h->d_xflags : nullptr, h->d_ctld + 1);
+  k_lnl_slots<<<1, 1, 0, h->stream>>>(h->d_red + h->K, (h->use_fused && h->nb > 0) ? h->d_xflags : nullptr, h->d_ctld + 1,
+                                      (h->split && h->use_fused && h->nb > 0) ? h->d_fz_aux + 2 : nullptr);
   TSEM_HIP(hipGetLastError());
   if (tsem_comm_on(h)) { if (int rc = tsem_comm_allreduce_dev(h->comm, h->d_ctld + 1, 2, 0, h->stream, h->err)) return rc; }
   return TSEM_OK;

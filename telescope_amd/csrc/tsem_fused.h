@@ -111,6 +111,15 @@ struct FusedArgs {
   // Q * c_t are this pass's numerators; c_{t-1} is a third table in LDS (ctab2); recip0(rowsum_t) was stored by pass t (rinv, one
   // double per row slot, written by member 0 of the team at the combine) and is staged through LDS a block ahead by the exchange wave.
   double* rinv;           // [N_amb_pad] read (rows of the blocks to come) and rewritten (rows just combined) by every MODE 4 pass
+  // SPLIT layout (round 4: parts of up to 15 424 columns, i.e. K up to 8 x 15 360 on the fused path; a part's pi*theta table AND its
+  // accumulators no longer fit the LDS together, so an iteration is two lighter passes with ONE table each):
+  //   MODE 5  row sums: c = pi*theta in LDS, phase 1 + the team exchange as in MODE 0; the combine's w_i * recip0(rowsum_i) goes to
+  //           rinv[row slot] (member 0 stores it; lnl_mode = 1: the unweighted recip0 of the PREVIOUS parameters' row sums)
+  //   MODE 7  scatter: the accumulators in LDS, no exchange (the exchange wave stages rinv through the s ring), acc[j] += Q_ij * s_i —
+  //           the column sum is pi_j theta_j * sum_i Q_ij s_i, the common factor is applied by k_colreduce
+  //   MODE 8  log-likelihood over ONE HALF of the part's columns (both tables of that half in LDS): sum z log1p(Q c_cur) with
+  //           z = Q c_prev * rinv; entries of the other half are skipped; two launches (koff = 0, Kh)
+  int Kh, koff;           // MODE 8: columns per half, first local column of this launch's half
   int lag;                // 0: rinv holds nothing yet (first pass of a run): the lnl partials of this launch are zero
   int dbg;              // bit0: skip partner loads (timing experiments only; wrong results)
                         // bit5 / bit6: behave like a hand-off time-out in the EM / lnl pass (tests of the recovery path)
@@ -251,6 +260,8 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   constexpr int FZ_RP = fz_rp(GEO);
   constexpr int FZ_YR = fz_yr(GEO);
   constexpr bool OWNREG = GEO == 3;                            // own partial sums travel in registers from publish to combine
+  constexpr bool SPA = MODE == 5;                              // split layout: row-sum pass (the row factors go to A.rinv)
+  constexpr bool SPS = MODE == 7 || MODE == 8;                 // split layout: no exchange, the s ring is staged from A.rinv
   constexpr int NPART = P > 1 ? P - 1 : 1;
   double* const y = X.y; double* const s = X.s; uint32_t* const offs = X.offs; uint32_t* const err = X.err;
   unsigned long long* const xbase = X.xbase;
@@ -286,7 +297,13 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     }
     const bool kv = k >= 0 && k < nblk;
     const uint64_t blk = kv ? (uint64_t)(team + k * T) : 0;
-    if (MODE != 1) {                                            // row weights (the lnl pass uses w = 1)
+    if (SPS) {                                                  // the row factors pass A left for block k
+      __amdgpu_buffer_rsrc_t rr = fz_rsrc(A.rinv, blk * R * 8, kv ? (unsigned)R * 8 : 0);
+#pragma unroll
+      for (int j = 0; j < FZ_RP; ++j)
+        g.rpv[j] = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(rr, (unsigned)(rlo + 2 * (lane + 64 * j)) * 8, 0, 0));
+    }
+    if (MODE != 1 && !SPS) {                                    // row weights (the lnl pass uses w = 1)
       if (FMT != 0) {
         __amdgpu_buffer_rsrc_t wr = fz_rsrc(A.wcode, blk * R * 2, kv ? (unsigned)R * 2 : 0);
 #pragma unroll
@@ -307,7 +324,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       for (int j = 0; j < FZ_RP; ++j)
         g.rpv[j] = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(rr, (unsigned)(rlo + 2 * (lane + 64 * j)) * 8, 0, 0));
     }
-    if (P > 1) {
+    if (P > 1 && !SPS) {
       // Validity lives in the DESCRIPTOR (an empty resource returns zeros), never in a per-lane select of the
       // offset: the compiler turned `ok ? offset : out-of-range` into two exec-masked loads with one destination
       // and put `s_waitcnt vmcnt(0)` between them — the exchange wave then sat behind the data waves' whole
@@ -333,6 +350,14 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   auto combine = [&](Gen& g, const Own& mine, int64_t k, int64_t ko) {
     if (offw && lane < 2 && ko >= 5 && ko < nblk) offs[(ko & 7) * 2 + lane] = g.off;   // blocks 0..4: prologue
     if (k < 0 || k >= nblk) return;
+    if (SPS) {                                            // nothing to combine: hand the stored row factors to the data waves
+#pragma unroll
+      for (int j = 0; j < FZ_RP; ++j) {
+        const int r = rlo + 2 * (lane + 64 * j);
+        if (r < rhi) *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = g.rpv[j];
+      }
+      return;
+    }
 #ifdef FZ_EXPERIMENT
     if (A.dbg & 2048) return;                             // timing experiment: no combine at all (s stays 0, members free-run)
 #endif
@@ -375,7 +400,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
           ys1 += __longlong_as_double((long long)v.y);
         }
         double2 w = make_double2(1.0, 1.0);
-        if (MODE != 1) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
+        if (MODE != 1 && !(SPA && A.lnl_mode)) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
         // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730).  (The exchange wave computes 4-6 of these IEEE
         // divisions per lane and step, on the critical path of a short-row step.  v_rcp_f64 + two fma-corrected Newton steps
         // instead: -3 % at 10 entries per row, -1.5 % at 40 with score codes when written without any special-case handling;
@@ -383,7 +408,14 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
         // short one — the gain is within the repeat spread, and it is not a correctly rounded quotient: not taken.
         // profiles/r03_exchange_bounds.txt section 7.)
         const double ri0 = recip0(ys0), ri1 = recip0(ys1);
-        *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(ri0 * w.x, ri1 * w.y);
+        if (!SPA) *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(ri0 * w.x, ri1 * w.y);
+        if (SPA && PP == 0) {                             // the scatter pass reads it back (every member computes the same bits: one stores)
+          __amdgpu_buffer_rsrc_t ro = fz_rsrc(A.rinv, (uint64_t)(team + k * T) * R * 8, (unsigned)R * 8);
+          const double f0 = ri0 * w.x, f1 = ri1 * w.y;
+          fz_u32x4 sv;
+          sv.x = (unsigned)__double2loint(f0); sv.y = (unsigned)__double2hiint(f0); sv.z = (unsigned)__double2loint(f1); sv.w = (unsigned)__double2hiint(f1);
+          __builtin_amdgcn_raw_buffer_store_b128(sv, ro, (unsigned)r * 8, 0, 0);
+        }
         if (MODE == 4 && PP == 0) {                       // what the NEXT pass needs of this one's E-step: one member stores it
           __amdgpu_buffer_rsrc_t ro = fz_rsrc(A.rinv, (uint64_t)(team + k * T) * R * 8, (unsigned)R * 8);
           fz_u32x4 sv;
@@ -426,6 +458,9 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     // publish y(i-1): tagged granules, 16-byte stores (a tear between halves is harmless).  PLAIN
     // stores: the line stays in the XCD's L2, where the partners' sc1 loads find it (a write-through
     // sc1 store drops it from L2: measured 14 M tag misses per pass vs 0.14 M)
+    if (SPS) {
+      // split layout, scatter / lnl pass: nothing to publish, the members of a team run free
+    } else
     if (OWNREG) {
       // geometry 3: read y(i-1) once — publish it, keep it for the combine three steps on, zero the slot now (it is
       // complete since the barrier that ended step i-1 and nobody else reads it; only the lanes that own a row pair zero
@@ -497,13 +532,15 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   constexpr int FZ_DT = fz_dt(GEO);
   constexpr int FZ_YR = fz_yr(GEO);
   const int Kp = A.Kp, R = A.R;
-  double* c = reinterpret_cast<double*>(smem);
-  double* acc = c + Kp;
   constexpr bool EXACT = MODE == 2 || MODE == 3;   // option "reproducible"
   constexpr bool LAG = MODE == 4;                  // EM pass + the log-likelihood of the previous iteration
+  constexpr bool SPA = MODE == 5, SPB = MODE == 7, SPL = MODE == 8;   // split layout (see FusedArgs): ONE table of Kp entries, or two of Kh
+  const int KT = SPL ? A.Kh : Kp;                  // entries per LDS table
+  double* c = reinterpret_cast<double*>(smem);
+  double* acc = (SPA || SPB) ? c : c + KT;         // (MODE 5 has no accumulators, MODE 7 no pi*theta table)
   double* const acc2 = acc + Kp;                   // MODE 3: the low pieces' accumulators [Kp];  MODE 4: pi*theta of the previous parameters
   double* const cprev = acc2;
-  double* y = acc + ((MODE == 3 || LAG) ? 2 : 1) * Kp;   // y[FZ_YR][R]  partial row sums (ring)
+  double* y = acc + ((MODE == 3 || LAG) ? 2 : 1) * KT;   // y[FZ_YR][R]  partial row sums (ring)
   double* s = y + FZ_YR * R;                       // s[2][R]      w_i / rowsum_i   (ring)
   double* const rpS = s + 2 * R;                   // MODE 4: rp[2][R]  1 / rowsum_i of the previous pass (ring)
   int* ibox = reinterpret_cast<int*>(s + (LAG ? 4 : 2) * R);   // [0]=ticket [1..8]=xcd counts
@@ -515,7 +552,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   // zeroed / tables loaded / loop start / loop end / exit, behind the per-step slots of team 0
   unsigned long long* const sprof = (A.prof && tid == 0) ? A.prof + 64 * FZ_PROF_SLOTS + (size_t)blockIdx.x * 8 : nullptr;
   if (sprof) sprof[0] = wall_clock64();
-  if (A.dbg & (MODE != 1 ? 32 : 64)) {                    // test hook: what a watchdog time-out leaves behind
+  if (A.dbg & ((MODE != 1 && MODE != 8) ? 32 : 64)) {     // test hook: what a watchdog time-out leaves behind
     if (blockIdx.x == 0 && tid == 0) atomicOr(err, 2u);
     return;
   }
@@ -531,7 +568,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
   if (tid == 0) ibox[0] = (int)__hip_atomic_fetch_add(&sync[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int t = tid; t < Kp; t += FZ_NT) acc[t] = 0.0;   // (lnl mode: overwritten with ctab2 below)
+  for (int t = tid; t < KT; t += FZ_NT) acc[t] = 0.0;   // (lnl mode: overwritten with ctab2 below)
   if (MODE == 3) for (int t = tid; t < Kp; t += FZ_NT) acc2[t] = 0.0;
   for (int t = tid; t < FZ_YR * R; t += FZ_NT) y[t] = 0.0;
   for (int t = tid; t < (LAG ? 4 : 2) * R; t += FZ_NT) s[t] = 0.0;
@@ -544,7 +581,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   uint16_t* const eS = reinterpret_cast<uint16_t*>(lutS + A.lut_len);   // MODE 2: [Kp] the slots' exponent bounds
   // MODE 1: [FZ_LOGTAB] (1 / c_i, log c_i) for fz_log1p_tab, in the same place (the two modes never share a launch)
   double2* const logtab = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(lutS + A.lut_len) + 15) & ~(uintptr_t)15);
-  if ((MODE == 1 || LAG) && tid < FZ_LOGTAB) {
+  if ((MODE == 1 || LAG || SPL) && tid < FZ_LOGTAB) {
     const double ci = 1.0 + (double)tid * (1.0 / FZ_LOGTAB);
     logtab[tid] = make_double2(1.0 / ci, ts_log1p_pos((double)tid * (1.0 / FZ_LOGTAB)));
   }
@@ -552,7 +589,15 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   if (sprof) sprof[2] = wall_clock64();
   const int ticket = __builtin_amdgcn_readfirstlane(ibox[0]);   // LDS broadcasts: tell the compiler they are uniform
   const int u = ticket / P, p = ticket % P;
-  for (int t = tid; t < Kp; t += FZ_NT) c[t] = A.ctab[p * Kp + t];
+  if (SPL) {                                               // one half of the part's columns: previous and current pi*theta
+    for (int t = tid; t < KT; t += FZ_NT) {
+      const bool in = A.koff + t < Kp;
+      c[t] = in ? A.ctab[p * Kp + A.koff + t] : 0.0;
+      acc[t] = in ? A.ctab2[p * Kp + A.koff + t] : 0.0;
+    }
+  } else if (!SPB) {
+    for (int t = tid; t < Kp; t += FZ_NT) c[t] = A.ctab[p * Kp + t];
+  }
   if (MODE == 1)
     for (int t = tid; t < Kp; t += FZ_NT) acc[t] = A.ctab2[p * Kp + t];
   if (LAG)
@@ -663,10 +708,11 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     // A lane whose quad is all zeros (past the end of the sub-block, or a step without a block) marks
     // itself idle in rc.x and skips both phases: zeros added to y[0] / acc[0] by every idle lane
     // would serialise on one LDS address.
-    constexpr bool lnl = MODE == 1;
+    constexpr bool lnl = MODE == 1 || SPL;
     auto phase1 = [&](FzRegs& rr, int64_t k) {
       const bool idle = FMT == 1 ? (rr.cd.x | rr.cd.y) == 0u
                                  : (rr.v0.x == 0.0) & (rr.v0.y == 0.0) & (rr.v1.x == 0.0) & (rr.v1.y == 0.0);
+      if (SPL) { if (idle) rr.rc.x = 0xFFFFFFFFu; return; }    // (the row factors come from pass A: nothing to sum)
       if (__builtin_amdgcn_ballot_w64(!idle) == 0) { rr.rc.x = 0xFFFFFFFFu; return; }   // whole wave idle
       double* yb = y + (k & (FZ_YR - 1)) * R;
       double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
@@ -697,6 +743,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       const double* sb = s + (k & 1) * R;
       if (lnl) {                                          // z = (Q c_prev) * recip0(rowsum);  acc[] holds c_cur
         auto term = [&](double q, uint32_t rc) {
+          if (SPL) {                                      // only the entries whose column lies in this launch's half
+            const uint32_t j = (rc & 0xFFFFu) - (uint32_t)A.koff;
+            if (j < (uint32_t)KT) {
+              const double z = (q * c[j]) * sb[rc >> 16];
+              if (z != 0.0) lsum += z * fz_log1p_tab(q * acc[j], logtab);
+            }
+            return;
+          }
           const double z = (q * c[rc & 0xFFFF]) * sb[rc >> 16];
           if (z != 0.0) lsum += z * fz_log1p_tab(q * acc[rc & 0xFFFF], logtab);
         };
@@ -773,7 +827,8 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       // — two LDS reads less per lane — was tried twice: with the select at the top (a second LDS round trip) 4.20 ->
       // 4.30 ms, with the select deferred to phase 2 3.57 -> 3.73 ms (codes) / 4.09 -> 4.19 ms: the ballot, the
       // compares and the selects cost more issue slots than the two broadcast reads they save.)
-      const double s0 = sb[a0 >> 16], s1 = sb[a1 >> 16], s2 = sb[a2 >> 16], s3 = sb[a3 >> 16];
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      if (!SPA) { s0 = sb[a0 >> 16]; s1 = sb[a1 >> 16]; s2 = sb[a2 >> 16]; s3 = sb[a3 >> 16]; }
       double2 q0 = rp.v0, q1 = rp.v1;
 #ifdef FZ_EXPERIMENT   // upper bounds (WRONG RESULTS): what conflict-free LDS accesses would buy, per kind of access
       const uint32_t xm_l = (A.dbg & 128) ? 3u : 0xFFFFu, xm_c = (A.dbg & 256) ? 31u : 0xFFFFu;
@@ -784,13 +839,16 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
         q0 = make_double2(lutS[rp.cd.x & xm_l], lutS[(rp.cd.x >> 16) & xm_l]);
         q1 = make_double2(lutS[rp.cd.y & xm_l], lutS[(rp.cd.y >> 16) & xm_l]);
       }
-      const double c0 = c[rp.rc.x & xm_c], c1 = c[rp.rc.y & xm_c], c2 = c[rp.rc.z & xm_c], c3 = c[rp.rc.w & xm_c];
+      double c0 = 1.0, c1 = 1.0, c2 = 1.0, c3 = 1.0;           // (MODE 7 scatters Q * s: the column's pi*theta is applied by k_colreduce)
+      if (!SPB) { c0 = c[rp.rc.x & xm_c]; c1 = c[rp.rc.y & xm_c]; c2 = c[rp.rc.z & xm_c]; c3 = c[rp.rc.w & xm_c]; }
       // ---- phase 1 of block i: numerators stay in the set, partial row sums into y(i) ----
       const double m0 = q0.x * c0, m1 = q0.y * c1, m2 = q1.x * c2, m3 = q1.y * c3;
       rp.v0 = make_double2(m0, m1); rp.v1 = make_double2(m2, m3);
       double* yb = y + (i & (FZ_YR - 1)) * R;
       if (pr) A.prof[i * FZ_PROF_SLOTS + 1] = clock64();
-      if (A.sorted) {
+      if (SPB) {
+        // no row sums in the scatter pass
+      } else if (A.sorted) {
         fz_row_sums(yb, idle, rp.rc.x >> 16, rp.rc.y >> 16, rp.rc.z >> 16, rp.rc.w >> 16, m0, m1, m2, m3);
       } else {                                            // strand-transposed order: neighbouring entries never share a row
         double* d = dum + lane_id;
@@ -802,7 +860,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase 2 of block i-LAG: w*z into the part's column accumulators; ALWAYS four atomics, issued last ----
-      {
+      if (!SPA) {
         const uint32_t dj = (uint32_t)(dum - acc) + (uint32_t)lane_id;   // the lane's dummy slot as an index into acc[]
 #ifdef FZ_EXPERIMENT
         const bool xa = (A.dbg & 512) != 0;                // every lane its own slot: no conflicts, no shared addresses
@@ -886,7 +944,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       load_blk(rs, oqa, oqb, i + FZ_DL);
       if (pr) A.prof[i * FZ_PROF_SLOTS + 2] = clock64();
       if (A.prof && team == 0 && p == 0 && tid == FZ_DT - 64 && (int)i < A.prof_blocks) A.prof[i * FZ_PROF_SLOTS + 8] = clock64();
-      __builtin_amdgcn_s_waitcnt(MODE == 3 ? 0xC87F : 0xC47F);   // lgkmcnt(4): everything but the four (MODE 3: eight) scatters above has completed
+      __builtin_amdgcn_s_waitcnt(MODE == 3 ? 0xC87F : (SPA ? 0xC07F : 0xC47F));   // lgkmcnt(4): everything but the four (MODE 3: eight; MODE 5: no) scatters above has completed
       oqa = __builtin_amdgcn_readfirstlane(on0); oqb = __builtin_amdgcn_readfirstlane(on1);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -895,7 +953,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       ++i;
     };
     auto step = [&](FzRegs& rs, FzRegs& rp) {
-      if (MODE == 1) step_lnl(rs, rp); else step_em(rs, rp);
+      if (MODE == 1 || SPL) step_lnl(rs, rp); else step_em(rs, rp);
     };
     load_blk(r0, offs[0], offs[1], 0);
     load_blk(r1, offs[2], offs[3], 1);
@@ -924,7 +982,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   }
   __syncthreads();
   if (sprof) sprof[5] = wall_clock64();
-  if (MODE == 1 || LAG) {                                 // one partial per workgroup, summed by k_sum_parts / k_colreduce
+  if (MODE == 1 || LAG || SPL) {                          // one partial per workgroup, summed by k_sum_parts / k_colreduce
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
     double* wsum = y;                                     // the y ring is idle now
     if ((tid & 63) == 0) wsum[tid >> 6] = lsum;
@@ -934,8 +992,9 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       for (int w = 0; w < FZ_NT / 64; ++w) t += wsum[w];
       A.lnl_out[team * P + p] = t;
     }
-    if (MODE == 1) return;
+    if (MODE == 1 || SPL) return;
   }
+  if (SPA) return;                                        // the row factors are in A.rinv; no column sums from this pass
 #ifdef FZ_EXPERIMENT
   if ((A.dbg & 4096) && A.prof && tid == 0) {             // per-member loop time (cycles) and blocks: prof[(team*P+p)*2 ..]
     A.prof[(team * P + p) * 2] = clock64() - fz_t0;

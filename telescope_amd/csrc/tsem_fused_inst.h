@@ -15,6 +15,18 @@ template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
     return nullptr;
 #endif
   }
+  if (mode == 5 || mode == 7 || mode == 8) {               // split layout (parts of more than 7680 columns): teams of 5-8 only
+#ifdef TSEM_NO_SPLIT
+    return nullptr;
+#else
+    if constexpr (P > 4 && (GEO == 1 || GEO == 2)) {
+      if (mode == 5) return fmt == 1 ? k_em_fused<P, 5, 1, GEO> : (fmt == 2 ? k_em_fused<P, 5, 2, GEO> : k_em_fused<P, 5, 0, GEO>);
+      if (mode == 7) return fmt == 1 ? k_em_fused<P, 7, 1, GEO> : (fmt == 2 ? k_em_fused<P, 7, 2, GEO> : k_em_fused<P, 7, 0, GEO>);
+      return fmt == 1 ? k_em_fused<P, 8, 1, GEO> : (fmt == 2 ? k_em_fused<P, 8, 2, GEO> : k_em_fused<P, 8, 0, GEO>);
+    }
+    return nullptr;
+#endif
+  }
   if (mode >= 2) {                                         // exact (binned) column sums: needs the score table in LDS (formats 1, 2)
 #ifdef TSEM_NO_REPRO
     return nullptr;

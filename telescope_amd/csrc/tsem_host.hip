@@ -168,6 +168,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "row_offset") h->row_offset = v;
   else if (k == "chunk_blocks") h->opt_chunk = v;
   else if (k == "fused_dbg") h->opt_dbg = v;
+  else if (k == "split") h->opt_split = v;
   else if (k == "value_format") h->opt_format = v;
   else if (k == "hot_split") h->opt_hot_split = v;
   else if (k == "geometry") h->opt_geo = v;
@@ -534,6 +535,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[17] = h->sorted_layout ? 1 : 0; info[18] = h->geo; info[19] = h->n_fallbacks;
   info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->bin_inexact ? 3 : (h->len_gt[5] ? 2 : 1)) : 0;     // 2: some row has more than 256 entries, see telescope_em.h
   info[22] = h->exact_single ? 1 : 0;                      // reproducible: both pieces in one pass
+  info[24] = h->split ? 1 : 0;                             // split layout: two light passes per iteration (K > 61 440)
   info[23] = h->lnl3 ? 1 : 0;                              // the layout lets the EM pass carry the previous iteration's log-likelihood (option "use_likelihood")
   return TSEM_OK;
 }

@@ -143,7 +143,8 @@ static inline bool fz_wants_codes(const tsem_ctx* h) {
   return h->opt_format != 1 && h->lut_len > 0 && h->lut_len <= 2048;
 }
 static inline size_t fz_lds_bytes(const tsem_ctx* h, bool codes) {
-  return (size_t)(((h->exact_single || h->lnl3) ? 3 : 2) * h->Kp + (fz_yr(h->geo) + (h->lnl3 ? 4 : 2)) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0) +
+  // (split layout: one table of Kp entries, or — the lnl pass — two of (Kp + 1) / 2)
+  return (size_t)((h->split ? h->Kp + 2 : ((h->exact_single || h->lnl3) ? 3 : 2) * h->Kp) + (fz_yr(h->geo) + (h->lnl3 ? 4 : 2)) * h->R) * 8 + 192 + 512 + (codes ? (size_t)h->lut_len * 8 : 0) +
          std::max<size_t>(h->opt_reproducible ? (size_t)h->Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16);   // (+ the slots' exponent table | the lnl pass's log table)
 }
 

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
         exact_split01(val, hi, lo);
         unsafeAtomicAdd(&A.colsums[(int64_t)m * A.K + grp_off + col], hi);
         if (lo != 0.0) unsafeAtomicAdd(&A.colsums_lo[(int64_t)m * A.K + grp_off + col], lo);
-      } else if (nhot1 && (int)(cm & 0x1FFFu) < A.Hs) lds_add(&hot[m * nhot1 + (cm >> 16) * A.Hs + (cm & 0x1FFFu)], val);
+      } else if (nhot1 && (int)(cm & CM_SM) < A.Hs) lds_add(&hot[m * nhot1 + (cm >> CM_PS) * A.Hs + (cm & CM_SM)], val);
       else unsafeAtomicAdd(&A.colsums[(int64_t)m * A.K + grp_off + col], val);
     };
     auto numer = [&](int64_t k) -> double {

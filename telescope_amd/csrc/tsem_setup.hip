@@ -198,8 +198,8 @@ __global__ __launch_bounds__(LM ? 1024 : 256) void k_row_partcounts(int64_t N_am
       uint32_t idv[E];
 #pragma unroll
       for (int j = 0; j < E; ++j) {
-        const uint32_t p = cm[j] >> 16;
-        idv[j] = (cm[j] & 0x1FFFu) * P + p;
+        const uint32_t p = cm[j] >> CM_PS;
+        idv[j] = (cm[j] & CM_SM) * P + p;
         if (k0 + j < len) {
           const unsigned long long one = 1ull << (16 * (p & 3));
           if (p < 4) lo += one; else hi += one;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_sb_count(int64_t N_amb, int R, int P, c
     int64_t i = amb_row[b * R + lr];                  // row slot -> CSR row, -1 = hole
     if (i < 0) continue;
     int64_t s = indptr[i], e = indptr[i + 1];
-    for (int64_t k = s + lane; k < e; k += RS_SUB) atomicAdd(&cnt[colmap[indices[k]] >> 16], 1u);
+    for (int64_t k = s + lane; k < e; k += RS_SUB) atomicAdd(&cnt[colmap[indices[k]] >> CM_PS], 1u);
   }
   __syncthreads();
   if (threadIdx.x < P) sb_cnt[b * P + threadIdx.x] = cnt[threadIdx.x];
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
     int64_t s = indptr[i], e = indptr[i + 1];
     for (int64_t k = s + lane; k < e; k += RS_SUB) {
       uint32_t cm = colmap[indices[k]];
-      uint32_t p = cm >> 16;
+      uint32_t p = cm >> CM_PS;
       // Entries of one row are handed consecutive tickets; writing ticket t of a
       // sub-block to slot (t % S) * L + t / S (S strands of L slots) puts them S..L
       // slots apart, so the lanes of one wave instruction hit different rows and the
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_sb_fill(int64_t N_amb, int R, int P, co
       int64_t pos = base + (int64_t)(t % TS_STRANDS) * L + t / TS_STRANDS;
       if (pcode) pcode[pos] = raw[k];
       else pval[pos] = lut[raw[k]];
-      prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
+      prc[pos] = ((uint32_t)lr << 16) | ((cm & CM_SM) + (t & ((1u << ((cm >> CM_LS) & 7u)) - 1u)));   // hot column: deal over its slots
     }
   }
 }
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
   } else {
     for (int lr = sub; lr < R; lr += subs) {
       const int64_t s0 = rstart[lr];
-      for (int k = lane; k < rlen[lr]; k += RS_SUB) atomicAdd(&cnt[lr * P + (colmap[indices[s0 + k]] >> 16)], 1u);
+      for (int k = lane; k < rlen[lr]; k += RS_SUB) atomicAdd(&cnt[lr * P + (colmap[indices[s0 + k]] >> CM_PS)], 1u);
     }
   }
   __syncthreads();
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
   const uint32_t below = (1u << lane) - 1u;
   // one step of 16 entries: column-map word cm of this lane's entry (0xFFFF.... part for lanes past the row's end), its score
   auto place = [&](int lr, uint32_t (&run)[8], bool valid, uint32_t cm, uint32_t code) {
-    const uint32_t p = valid ? cm >> 16 : 0xFFFFu;
+    const uint32_t p = valid ? cm >> CM_PS : 0xFFFFu;
     uint32_t t = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -451,13 +451,13 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
       const int64_t pos = sbase[p] + t;
       if (pcode) pcode[pos] = (uint16_t)code;
       else pval[pos] = lut[code];
-      prc[pos] = ((uint32_t)lr << 16) | ((cm & 0x1FFFu) + (t & ((1u << ((cm >> 13) & 7u)) - 1u)));   // hot column: deal over its slots
+      prc[pos] = ((uint32_t)lr << 16) | ((cm & CM_SM) + (t & ((1u << ((cm >> CM_LS) & 7u)) - 1u)));   // hot column: deal over its slots
     }
   };
   auto cm_of_id = [&](uint32_t id) -> uint32_t {           // the ids k_row_partcounts wrote: a coalesced 2-byte read instead of a gather
     const uint32_t slot = P == 1 ? id : __umulhi(id, magicP);   // id / P, exact for 16-bit ids and 2 <= P <= 8 (ceil(2^32 / 1) does not fit 32 bits)
     const uint32_t lg = (int)id < nsplit ? (uint32_t)lgtab[id] : 0u;
-    return ((id - slot * (uint32_t)P) << 16) | (lg << 13) | slot;
+    return ((id - slot * (uint32_t)P) << CM_PS) | (lg << CM_LS) | slot;
   };
   if (rid) {
     constexpr int PF = 4;                                  // steps of a row loaded ahead (64 entries)
@@ -587,7 +587,7 @@ __global__ void k_make_ctab(int K, const double* __restrict__ pi, const double* 
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= K) return;
   const uint32_t cm = colmap[j];
-  const int pc = (int)(cm >> 16) * Kp + (int)(cm & 0x1FFFu), copies = 1 << ((cm >> 13) & 7u);
+  const int pc = (int)(cm >> CM_PS) * Kp + (int)(cm & CM_SM), copies = 1 << ((cm >> CM_LS) & 7u);
   for (int c = 0; c < copies; ++c) ctab[pc + c] = pi[j] * theta[j];
 }
 
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void k_rid16_rows(int64_t N, const int64_t* __
   for (int64_t i = (int64_t)blockIdx.x * subs + sub; i < N; i += (int64_t)gridDim.x * subs) {
     const int64_t s = indptr[i], e = indptr[i + 1];
     if (only_short && e - s > 1) continue;                 // (the ambiguous rows were written by k_row_partcounts)
-    for (int64_t k = s + lane; k < e; k += RS_SUB) { const uint32_t cm = colmap[indices[k]]; rid[k] = (uint16_t)((cm & 0x1FFFu) * P + (cm >> 16)); }
+    for (int64_t k = s + lane; k < e; k += RS_SUB) { const uint32_t cm = colmap[indices[k]]; rid[k] = (uint16_t)((cm & CM_SM) * P + (cm >> CM_PS)); }
   }
 }
 
@@ -667,6 +667,23 @@ int tsem_choose_geometry(tsem_ctx* h) {
     const int max_kp = h->exact_single ? TS_MAX_KP3 - 64 : (h->lnl3 ? TS_MAX_KP_LNL - 64 : TS_MAX_KP);
     int P = h->opt_P > 0 ? (int)h->opt_P : (K + max_kp - 1) / max_kp;
     if (P < 1) P = 1;
+    // SPLIT layout (round 4): more columns than 8 parts of 7680 hold.  A part's pi*theta table and its accumulators then live in LDS
+    // one at a time — a row-sum pass and a scatter pass per iteration, every entry read twice — with parts of up to 15 360 columns:
+    // K <= 122 880 stays on the fused kernel (the two-pass kernels beyond; they took 7x the time per entry at K = 100k).  Teams of
+    // 5-8 only (the instantiations that exist); option "split" = 1 forces it on a smaller matrix (tests), 0 forbids it.
+    constexpr int SPLIT_MAX_KP = 2 * TS_MAX_KP;
+    h->split = false;
+    if (h->em_kernel != TSEM_EMK_TWOPASS && !h->opt_reproducible && h->opt_precision == 0 && na > 0 && h->opt_split != 0) {
+      const int p2 = std::max(5, (K + SPLIT_MAX_KP - 64 - 1) / (SPLIT_MAX_KP - 64));
+      if (h->opt_P > 0) {
+        const int kp = (K + P - 1) / P;
+        h->split = P >= 5 && P <= FZ_MAX_P && ((kp > TS_MAX_KP && kp <= SPLIT_MAX_KP) || h->opt_split == 1);
+      } else if ((P > FZ_MAX_P || h->opt_split == 1) && p2 <= FZ_MAX_P) {
+        P = std::max(p2, std::min(P, FZ_MAX_P));
+        h->split = true;
+      }
+      if (h->split) { h->lnl3 = false; h->exact_single = false; }
+    }
     if (h->opt_P <= 0 && h->em_kernel != TSEM_EMK_TWOPASS && P < FZ_MAX_P && na > 0) {
       // Teams never span XCDs, so floor(cpx / P) * P of an XCD's cpx CUs work: 28 of 32 for teams of 7.
       // One more member per team is worth it when it puts >= 10 % more CUs to work and the rows are
@@ -680,9 +697,9 @@ int tsem_choose_geometry(tsem_ctx* h) {
     }
     if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
     int Kp = (K + P - 1) / P;
-    if (Kp > TS_MAX_KP) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
+    if (Kp > (h->split ? SPLIT_MAX_KP : TS_MAX_KP)) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
     // spare accumulator slots per part for very popular columns (build_layout splits them)
-    h->hot_extra = h->opt_hot_split ? std::min(64, (h->exact_single ? TS_MAX_KP3 : (h->lnl3 ? TS_MAX_KP_LNL : TS_MAX_KP)) - Kp) : 0;
+    h->hot_extra = h->opt_hot_split ? std::min(64, (h->split ? SPLIT_MAX_KP : (h->exact_single ? TS_MAX_KP3 : (h->lnl3 ? TS_MAX_KP_LNL : TS_MAX_KP))) - Kp) : 0;
     Kp += h->hot_extra;
     h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
     h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
@@ -712,7 +729,7 @@ int tsem_choose_geometry(tsem_ctx* h) {
       if (h->opt_geo >= 0 && P > 4) h->geo = h->opt_geo == 2 ? 2 : 1;
       double r = 1.07 * fz_cap(h->geo) * P / std::max(2.0, mean_len);
       const int lut_bytes = (h->lut_len > 0 && h->lut_len <= 2048) ? h->lut_len * 8 : 0;   // the score table shares LDS with the rings
-      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - ((h->exact_single || h->lnl3) ? 3 : 2) * Kp * 8 - lut_bytes - std::max(h->opt_reproducible ? Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16)) / ((fz_yr(h->geo) + (h->lnl3 ? 4 : 2)) * 8));
+      int rmax = std::min(fz_rmax(h->geo), (TS_LDS_MAX - 2560 - (h->split ? Kp + 2 : ((h->exact_single || h->lnl3) ? 3 : 2) * Kp) * 8 - lut_bytes - std::max(h->opt_reproducible ? Kp * 2 + 16 : 0, FZ_LOGTAB * 16 + 16)) / ((fz_yr(h->geo) + (h->lnl3 ? 4 : 2)) * 8));
       rmax = std::min(rmax, FILL_MAX_RP / P);                // (k_sb_fill_sorted keeps R x P counters in LDS)
       R = (int)std::min<double>(r, rmax);
       R = std::max(64, (R + 63) / 64 * 64);
@@ -881,7 +898,7 @@ int tsem_build_layout(tsem_ctx* h) {
   std::vector<int> order(K);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return counts[a] > counts[b]; });
-  // colmap[j] = part << 16 | log2(copies) << 13 | first slot.  A column that holds a large share of its
+  // colmap[j] = part << CM_PS | log2(copies) << CM_LS | first slot (tsem_device.h).  A column that holds a large share of its
   // part's entries would serialise the LDS scatter (64 f lanes of every ds_add_f64 on ONE address:
   // the hottest column of a Zipf-like matrix, or Telescope's `__no_feature`, reaches 8-way), so it
   // gets 2..16 consecutive slots; k_sb_fill deals its entries over them, k_colreduce adds them up.
@@ -910,7 +927,7 @@ int tsem_build_layout(tsem_ctx* h) {
     while (lg < 4 && lanes / (1 << lg) > 1.5 && (2 << lg) - 1 <= spare[p]) ++lg;
     spare[p] -= (1 << lg) - 1;
     if (lg) h->n_hot_cols += 1;
-    colmap[j] = ((uint32_t)p << 16) | ((uint32_t)lg << 13) | (uint32_t)cursor[p];
+    colmap[j] = ((uint32_t)p << CM_PS) | ((uint32_t)lg << CM_LS) | (uint32_t)cursor[p];
     col_of_pc[p * Kp + cursor[p]] = j;                     // the first slot owns the column; the others stay -1
     cursor[p] += 1 << lg;
   }
@@ -1089,8 +1106,8 @@ int tsem_build_layout(tsem_ctx* h) {
     if (h->d_rid16 && P <= 8) {
       std::vector<uint8_t> lgt;
       for (int j = 0; j < K; ++j) {
-        const uint32_t cm = colmap[j], lg = (cm >> 13) & 7u;
-        if (lg) { const uint32_t id = (cm & 0x1FFFu) * P + (cm >> 16); if (id >= lgt.size()) lgt.resize(id + 1, 0); lgt[id] = (uint8_t)lg; }
+        const uint32_t cm = colmap[j], lg = (cm >> CM_LS) & 7u;
+        if (lg) { const uint32_t id = (cm & CM_SM) * P + (cm >> CM_PS); if (id >= lgt.size()) lgt.resize(id + 1, 0); lgt[id] = (uint8_t)lg; }
       }
       nsplit = (int)lgt.size();
       if (nsplit <= 4096) {
@@ -1150,6 +1167,15 @@ int tsem_build_layout(tsem_ctx* h) {
         TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
         k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);
       }
+      if (h->split) {                                      // row-sum pass, scatter pass, log-likelihood over a column half
+        for (int mode : {5, 7, 8}) {
+          fz_fn f = fz_kernel(P, mode, fz_fmt(h), h->geo);
+          if (!f) TSEM_FAIL(TSEM_ERR_ARG, "split layout: no fused kernel for this team size / geometry");
+          TSEM_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        }
+        TSEM_ALLOC(h->d_rinv, h->N_amb_pad);               // the row factors pass A hands to pass B
+        TSEM_HIP(hipMemsetAsync(h->d_rinv, 0, sizeof(double) * h->N_amb_pad, h->stream));
+      } else
       for (int mode = 0; mode < 2; ++mode)
         TSEM_HIP(hipFuncSetAttribute((const void*)fz_kernel(P, mode, fz_fmt(h), h->geo),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));

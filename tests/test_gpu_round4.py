@@ -247,3 +247,88 @@ def test_per_barcode_sums_at_config5_scale(gpu_device):
     assert np.array_equal(tiled, out)
     with pytest.raises(Exception):
         eng.set_groups(np.full(rows, n_groups, np.int32), n_groups)      # out of range: refused (checked on the device)
+
+
+# ---- the SPLIT layout: K beyond 8 x 7680 on the fused kernel ---------------------------------------------
+
+def _engine_with(raw, options):
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import score_lut
+    eng = _lib.Engine(0)
+    for k, v in options:
+        eng.set_option(k, v)
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), raw.shape[1], score_lut(int(raw.data.max())))
+    return eng
+
+
+@pytest.mark.parametrize('name', ['bundled', 'bundled_lnl', 'tiny_ties', 'tiny_twins', 'tiny_priors', 'tiny_empty_row', 'mid_zipf_20k', 'mid_uniform_200k'])
+@pytest.mark.parametrize('fmt,parts', [(0, 5), (1, 8)])
+def test_split_layout_forced_on_the_goldens(gpu_device, name, fmt, parts):
+    """Option `split` = 1 forces the two-pass-per-iteration form of the fused kernel (row factors through HBM, then
+    acc[j] += Q_ij s_i, pi_j theta_j applied by the column reduce; the log-likelihood over two halves of every part's columns)
+    on matrices that do not need it: the reference's iteration count, parameters, lnl and integer reassign outputs."""
+    import scipy.sparse as sp
+    from telescope_amd.likelihood import TelescopeLikelihood
+    c = load_case(name)
+    raw = case_matrix(c)
+    eng = _engine_with(raw, (('split', 1), ('parts', parts), ('value_format', fmt)))
+    tl = TelescopeLikelihood.from_engine(eng, Opts(c))
+    tl._raw = sp.csr_matrix(raw)
+    tl.em(use_likelihood=bool(c['use_likelihood']))
+    info = eng.layout_info()
+    if raw.shape[0] - int((np.diff(raw.indptr) <= 1).sum()) > 0:
+        assert info['split'] == 1 and info['fused'] == 1 and info['P'] == parts
+    assert tl.n_iter == int(c['n_iter']) and tl.converged == bool(c['converged'])
+    assert abs(tl.lnl - float(c['lnl'])) <= RTOL * abs(float(c['lnl']))
+    assert np.allclose(tl.pi, c['pi'], rtol=RTOL, atol=0) and np.allclose(tl.theta, c['theta'], rtol=RTOL, atol=0)
+    assert np.allclose(tl.pi_init, c['pi_init'], rtol=RTOL, atol=0)
+    if 'ra_exclude_0_colsum' in c:
+        assert np.array_equal(tl.reassign_colsums('exclude'), c['ra_exclude_0_colsum'])
+        assert np.allclose(tl.reassign_colsums('conf', 0.9), c['ra_conf_0_colsum'], rtol=RTOL, atol=1e-12)
+
+
+@pytest.mark.parametrize('rows,cols,d,fmt', [(200_000, 100_000, 100, 0), (200_000, 100_000, 100, 1), (300_000, 70_000, 30, 0),
+                                             (150_000, 122_000, 60, 0)])
+def test_large_K_runs_on_the_fused_kernel_and_matches_the_c_oracle(gpu_device, rows, cols, d, fmt):
+    """K > 61 440 (more than 8 parts of 7680 columns): the split layout keeps the fused kernel — parts of up to 15 360 columns, a
+    row-sum pass and a scatter pass per iteration — instead of the two-pass kernels.  pi, theta, pi_init and lnl to 1e-9 against
+    oracle/em_fused.c over the SAME matrix, the per-locus `exclude` counts bit for bit; use_likelihood (a log-likelihood per
+    iteration: three more launches each) ends in the same iteration with the same trace."""
+    from oracle import em_fused as oc
+    from telescope_amd._lib import Z_PREV
+    iters = 6
+    tl = _synthetic_tl(rows, cols, d, 'zipf', uniq=0.05, options=(('value_format', fmt),), opts=Opts(max_iter=iters, em_epsilon=0.0))
+    info = tl._eng.layout_info()
+    assert info['split'] == 1 and info['fused'] == 1 and 5 <= info['P'] <= 8 and info['Kp'] > 7680
+    tl.em()
+    ip, ix, rw = tl._eng.export_csr()
+    ref = oc.em_fused_arrays(ip, ix, rw, cols, 0, 200000, 0.0, iters)
+    assert ref['n_iter'] == tl.n_iter == iters
+    assert abs(tl.lnl - ref['lnl']) <= RTOL * abs(ref['lnl'])
+    assert np.allclose(tl.pi, ref['pi'], rtol=RTOL, atol=0) and np.allclose(tl.theta, ref['theta'], rtol=RTOL, atol=0)
+    assert np.allclose(tl.pi_init, ref['pi_init'], rtol=RTOL, atol=0)
+    pp, tp = tl._eng.get_params(Z_PREV)
+    conf, excl, avg = oc.report_sums(ip, ix, rw, cols, pp, tp, 0.9, False, max_score=tl.max_score)
+    assert np.array_equal(tl.reassign_colsums('exclude'), excl)
+    assert np.allclose(tl.reassign_colsums('conf', 0.9), conf, rtol=RTOL, atol=1e-9)
+    assert tl._eng.layout_info()['fallbacks'] == 0
+    tl2 = _synthetic_tl(rows, cols, d, 'zipf', uniq=0.05, options=(('value_format', fmt),), opts=Opts(max_iter=4, em_epsilon=0.0))
+    tl2.em(use_likelihood=True)
+    ref2 = oc.em_fused_arrays(ip, ix, rw, cols, 0, 200000, 0.0, 4, use_likelihood=True)
+    assert tl2.n_iter == ref2['n_iter'] and abs(tl2.lnl - ref2['lnl']) <= RTOL * abs(ref2['lnl'])
+
+
+def test_split_layout_time_out_falls_back_to_the_two_pass_kernels(gpu_device):
+    """A hand-off time-out of the row-sum pass (fused_dbg bit 5) or of the log-likelihood launches (bit 6) on the split layout:
+    nobody commits, the handle rebuilds for the two-pass kernels (which take any K up to 64 x 7680) and finishes with the same numbers."""
+    from telescope_amd.likelihood import TelescopeLikelihood
+    ref = _synthetic_tl(60_000, 70_000, 40, 'zipf', uniq=0.05, opts=Opts(max_iter=4, em_epsilon=0.0))
+    ref.em()
+    for bit in (32, 64):
+        tl = _synthetic_tl(60_000, 70_000, 40, 'zipf', uniq=0.05, options=(('fused_dbg', bit),), opts=Opts(max_iter=4, em_epsilon=0.0))
+        assert tl._eng.layout_info()['split'] == 1
+        tl.em()
+        info = tl._eng.layout_info()
+        assert info['fused'] == 0 and info['split'] == 0 and info['fallbacks'] == 1
+        assert tl.n_iter == ref.n_iter and abs(tl.lnl - ref.lnl) <= 1e-10 * abs(ref.lnl)
+        assert np.allclose(tl.pi, ref.pi, rtol=1e-10, atol=0)
