@@ -210,6 +210,26 @@ __global__ __launch_bounds__(256) void k_colreduce(int Kpad, int G, const double
   }
 }
 
+// split layout: rinv[slot] = [w_i *] recip0(sum of the members' partial row sums), members in order — the bits of the fused combine
+__global__ __launch_bounds__(256) void k_row_factors(int64_t n, int P, const double* __restrict__ ypart, const uint16_t* __restrict__ wcode,
+                                                    const double* __restrict__ wrow, const double* __restrict__ lut, int weighted,
+                                                    double* __restrict__ rinv, const uint32_t* __restrict__ ctl) {
+  if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the run has stopped
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;                   // two slots per thread (16-byte accesses; n is even)
+  if (i >= n) return;
+  double t0 = 0.0, t1 = 0.0;
+  for (int p = 0; p < P; ++p) {
+    const double2 v = *reinterpret_cast<const double2*>(ypart + (int64_t)p * n + i);
+    t0 += v.x; t1 += v.y;
+  }
+  double r0 = recip0(t0), r1 = recip0(t1);
+  if (weighted) {
+    if (wcode) { r0 *= lut[wcode[i]]; r1 *= lut[wcode[i + 1]]; }
+    else { r0 *= wrow[i]; r1 *= wrow[i + 1]; }
+  }
+  *reinterpret_cast<double2*>(rinv + i) = make_double2(r0, r1);
+}
+
 __global__ void k_keep_err(const uint32_t* sync, uint32_t* errlog) { errlog[0] |= sync[9]; errlog[1] = sync[10]; }
 
 // Loop control of tsem_em_chunk, evaluated on the device so that the host need not synchronise every
@@ -430,12 +450,12 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
   const bool lnl = mode == 1;                               // modes 2, 3 (exact column sums) and 4 (+ the previous lnl) are EM passes
   A.ctab = lnl ? h->d_ctab_prev : h->d_ctab; A.ctab2 = mode == 4 ? h->d_ctab_prev : h->d_ctab; A.lnl_out = h->d_lnl_part; A.lnl_mode = lnl ? 1 : 0;
   A.rinv = h->d_rinv; A.lag = (mode == 4 && h->lag_valid) ? 1 : 0;
-  A.Kh = (h->Kp + 1) / 2; A.koff = 0;
+  A.Kh = (h->Kp + 1) / 2; A.koff = 0; A.ypart = h->d_ypart;
   if (mode == 5 && bin == 1) { A.ctab = h->d_ctab_prev; A.lnl_mode = 1; }           // split layout, lnl: unweighted recip0 of the PREVIOUS parameters' row sums
   if (mode == 8) { A.ctab = h->d_ctab_prev; A.ctab2 = h->d_ctab; A.koff = bin * A.Kh; A.lnl_out = h->d_lnl_part + (size_t)bin * h->fz_grid; }
   A.wrow = h->d_amb_w; A.partial = h->d_fpartial; A.xchg = h->d_xchg; A.sorted = h->sorted_layout ? 1 : 0;
   A.sync = h->d_xflags;
-  A.prof = (mode == 0 || mode == 4) ? h->d_prof : nullptr; A.prof_blocks = A.prof ? h->prof_steps : 0; A.dbg = (int)h->opt_dbg;
+  A.prof = (mode == 0 || mode == 4 || mode == 5) ? h->d_prof : nullptr; A.prof_blocks = A.prof ? h->prof_steps : 0; A.dbg = (int)h->opt_dbg;
   A.ctl = h->d_ctl;
   A.ebias = h->d_ebias; A.bin = bin; A.ovf = h->d_ovf; A.partial2 = h->d_fpartial2;
 
@@ -449,6 +469,14 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
   fn<<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
   h->fused_launched = true;
+  return TSEM_OK;
+}
+
+static int launch_row_factors(tsem_ctx* h, int weighted) {
+  const bool codes = h->fmt_code || h->fmt_wcode;
+  k_row_factors<<<cdiv64(h->N_amb_pad / 2 + 1, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->P, h->d_ypart, codes ? h->d_amb_wcode : nullptr,
+                                                                          codes ? nullptr : h->d_amb_w, h->d_lut, weighted, h->d_rinv, h->d_ctl);
+  TSEM_HIP(hipGetLastError());
   return TSEM_OK;
 }
 
@@ -621,6 +649,7 @@ static int em_pass(tsem_ctx* h, bool lag) {
         TSEM_HIP(hipMemsetAsync(h->d_fz_aux, 0, sizeof(uint32_t) * 4, h->stream));
       }
       if (int rc = launch_fused(h, 5, pair)) return rc;
+      if (int rc = launch_row_factors(h, 1)) return rc;
       if (int rc = launch_fused(h, 7, nullptr)) return rc;
       if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
       h->em_launches += 1;
@@ -794,6 +823,7 @@ static int launch_lnl(tsem_ctx* h) {
       TSEM_HIP(hipMemsetAsync(h->d_fz_aux, 0, sizeof(uint32_t) * 4, h->stream));
     }
     if (int rc = launch_fused(h, 5, nullptr, 1)) return rc;
+    if (int rc = launch_row_factors(h, 0)) return rc;
     if (int rc = launch_fused(h, 8, nullptr, 0)) return rc;
     if (int rc = launch_fused(h, 8, nullptr, 1)) return rc;
     na = 2 * h->fz_grid;

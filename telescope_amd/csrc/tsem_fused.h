@@ -113,13 +113,17 @@ struct FusedArgs {
   double* rinv;           // [N_amb_pad] read (rows of the blocks to come) and rewritten (rows just combined) by every MODE 4 pass
   // SPLIT layout (round 4: parts of up to 15 424 columns, i.e. K up to 8 x 15 360 on the fused path; a part's pi*theta table AND its
   // accumulators no longer fit the LDS together, so an iteration is two lighter passes with ONE table each):
-  //   MODE 5  row sums: c = pi*theta in LDS, phase 1 + the team exchange as in MODE 0; the combine's w_i * recip0(rowsum_i) goes to
-  //           rinv[row slot] (member 0 stores it; lnl_mode = 1: the unweighted recip0 of the PREVIOUS parameters' row sums)
+  //   MODE 5  row sums: c = pi*theta in LDS, phase 1 only; NO exchange — every member writes its partial row sums to
+  //           ypart[member][row slot] (8 B per row and member) and runs free; k_row_factors then forms rinv[slot] = w_i *
+  //           recip0(sum over the members, in member order: the fused combine's bits).  (A first version kept the team exchange and
+  //           let member 0 store the factors: with nothing but phase 1 to hide it behind, the exchange round trip — 3400 clk at 768 row
+  //           slots — WAS the step: 1.50 ms for the pass at 10M x 100k x 40 where the scatter pass takes 0.49.)
   //   MODE 7  scatter: the accumulators in LDS, no exchange (the exchange wave stages rinv through the s ring), acc[j] += Q_ij * s_i —
   //           the column sum is pi_j theta_j * sum_i Q_ij s_i, the common factor is applied by k_colreduce
   //   MODE 8  log-likelihood over ONE HALF of the part's columns (both tables of that half in LDS): sum z log1p(Q c_cur) with
   //           z = Q c_prev * rinv; entries of the other half are skipped; two launches (koff = 0, Kh)
   int Kh, koff;           // MODE 8: columns per half, first local column of this launch's half
+  double* ypart;          // MODE 5: [P][N_amb_pad] partial row sums
   int lag;                // 0: rinv holds nothing yet (first pass of a run): the lnl partials of this launch are zero
   int dbg;              // bit0: skip partner loads (timing experiments only; wrong results)
                         // bit5 / bit6: behave like a hand-off time-out in the EM / lnl pass (tests of the recovery path)
@@ -260,8 +264,9 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   constexpr int FZ_RP = fz_rp(GEO);
   constexpr int FZ_YR = fz_yr(GEO);
   constexpr bool OWNREG = GEO == 3;                            // own partial sums travel in registers from publish to combine
-  constexpr bool SPA = MODE == 5;                              // split layout: row-sum pass (the row factors go to A.rinv)
+  constexpr bool SPA = MODE == 5;                              // split layout: row-sum pass (the partial sums go to A.ypart, no exchange)
   constexpr bool SPS = MODE == 7 || MODE == 8;                 // split layout: no exchange, the s ring is staged from A.rinv
+  constexpr bool NOX = SPA || SPS;
   constexpr int NPART = P > 1 ? P - 1 : 1;
   double* const y = X.y; double* const s = X.s; uint32_t* const offs = X.offs; uint32_t* const err = X.err;
   unsigned long long* const xbase = X.xbase;
@@ -303,7 +308,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       for (int j = 0; j < FZ_RP; ++j)
         g.rpv[j] = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(rr, (unsigned)(rlo + 2 * (lane + 64 * j)) * 8, 0, 0));
     }
-    if (MODE != 1 && !SPS) {                                    // row weights (the lnl pass uses w = 1)
+    if (MODE != 1 && !NOX) {                                    // row weights (the lnl pass uses w = 1)
       if (FMT != 0) {
         __amdgpu_buffer_rsrc_t wr = fz_rsrc(A.wcode, blk * R * 2, kv ? (unsigned)R * 2 : 0);
 #pragma unroll
@@ -324,7 +329,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       for (int j = 0; j < FZ_RP; ++j)
         g.rpv[j] = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(rr, (unsigned)(rlo + 2 * (lane + 64 * j)) * 8, 0, 0));
     }
-    if (P > 1 && !SPS) {
+    if (P > 1 && !NOX) {
       // Validity lives in the DESCRIPTOR (an empty resource returns zeros), never in a per-lane select of the
       // offset: the compiler turned `ok ? offset : out-of-range` into two exec-masked loads with one destination
       // and put `s_waitcnt vmcnt(0)` between them — the exchange wave then sat behind the data waves' whole
@@ -358,6 +363,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       }
       return;
     }
+    if (SPA) return;
 #ifdef FZ_EXPERIMENT
     if (A.dbg & 2048) return;                             // timing experiment: no combine at all (s stays 0, members free-run)
 #endif
@@ -400,7 +406,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
           ys1 += __longlong_as_double((long long)v.y);
         }
         double2 w = make_double2(1.0, 1.0);
-        if (MODE != 1 && !(SPA && A.lnl_mode)) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
+        if (MODE != 1) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
         // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730).  (The exchange wave computes 4-6 of these IEEE
         // divisions per lane and step, on the critical path of a short-row step.  v_rcp_f64 + two fma-corrected Newton steps
         // instead: -3 % at 10 entries per row, -1.5 % at 40 with score codes when written without any special-case handling;
@@ -408,14 +414,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
         // short one — the gain is within the repeat spread, and it is not a correctly rounded quotient: not taken.
         // profiles/r03_exchange_bounds.txt section 7.)
         const double ri0 = recip0(ys0), ri1 = recip0(ys1);
-        if (!SPA) *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(ri0 * w.x, ri1 * w.y);
-        if (SPA && PP == 0) {                             // the scatter pass reads it back (every member computes the same bits: one stores)
-          __amdgpu_buffer_rsrc_t ro = fz_rsrc(A.rinv, (uint64_t)(team + k * T) * R * 8, (unsigned)R * 8);
-          const double f0 = ri0 * w.x, f1 = ri1 * w.y;
-          fz_u32x4 sv;
-          sv.x = (unsigned)__double2loint(f0); sv.y = (unsigned)__double2hiint(f0); sv.z = (unsigned)__double2loint(f1); sv.w = (unsigned)__double2hiint(f1);
-          __builtin_amdgcn_raw_buffer_store_b128(sv, ro, (unsigned)r * 8, 0, 0);
-        }
+        *reinterpret_cast<double2*>(&s[(k & 1) * R + r]) = make_double2(ri0 * w.x, ri1 * w.y);
         if (MODE == 4 && PP == 0) {                       // what the NEXT pass needs of this one's E-step: one member stores it
           __amdgpu_buffer_rsrc_t ro = fz_rsrc(A.rinv, (uint64_t)(team + k * T) * R * 8, (unsigned)R * 8);
           fz_u32x4 sv;
@@ -460,6 +459,21 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
     // sc1 store drops it from L2: measured 14 M tag misses per pass vs 0.14 M)
     if (SPS) {
       // split layout, scatter / lnl pass: nothing to publish, the members of a team run free
+    } else if (SPA) {
+      // split layout, row-sum pass: y(i-1) goes to HBM as it is (k_row_factors sums the members), the slot is zeroed at once; only
+      // the lane that owns a row pair touches it (a clamped lane would read the slot after its owner zeroed it)
+      const int64_t kp = i - 1;
+      const bool pv = kp >= 0 && kp < nblk;
+      __amdgpu_buffer_rsrc_t ys = fz_rsrc(A.ypart, ((uint64_t)p * (uint64_t)A.N_amb_pad + (pv ? (uint64_t)(team + kp * T) : 0ull) * (uint64_t)R) * 8,
+                                          pv ? (unsigned)R * 8 : 0u);
+#pragma unroll
+      for (int j = 0; j < FZ_RP; ++j) {
+        const int r0 = rlo + 2 * (lane + 64 * j);
+        const int r = min(r0, R - 2);
+        const fz_u32x4 gq = *reinterpret_cast<const fz_u32x4*>(&y[(kp & (FZ_YR - 1)) * R + r]);
+        if (pv && r0 < rhi) *reinterpret_cast<double2*>(&y[(kp & (FZ_YR - 1)) * R + r]) = make_double2(0.0, 0.0);
+        __builtin_amdgcn_raw_buffer_store_b128(gq, ys, r0 < rhi ? (unsigned)r * 8 : FZ_OOB, 0, 0);
+      }
     } else
     if (OWNREG) {
       // geometry 3: read y(i-1) once — publish it, keep it for the combine three steps on, zero the slot now (it is

@@ -674,7 +674,7 @@ int tsem_choose_geometry(tsem_ctx* h) {
     constexpr int SPLIT_MAX_KP = 2 * TS_MAX_KP;
     h->split = false;
     if (h->em_kernel != TSEM_EMK_TWOPASS && !h->opt_reproducible && h->opt_precision == 0 && na > 0 && h->opt_split != 0) {
-      const int p2 = std::max(5, (K + SPLIT_MAX_KP - 64 - 1) / (SPLIT_MAX_KP - 64));
+      const int p2 = std::max(5, (K + SPLIT_MAX_KP - 1) / SPLIT_MAX_KP);       // (a part that needs every slot has no spare ones for hot columns)
       if (h->opt_P > 0) {
         const int kp = (K + P - 1) / P;
         h->split = P >= 5 && P <= FZ_MAX_P && ((kp > TS_MAX_KP && kp <= SPLIT_MAX_KP) || h->opt_split == 1);
@@ -1149,7 +1149,7 @@ int tsem_build_layout(tsem_ctx* h) {
   if (!h->use_fused) TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad);   // partial row sums of the two-pass kernels
   // launch geometry
   const size_t lds1 = (size_t)(Kp + R) * 8, lds2 = (size_t)(2 * Kp + R) * 8;
-  if (lds2 > (size_t)TS_LDS_MAX - 1024) TSEM_FAIL(TSEM_ERR_ARG, "LDS budget exceeded (reduce block_rows)");
+  if (lds2 > (size_t)TS_LDS_MAX - 1024 && !h->use_fused) TSEM_FAIL(TSEM_ERR_ARG, "LDS budget exceeded (reduce block_rows)");   // (the two-pass kernels' tables; the split layout has its own budget)
   int w1 = std::max(1, std::min(4, (int)(TS_LDS_MAX / lds1)));   // 512-thread WGs per CU
   int w2 = std::max(1, std::min(2, (int)(TS_LDS_MAX / lds2)));   // 1024-thread WGs per CU
   h->G1 = (int)std::max<int64_t>(1, std::min<int64_t>(nb, (int64_t)h->n_cu * w1 / P));
@@ -1174,6 +1174,7 @@ int tsem_build_layout(tsem_ctx* h) {
           TSEM_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
         }
         TSEM_ALLOC(h->d_rinv, h->N_amb_pad);               // the row factors pass A hands to pass B
+        TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad); // the members' partial row sums (row-sum pass -> k_row_factors)
         TSEM_HIP(hipMemsetAsync(h->d_rinv, 0, sizeof(double) * h->N_amb_pad, h->stream));
       } else
       for (int mode = 0; mode < 2; ++mode)

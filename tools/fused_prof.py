@@ -9,15 +9,18 @@ from telescope_amd.likelihood import TelescopeLikelihood
 class O: em_epsilon=0.0; max_iter=3; pi_prior=0; theta_prior=200000
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 nnz_row = 40
+cols = 30000
 eng = Engine(0)
 eng.set_option('em_kernel', 2)
 for kv in sys.argv[2:]:
     k, v = kv.split('=')
     if k == 'nnz_row':
         nnz_row = int(v)
+    elif k == 'cols':
+        cols = int(v)
     else:
         eng.set_option(k, int(v))
-eng.generate(0, rows, 30000, synthetic.poisson_cdf_u32(nnz_row), 42, 1, 0.0)
+eng.generate(0, rows, cols, synthetic.poisson_cdf_u32(nnz_row), 42, 1, 0.0)
 tl = TelescopeLikelihood.from_engine(eng, O())
 eng.em_steps(2, False)
 eng.set_option('fused_prof', 1)

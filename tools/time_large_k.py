@@ -50,6 +50,9 @@ def line(tag, rows, cols, d, options=()):
 
 if __name__ == '__main__':
     import numpy as np
+    if len(sys.argv) > 1 and sys.argv[1] == 'one':          # one configuration (for rocprofv3): one <rows> <cols> <per row> [value_format]
+        line('one', int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), (('value_format', int(sys.argv[5])),) if len(sys.argv) > 5 else ())
+        sys.exit(0)
     for rows, d in ((4_000_000, 100), (10_000_000, 40)):
         print('== %d rows x ~%d per row' % (rows, d))
         base, _, _ = line('K = 50k, fused (codes)', rows, 50_000, d)
