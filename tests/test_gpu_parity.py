@@ -331,10 +331,17 @@ def test_column_part_counts(gpu_device, cols, expect_parts):
 
 
 def test_more_than_eight_column_parts_use_the_two_pass_kernels(gpu_device):
-    """K = 70 000 -> 10 column parts: beyond the fused kernel's team size, the two-pass form runs."""
+    """K = 130 000 -> 17 column parts of 7680: beyond the fused kernel's teams of 8 AND beyond its split layout (8 x 15 360), the
+    two-pass form runs; K = 70 000 (round 3: two-pass) now stays on the fused kernel (split layout); option split = 0 gives the
+    round-3 behaviour."""
     from telescope_amd import synthetic
+    ip, ix, rw = synthetic.generate(30000, 130000, 30, seed=17, dist='zipf', uniq_frac=0.05)
+    info = _oracle_vs_gpu(sp.csr_matrix((rw, ix, ip), shape=(30000, 130000)))
+    assert info['P'] == 17 and info['fused'] == 0 and info['value_bytes'] == 8
     ip, ix, rw = synthetic.generate(30000, 70000, 30, seed=17, dist='zipf', uniq_frac=0.05)
     info = _oracle_vs_gpu(sp.csr_matrix((rw, ix, ip), shape=(30000, 70000)))
+    assert 5 <= info['P'] <= 8 and info['fused'] == 1 and info['split'] == 1
+    info = _oracle_vs_gpu(sp.csr_matrix((rw, ix, ip), shape=(30000, 70000)), options=(('split', 0),))
     assert info['P'] == 10 and info['fused'] == 0 and info['value_bytes'] == 8
 
 

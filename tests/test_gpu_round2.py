@@ -668,9 +668,13 @@ def test_report_pass_on_the_layouts_the_row_pass_branches_on(gpu_device):
     np.random.seed(3)
     want, _ = tl._eng.reassign('choose', 0.9, Z_USER, tl._dense_picks(tl._picks(Z_USER)))
     assert np.array_equal(a, np.rint(want).astype(np.int64))
-    big = _synthetic_tl(300_000, 70_000, 30, 'zipf', uniq=0.05)            # P = 10 column parts: two-pass layout
+    big = _synthetic_tl(300_000, 70_000, 30, 'zipf', uniq=0.05, options=(('split', 0),))   # P = 10 column parts: two-pass layout
     big.em()
     assert big._eng.layout_info()['P'] > 8
+    _check_report(big, (Z_PREV, Z_INITIAL))
+    big = _synthetic_tl(300_000, 70_000, 30, 'zipf', uniq=0.05)            # round 4: the same matrix on the split layout of the fused kernel
+    big.em()
+    assert big._eng.layout_info()['split'] == 1
     _check_report(big, (Z_PREV, Z_INITIAL))
 
 
