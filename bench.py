@@ -45,7 +45,7 @@ def parse():
     ap.add_argument('--rows', type=int, default=50_000_000)
     ap.add_argument('--cols', type=int, default=30_000)
     ap.add_argument('--nnz-row', type=float, default=40.0)
-    ap.add_argument('--dist', choices=('zipf', 'uniform'), default='zipf')
+    ap.add_argument('--dist', choices=('zipf', 'uniform', 'family'), default='zipf')
     ap.add_argument('--uniq-frac', type=float, default=0.0)
     ap.add_argument('--seed', type=int, default=42)
     ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong')

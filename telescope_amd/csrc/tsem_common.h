@@ -34,6 +34,8 @@
 #define TS_SALT_UNIQ 0x5BD1E9955BD1E995ull
 #define TS_SALT_COL0 0xC2B2AE3D27D4EB4Full
 #define TS_SALT_SCORE 0x165667B19E3779F9ull
+#define TS_SALT_FAM 0x27D4EB2F165667C5ull
+#define TS_FAMILY 256                 /* loci per family of the synthetic distribution 2 ('family', telescope_amd/synthetic.py) */
 
 __host__ __device__ inline uint64_t ts_mix64(uint64_t z) {
   z += TS_GOLDEN;
@@ -129,6 +131,7 @@ struct tsem_ctx {
   int64_t opt_lnl_fused = 0;        // option "use_likelihood" = 1: lay the matrix out so that the EM pass can sum the previous iteration's log-likelihood
                                     //    as well (fused kernel MODE 4: three tables per part in LDS, tsem_fused.h); tsem_em_chunk then needs no lnl pass per iteration
   bool lnl3 = false;                // the current layout allows it
+  int64_t n_single_part = 0;        // ambiguous rows with all their entries in one column part (layout statistic, tsem_layout_info[25])
   bool split = false;               // SPLIT layout (K > 8 x 7680 on the fused path): parts of up to 15 424 columns, one LDS table per pass — a row-sum pass and a
                                     // scatter pass per iteration (tsem_fused.h MODE 5 / 7), the log-likelihood over column halves (MODE 8)
   double* d_rinv = nullptr;         // [N_amb_pad] recip0(row sum) of the last MODE 4 pass (what the next one needs of its E-step)

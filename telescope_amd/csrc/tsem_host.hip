@@ -54,13 +54,23 @@ __global__ void k_gen_rows(int64_t row_begin, int64_t n, int32_t K, uint64_t see
   int len = (int)(indptr[t + 1] - s);
   int32_t cols[256];
   bool has0 = (uint32_t)(ts_hash3(seed ^ TS_SALT_COL0, row, 0) >> 32) < 214748364u;  // int(0.05*2^32)
+  int32_t fam = 0;
+  if (dist == 2) {
+    const double v = (double)(ts_hash3(seed ^ TS_SALT_FAM, row, 0) >> 11) * (1.0 / 9007199254740992.0);
+    fam = (int32_t)floor(__dmul_rn((double)((K - 1) / TS_FAMILY), __dmul_rn(__dmul_rn(v, v), v)));
+  }
   for (int k = 0; k < len; ++k) {
     if (k == 0 && has0) { cols[0] = 0; continue; }
     for (int attempt = 0;; ++attempt) {
       uint64_t h = ts_hash3(seed, row, (uint64_t)(k + 256 * attempt));
       double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
-      if (dist == 1) u = __dmul_rn(__dmul_rn(u, u), u);
-      int32_t cand = 1 + (int32_t)floor(__dmul_rn((double)(K - 1), u));
+      int32_t cand;
+      if (dist == 2) {                                     // 'family': every column of the row inside the row's family of TS_FAMILY loci
+        cand = 1 + TS_FAMILY * fam + (int32_t)floor(__dmul_rn((double)TS_FAMILY, u));
+      } else {
+        if (dist == 1) u = __dmul_rn(__dmul_rn(u, u), u);
+        cand = 1 + (int32_t)floor(__dmul_rn((double)(K - 1), u));
+      }
       bool dup = false;
       for (int q = 0; q < k; ++q) dup |= (cols[q] == cand);
       if (!dup) { cols[k] = cand; break; }
@@ -295,6 +305,7 @@ int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_col
   int64_t n = row_end - row_begin;
   if (n < 0 || n_cols < 2 || !len_cdf || cdf_len <= 0) TSEM_FAIL(TSEM_ERR_ARG, "bad generator arguments");
   if (n >= (int64_t)INT32_MAX) TSEM_FAIL(TSEM_ERR_ARG, "more than 2^31-1 rows per rank is not supported");
+  if (dist < 0 || dist > 2 || (dist == 2 && n_cols <= TS_FAMILY)) TSEM_FAIL(TSEM_ERR_ARG, "dist: 0 uniform, 1 zipf, 2 family (more than 256 columns)");
   tsem_free_matrix(h);
   h->N = n; h->K = n_cols;
   uint32_t* d_cdf = nullptr;
@@ -535,6 +546,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[17] = h->sorted_layout ? 1 : 0; info[18] = h->geo; info[19] = h->n_fallbacks;
   info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->bin_inexact ? 3 : (h->len_gt[5] ? 2 : 1)) : 0;     // 2: some row has more than 256 entries, see telescope_em.h
   info[22] = h->exact_single ? 1 : 0;                      // reproducible: both pieces in one pass
+  info[25] = h->n_single_part;                             // ambiguous rows whose entries all lie in ONE column part (they would need no exchange)
   info[24] = h->split ? 1 : 0;                             // split layout: two light passes per iteration (K > 61 440)
   info[23] = h->lnl3 ? 1 : 0;                              // the layout lets the EM pass carry the previous iteration's log-likelihood (option "use_likelihood")
   return TSEM_OK;

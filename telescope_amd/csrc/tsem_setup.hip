@@ -302,6 +302,19 @@ __global__ __launch_bounds__(64) void k_sb_count_pc(int64_t nb, int P, const int
     if (threadIdx.x == 0 && q < P) sb_cnt[b * P + q] = t;
   }
 }
+// layout statistic: ambiguous rows whose entries all fall into ONE column part (such a row's normaliser needs no exchange)
+__global__ __launch_bounds__(256) void k_single_part_rows(int64_t na, const unsigned long long* __restrict__ pc, unsigned long long* __restrict__ out) {
+  unsigned n = 0;
+  for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < na; a += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long lo = pc[2 * a], hi = pc[2 * a + 1];
+    int parts = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) parts += (((q < 4 ? lo : hi) >> (16 * (q & 3))) & 0xFFFF) != 0;
+    n += parts == 1;
+  }
+  const int t = sg_sum_i<64>((int)n);
+  if ((threadIdx.x & 63) == 0 && t) atomicAdd(out, (unsigned long long)t);
+}
 __global__ void k_fixed_blocks(int64_t nb, int R, int64_t na, int64_t* __restrict__ bstart) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b <= nb) bstart[b] = min(na, b * R);
@@ -891,6 +904,7 @@ int tsem_build_layout(tsem_ctx* h) {
   const int64_t na = h->N_amb;
   tsem_free_layout(h);
   h->nnz_amb = 0;
+  h->n_single_part = 0;
   // 1. column popularity: global entry counts handed in by set_model
   const std::vector<uint64_t>& counts = h->col_count;
   // 2. parts: deal columns by popularity so every part carries ~equal nnz
@@ -976,6 +990,16 @@ int tsem_build_layout(tsem_ctx* h) {
     }
     TSEM_HIP(hipGetLastError());
     rid_amb_done = true;
+    {
+      DevTmp t_sp;
+      TSEM_TMP(t_sp, 8);
+      TSEM_HIP(hipMemsetAsync(t_sp.p, 0, 8, h->stream));
+      k_single_part_rows<<<(unsigned)std::min<int64_t>(4096, (na + 255) / 256), 256, 0, h->stream>>>(na, d_pc, t_sp.as<unsigned long long>());
+      unsigned long long nsp = 0;
+      TSEM_HIP(hipMemcpyAsync(&nsp, t_sp.p, 8, hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      h->n_single_part = (int64_t)nsp;
+    }
     const int cap = fz_cap(h->geo) - TS_STRANDS * 4;          // sub-blocks are padded to TS_STRANDS*4 entries
     // chunk length: >= 64 blocks' worth of rows (the forced break at a chunk end costs ~0.8 % more blocks; round 2 used 256 blocks' worth,
     // 484 sequential waves for 47M rows: 2 x 2.5 ms; four times as many waves walk a quarter each)

@@ -13,6 +13,9 @@ Row i of the global matrix:
   * the other slots draw columns from [1, K) without replacement: slot k,
     attempt a uses u = hash(seed, i, k + 256*a); 'uniform': j = 1+floor((K-1)u),
     'zipf': j = 1+floor((K-1)*u*u*u) (hot-locus skew); a duplicate bumps a;
+    'family' (round 4: what multi-mapping inside repeat families looks like): the columns 1 .. are cut into families of FAMILY
+    consecutive loci; row i belongs to family f_i = floor(nfam * v^3), v = hash(seed ^ SALT_FAM, i, 0) (hot families), and draws
+    all its columns inside it, j = 1 + FAMILY*f_i + floor(FAMILY*u) (columns past the last whole family stay empty);
   * columns are then sorted ascending (canonical CSR);
   * the raw score of sorted position p is 139 + hash(seed^SALT, i, p) % 162,
     i.e. uniform on [139, 300] like the bundled data's range with max AS 300.
@@ -29,9 +32,11 @@ SALT_LEN = np.uint64(0xA5A5A5A5A5A5A5A5)
 SALT_UNIQ = np.uint64(0x5BD1E9955BD1E995)
 SALT_COL0 = np.uint64(0xC2B2AE3D27D4EB4F)
 SALT_SCORE = np.uint64(0x165667B19E3779F9)
+SALT_FAM = np.uint64(0x27D4EB2F165667C5)
+FAMILY = 256               # loci per family of dist 'family' (> MAX_ROW_LEN: a row always fits its family)
 SCORE_LO, SCORE_SPAN = 139, 162
 MAX_ROW_LEN = 255          # slots per row are capped (k + 256*a addressing)
-DIST_CODE = {'uniform': 0, 'zipf': 1}
+DIST_CODE = {'uniform': 0, 'zipf': 1, 'family': 2}
 
 
 def mix64(z):
@@ -80,6 +85,13 @@ def row_lengths(seed, rows, mean_nnz, n_cols, uniq_frac=0.0, cdf=None):
 def _draw(seed, rows, slot, n_cols, dist):
     h = hash3(seed, rows, slot)
     u = (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    if dist == 'family':
+        nfam = (n_cols - 1) // FAMILY
+        if nfam < 1:
+            raise ValueError("dist='family' needs more than %d columns" % FAMILY)
+        v = (hash3(np.uint64(seed) ^ SALT_FAM, rows, 0) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        f = np.floor(nfam * ((v * v) * v)).astype(np.int64)
+        return 1 + FAMILY * f + np.floor(FAMILY * u).astype(np.int64)
     if dist == 'zipf':
         u = (u * u) * u
     return 1 + np.floor((n_cols - 1) * u).astype(np.int64)

@@ -189,7 +189,7 @@ def test_csr_matrix_plus_primitives(gpu_device):
     assert np.array_equal(_lib.csr_binmax_rows(m.indptr, m.data, 3), [1, 0, 1, 0, 0, 1])
 
 
-@pytest.mark.parametrize('dist,uniq', [('uniform', 0.0), ('zipf', 0.1)])
+@pytest.mark.parametrize('dist,uniq', [('uniform', 0.0), ('zipf', 0.1), ('family', 0.05)])
 def test_device_generator_is_bit_exact(gpu_device, dist, uniq):
     from telescope_amd import _lib, synthetic
     n, k, d = 20000, 3000, 20

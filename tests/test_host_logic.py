@@ -180,3 +180,21 @@ def test_every_translation_unit_is_built():
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'telescope_amd', 'csrc')
     on_disk = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(csrc, '*.hip')))
     assert on_disk == sorted(list(_lib.LIB_UNITS) + list(_lib.FZ_UNITS))
+
+
+def test_family_distribution_keeps_a_row_inside_one_family():
+    """dist='family' (telescope_amd/synthetic.py): every row draws its columns inside ONE family of 256 consecutive loci (plus
+    column 0 in ~5 % of the rows), sorted, without duplicates; hot families exist (cubic skew)."""
+    from telescope_amd import synthetic
+    ip, ix, rw = synthetic.generate(4000, 3000, 20, seed=7, dist='family', uniq_frac=0.05)
+    fam_rows = {}
+    for i in range(4000):
+        c = ix[ip[i]:ip[i + 1]]
+        assert np.all(np.diff(c) > 0)
+        c = c[c > 0]
+        if len(c):
+            f = (c - 1) // synthetic.FAMILY
+            assert f.min() == f.max() < (3000 - 1) // synthetic.FAMILY
+            fam_rows[int(f[0])] = fam_rows.get(int(f[0]), 0) + 1
+    assert len(fam_rows) == (3000 - 1) // synthetic.FAMILY and fam_rows[0] > 3 * fam_rows[max(fam_rows)]
+    assert rw.min() >= 139 and rw.max() <= 300
