@@ -322,7 +322,7 @@ int  tsem_csr_scale(int device, int mode, int64_t n_rows, int32_t n_cols, const 
  * algorithmic bytes one EM pass reads.  */
 int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launches,
                        int64_t* algo_bytes_per_pass);
-int  tsem_layout_info(tsem_ctx* h, int64_t* info32 /* 26 values written */);
+int  tsem_layout_info(tsem_ctx* h, int64_t* info32 /* 27 values written */);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
 /* the same option's start-up timeline: per workgroup b (up to 512), out[8 b ..] = 100 MHz wall clock at entry / tickets counted /

@@ -131,6 +131,8 @@ struct tsem_ctx {
   int64_t opt_lnl_fused = 0;        // option "use_likelihood" = 1: lay the matrix out so that the EM pass can sum the previous iteration's log-likelihood
                                     //    as well (fused kernel MODE 4: three tables per part in LDS, tsem_fused.h); tsem_em_chunk then needs no lnl pass per iteration
   bool lnl3 = false;                // the current layout allows it
+  bool em_rows = false;             // K beyond 64 x 7680 columns: no blocked layout at all, the EM pass and the log-likelihood are plain CSR row passes
+                                    // with global gathers and fp64 atomics (any K; slow: a completeness path, tsem_em.hip k_em_rows)
   int64_t n_single_part = 0;        // ambiguous rows with all their entries in one column part (layout statistic, tsem_layout_info[25])
   bool split = false;               // SPLIT layout (K > 8 x 7680 on the fused path): parts of up to 15 424 columns, one LDS table per pass — a row-sum pass and a
                                     // scatter pass per iteration (tsem_fused.h MODE 5 / 7), the log-likelihood over column halves (MODE 8)

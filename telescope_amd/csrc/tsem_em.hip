@@ -392,6 +392,50 @@ __global__ __launch_bounds__(256) void k_em_rows_f32(int64_t N, const int64_t* _
     }
   }
 }
+// Any K (more than 64 column parts): the EM pass as a plain CSR row pass — 16 lanes per row, pi*theta gathered from global memory,
+// w*z added to the column sums with global fp64 atomics.  A completeness path (the reference takes any number of loci), an
+// order of magnitude slower per entry than the fused kernel.  red[0..K) must be zero; unique rows feed pi through pisum0 only.
+__global__ __launch_bounds__(256) void k_em_rows(int64_t N, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const uint16_t* __restrict__ raw, const double* __restrict__ lut, const double* __restrict__ c, double* __restrict__ red,
+    const uint32_t* __restrict__ ctl) {
+  if (ctl && __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the run has stopped
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
+    const int64_t s = indptr[row], e = indptr[row + 1];
+    if (e - s < 2) continue;
+    double y = 0.0, w = 0.0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) { const double q = lut[raw[k]]; y += q * c[indices[k]]; w = fmax(w, q); }
+    y = sg_sum<RP_SUB>(y); w = sg_max<RP_SUB>(w);
+    const double r = recip0(y) * w;                         // sparse_plus.py:16-22, model.py:730
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      const double v = (lut[raw[k]] * c[indices[k]]) * r;
+      if (v != 0.0) unsafeAtomicAdd(&red[indices[k]], v);
+    }
+  }
+}
+// ... and calculate_lnl's ambiguous rows (model.py:744-760): sum z(prev) log1p(Q c_cur), one partial per workgroup
+__global__ __launch_bounds__(256) void k_lnl_rows_amb(int64_t N, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const uint16_t* __restrict__ raw, const double* __restrict__ lut, const double* __restrict__ c_prev, const double* __restrict__ c_cur,
+    double* __restrict__ part) {
+  __shared__ double scratch[16];
+  const int sub = threadIdx.x / RP_SUB, lane = threadIdx.x % RP_SUB, subs = blockDim.x / RP_SUB;
+  double acc = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * subs + sub; row < N; row += (int64_t)gridDim.x * subs) {
+    const int64_t s = indptr[row], e = indptr[row + 1];
+    if (e - s < 2) continue;
+    double y = 0.0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) y += lut[raw[k]] * c_prev[indices[k]];
+    y = sg_sum<RP_SUB>(y);
+    const double r = recip0(y);
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      const double q = lut[raw[k]];
+      const double z = (q * c_prev[indices[k]]) * r;
+      if (z != 0.0) acc += z * ts_log1p_pos(q * c_cur[indices[k]]);
+    }
+  }
+  const double t = block_sum(acc, scratch);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
 __global__ void k_red_from_f32(int K, const float* __restrict__ colsums, double* __restrict__ red) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < K) red[j] = ldexp((double)colsums[j], F32_SHIFT);
@@ -584,6 +628,15 @@ static int em_pass(tsem_ctx* h, bool lag) {
   if (h->opt_precision == 1) return em_pass_f32(h);
   hipEvent_t* pair = nullptr;
   if (int rc = begin_timing(h, &pair)) return rc;
+  if (h->em_rows) {
+    // K beyond 64 column parts: the identity column map makes d_ctab pi*theta in column order
+    TSEM_HIP(hipMemsetAsync(h->d_red, 0, sizeof(double) * (h->K + 2), h->stream));
+    if (h->N) k_em_rows<<<tsem_rowpass_grid(h), 256, 0, h->stream>>>(h->N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, h->d_ctab, h->d_red, h->d_ctl);
+    TSEM_HIP(hipGetLastError());
+    if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
+    h->em_launches += 1;
+    return TSEM_OK;
+  }
   if (h->nb > 0 && h->use_fused && h->opt_reproducible) {
     // two exact passes (high and low pieces of every contribution); the high pass is repeated while a column's bound has to move:
     // the first iteration of a run takes a few repeats (the bounds start at the largest fragment weight), later ones rarely any
@@ -816,7 +869,11 @@ int tsem_em_update(tsem_ctx* h, double* diff_est) {
 
 static int launch_lnl(tsem_ctx* h) {
   int na = 0, nu = 0;
-  if (h->nb > 0 && h->use_fused && h->split) {
+  if (h->em_rows) {
+    na = h->N ? std::min(2048, tsem_rowpass_grid(h)) : 0;
+    if (na) k_lnl_rows_amb<<<na, 256, 0, h->stream>>>(h->N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, h->d_ctab_prev, h->d_ctab, h->d_lnl_part);
+    TSEM_HIP(hipGetLastError());
+  } else if (h->nb > 0 && h->use_fused && h->split) {
     // the previous parameters' row factors (unweighted) through HBM, then sum z log1p(Q c) over the two halves of every part's columns
     if (!h->d_fz_aux) {
       TSEM_ALLOC(h->d_fz_aux, 4);

@@ -546,6 +546,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[17] = h->sorted_layout ? 1 : 0; info[18] = h->geo; info[19] = h->n_fallbacks;
   info[20] = h->n_bin_repeats; info[21] = h->opt_reproducible ? (h->bin_inexact ? 3 : (h->len_gt[5] ? 2 : 1)) : 0;     // 2: some row has more than 256 entries, see telescope_em.h
   info[22] = h->exact_single ? 1 : 0;                      // reproducible: both pieces in one pass
+  info[26] = h->em_rows ? 1 : 0;                           // K beyond 64 column parts: plain CSR row passes (no blocked layout)
   info[25] = h->n_single_part;                             // ambiguous rows whose entries all lie in ONE column part (they would need no exchange)
   info[24] = h->split ? 1 : 0;                             // split layout: two light passes per iteration (K > 61 440)
   info[23] = h->lnl3 ? 1 : 0;                              // the layout lets the EM pass carry the previous iteration's log-likelihood (option "use_likelihood")

@@ -708,14 +708,20 @@ int tsem_choose_geometry(tsem_ctx* h) {
       for (int p2 = P + 1; p2 <= FZ_MAX_P; ++p2)
         if (util(p2) >= util(P) + 0.10 && mean_len * fz_rmax(2) >= 1.05 * fz_cap(1) * p2) { P = p2; break; }
     }
-    if (P > 64) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
-    int Kp = (K + P - 1) / P;
+    // more than 64 column parts (K > 491 520): no blocked layout — the reference takes any number of loci (model.py:643), so the
+    // EM pass and the log-likelihood fall back to plain CSR row passes (global gathers of pi*theta, fp64 atomics on the column
+    // sums: k_em_rows / k_lnl_rows_amb).  The column map is the identity cut into virtual parts, which is all k_update needs.
+    h->em_rows = P > 64 && h->opt_P <= 0;
+    if (P > 64 && !h->em_rows) TSEM_FAIL(TSEM_ERR_ARG, "more than 64 column parts (K > 491520) is not supported");
+    if (h->em_rows) { h->split = false; h->lnl3 = false; h->exact_single = false; }
+    if (h->em_rows && h->opt_reproducible) TSEM_FAIL(TSEM_ERR_ARG, "reproducible mode needs the fused kernel (K <= 61440)");
+    int Kp = h->em_rows ? TS_MAX_KP : (K + P - 1) / P;
     if (Kp > (h->split ? SPLIT_MAX_KP : TS_MAX_KP)) TSEM_FAIL(TSEM_ERR_ARG, "parts option leaves more than 7680 columns per part");
     // spare accumulator slots per part for very popular columns (build_layout splits them)
-    h->hot_extra = h->opt_hot_split ? std::min(64, (h->split ? SPLIT_MAX_KP : (h->exact_single ? TS_MAX_KP3 : (h->lnl3 ? TS_MAX_KP_LNL : TS_MAX_KP))) - Kp) : 0;
+    h->hot_extra = (h->opt_hot_split && !h->em_rows) ? std::min(64, (h->split ? SPLIT_MAX_KP : (h->exact_single ? TS_MAX_KP3 : (h->lnl3 ? TS_MAX_KP_LNL : TS_MAX_KP))) - Kp) : 0;
     Kp += h->hot_extra;
     h->P = P; h->Kp = Kp; h->Kpad = P * Kp;
-    h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P;   // AUTO: fused when the layout allows it
+    h->use_fused = (h->em_kernel != TSEM_EMK_TWOPASS) && P <= FZ_MAX_P && !h->em_rows;   // AUTO: fused when the layout allows it
     int R = 2048;
     h->geo = P > 4 ? 1 : 0;
     h->run_len_est = na > 0 ? (double)(h->nnz - nu) / (double)na / P : 0.0;   // entries per ambiguous row and part
@@ -905,6 +911,21 @@ int tsem_build_layout(tsem_ctx* h) {
   tsem_free_layout(h);
   h->nnz_amb = 0;
   h->n_single_part = 0;
+  if (h->em_rows) {
+    // identity column map in virtual parts of Kp columns: pc == column (k_update / k_make_ctab / k_colreduce index conventions hold)
+    std::vector<uint32_t> cm((size_t)K);
+    std::vector<int32_t> cpc((size_t)h->Kpad, -1);
+    for (int j = 0; j < K; ++j) { cm[j] = ((uint32_t)(j / h->Kp) << CM_PS) | (uint32_t)(j % h->Kp); cpc[j] = j; }
+    TSEM_ALLOC(h->d_colmap, K);
+    TSEM_ALLOC(h->d_col_of_pc, h->Kpad);
+    TSEM_HIP(hipMemcpy(h->d_colmap, cm.data(), sizeof(uint32_t) * K, hipMemcpyHostToDevice));
+    TSEM_HIP(hipMemcpy(h->d_col_of_pc, cpc.data(), sizeof(int32_t) * h->Kpad, hipMemcpyHostToDevice));
+    h->nb = 0; h->N_amb_pad = 1; h->nnz_pad = 0; h->max_subblock = 0; h->n_hot_cols = 0;
+    h->nnz_amb = h->nnz - h->N_uni;
+    h->fmt_code = h->fmt_wcode = false; h->sorted_layout = false;
+    h->G1 = h->G2 = 1;
+    return TSEM_OK;
+  }
   // 1. column popularity: global entry counts handed in by set_model
   const std::vector<uint64_t>& counts = h->col_count;
   // 2. parts: deal columns by popularity so every part carries ~equal nnz

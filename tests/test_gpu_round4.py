@@ -332,3 +332,39 @@ def test_split_layout_time_out_falls_back_to_the_two_pass_kernels(gpu_device):
         assert info['fused'] == 0 and info['split'] == 0 and info['fallbacks'] == 1
         assert tl.n_iter == ref.n_iter and abs(tl.lnl - ref.lnl) <= 1e-10 * abs(ref.lnl)
         assert np.allclose(tl.pi, ref.pi, rtol=1e-10, atol=0)
+
+
+def test_any_number_of_loci(gpu_device):
+    """The reference takes any K (model.py:643).  K = 600 000 is beyond the fused kernel (<= 122 880) and the two-pass kernels
+    (<= 64 parts of 7680): the EM pass and the log-likelihood run as plain CSR row passes (round 3 refused the matrix) — against the
+    oracle: parameters, lnl, integer and float report columns, `use_likelihood`."""
+    import scipy.sparse as sp
+    from oracle.telescope_oracle import OracleModel
+    from telescope_amd.likelihood import TelescopeLikelihood
+    rng = np.random.RandomState(11)
+    n, k = 40_000, 600_000
+    hot = rng.randint(0, k, 3000)                                           # a few thousand loci carry most of the entries
+    rows, cols = [], []
+    for i in range(n):
+        l = 1 if rng.rand() < 0.1 else rng.randint(2, 40)
+        c = np.unique(np.where(rng.rand(l) < 0.8, hot[rng.randint(0, 3000, l)], rng.randint(0, k, l)))
+        rows.append(np.full(len(c), i)); cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    data = rng.randint(139, 213, len(cols)).astype(np.uint16)
+    raw = sp.csr_matrix((data, (rows, cols)), shape=(n, k))
+    raw.sort_indices()
+    for use_lnl in (False, True):
+        o = Opts(max_iter=5, em_epsilon=0.0)
+        tl = TelescopeLikelihood(raw, o)
+        info = tl._eng.layout_info()
+        assert info['row_pass_em'] == 1 and info['fused'] == 0 and info['split'] == 0
+        tl.em(use_likelihood=use_lnl)
+        om = OracleModel(raw, o.pi_prior, o.theta_prior)
+        om.em(0.0, 5, use_lnl)
+        assert tl.n_iter == om.n_iter == 5
+        assert abs(tl.lnl - om.lnl) <= RTOL * abs(om.lnl)
+        assert np.allclose(tl.pi, om.pi, rtol=RTOL, atol=1e-300) and np.allclose(tl.theta, om.theta, rtol=RTOL, atol=1e-300)
+        assert np.allclose(tl.pi_init, om.pi_init, rtol=RTOL, atol=1e-300)
+    assert np.array_equal(tl.reassign_colsums('exclude'), np.asarray(om.reassign('exclude').sum(0)).ravel())
+    assert np.allclose(tl.reassign_colsums('conf', 0.9), np.asarray(om.reassign('conf', 0.9).sum(0)).ravel(), rtol=RTOL, atol=1e-12)
+    assert np.array_equal(tl.reassign_colsums('unique'), np.asarray(om.reassign('unique').sum(0)).ravel())
