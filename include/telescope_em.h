@@ -95,6 +95,13 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *                  codes, at most 4800 columns per part with at most 8 parts — i.e. K <= 19k with teams of 4, K <= 38k with
  *                  long rows) — ~1.65x the default mode's time per iteration instead of ~2.5x; 2: always the two-pass form
  *                  (tsem_layout_info[22] says which one runs).  Default 0.
+ *   "split"        how many loci the layout takes.  K <= 61 440 (8 column parts of 7680): the fused single-pass kernel.  K <= 122 880:
+ *                  the SPLIT layout of the fused kernel (-1, default: when K needs it) — parts of up to 15 360 columns, one LDS table
+ *                  per pass: a row-sum pass and a scatter pass per iteration (every entry read twice), the log-likelihood over two
+ *                  halves of every part's columns; ~1.4-1.5x the fused kernel's time per entry.  1 forces it on a smaller matrix
+ *                  (tests; needs "parts" >= 5), 0 forbids it (the two-pass kernels then take over at K > 61 440).  K <= 491 520:
+ *                  the two-pass kernels (64 column parts).  Beyond: plain CSR row passes with global fp64 atomics — any K, an order
+ *                  of magnitude slower per entry (tsem_layout_info[24] / [26] say which form runs).
  *   "em_precision" 1: the EM pass in fp32 arithmetic (row sums, posteriors and column sums in fp32) — a
  *                  DIAGNOSTIC for the fp32-vs-fp64 tolerance sweep of BASELINE config 3, not a product path
  *   "fused_dbg", "fused_prof", "chunk_blocks"     timing experiments */
