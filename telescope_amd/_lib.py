@@ -42,6 +42,9 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
         [os.path.join(ROOT, 'include', 'telescope_em.h')]
     target = out or LIB_PATH
     if (not force and os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)):
+        if verbose:
+            print('build_library: %s is newer than all %d sources and headers: nothing to compile' % (os.path.relpath(target, ROOT), len(deps)),
+                  flush=True)
         return target
     objdir = os.path.join(csrc, '_obj' + ('' if out is None else '_' + os.path.basename(out)))
     os.makedirs(objdir, exist_ok=True)
@@ -66,19 +69,26 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
         flags = ' '.join(common)
         if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == flags and \
                 all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + sorted(includes(src, set()))):
+            if verbose:
+                print('up to date: %s' % os.path.relpath(obj, ROOT), flush=True)
             return obj                                   # this unit's object is newer than everything it is made from
         cmd = common + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         open(stamp, 'w').write(flags)
+        compiled.append(os.path.basename(src))
         return obj
+    compiled = []
     with ThreadPoolExecutor(max_workers=len(units)) as ex:
         objs = list(ex.map(compile_unit, units))
     link = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', target] + objs + ['-ldl', '-lpthread']   # (RCCL is resolved at run time)
     if verbose:
         print(' '.join(link), flush=True)
     subprocess.run(link, check=True)
+    if verbose:      # what this call actually did (whether build() compiled anything must be visible)
+        print('build_library: compiled %d of %d units (%s), linked %s' % (len(compiled), len(units), ', '.join(compiled) or 'none',
+                                                                          os.path.relpath(target, ROOT)), flush=True)
     return target
 
 
