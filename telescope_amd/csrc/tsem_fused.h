@@ -817,6 +817,9 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     auto step_em = [&](FzRegs& rs, FzRegs& rp) {
       const bool pr = A.prof && team == 0 && p == 0 && tid == 0 && (int)i < A.prof_blocks;
       if (pr) A.prof[i * FZ_PROF_SLOTS + 0] = clock64();
+      // (Round 4: the exchange wave's publish is late — 900 instead of 200 clk — in the steps where its two LDS reads of y(i-1) queue
+      // behind the data waves' gather burst.  `s_sleep` of 64 / 192 clk here, to let them in first: 18 per row 1.70 = 1.70 / 1.78 ms
+      // (codes), 2.20 / 2.24 / 2.25 (fp64 entries); 40 per row 3.35 / 3.37 / 3.51 — nothing, then slower.  profiles/r04_ab_delay.txt)
       const int64_t k2 = i - FZ_LAG;
       const uint32_t on0 = offs[((i + FZ_DL + 1) & 7) * 2], on1 = offs[((i + FZ_DL + 1) & 7) * 2 + 1];   // burst of the NEXT step
       const bool idle2 = rs.rc.x == 0xFFFFFFFFu;
