@@ -42,7 +42,8 @@ def _run_ranks(world, fn):
 @pytest.mark.parametrize('name,fail_rank,fmt', [
     ('mid_zipf_20k', None, 0), ('bundled', None, 0), ('bundled_lnl', None, 0), ('tiny_ties_lnl', None, 0),
     ('tiny_twins', None, 0), ('mid_zipf_20k', None, 1),
-    ('mid_zipf_20k', 1, 0), ('bundled_lnl', 0, 0), ('bundled_lnl', 1, 0)])
+    ('mid_zipf_20k', 1, 0), ('bundled_lnl', 0, 0), ('bundled_lnl', 1, 0),
+    ('mid_zipf_20k', None, 'split'), ('bundled_lnl', None, 'split'), ('bundled_lnl', 1, 'split')])   # round 4: the split layout (two passes per iteration)
 def test_chunked_protocol_between_two_ranks(gpu_device, name, fail_rank, fmt):
     """Two engines (rows split by nnz) as two threads with the in-process transport: the loop body is the shipped
     `tsem_em_chunk` — k_em_fused, k_colreduce, all-reduce of K+2 doubles, k_update, (lnl pass, all-reduce of 2
@@ -62,7 +63,7 @@ def test_chunked_protocol_between_two_ranks(gpu_device, name, fail_rank, fmt):
     def rank_main(rank):
         comm = group.comm(rank)
         r0, r1 = cuts[rank], cuts[rank + 1]
-        opts = {'row_offset': r0, 'value_format': fmt}
+        opts = {'row_offset': r0, 'value_format': fmt} if fmt != 'split' else {'row_offset': r0, 'split': 1, 'parts': 5}
         if fail_rank == rank:
             opts['fused_dbg'] = 32 | (64 if use_lnl else 0)
         tl = TelescopeLikelihood(raw[r0:r1], o, device=0, comm=comm, engine_options=opts)
