@@ -484,7 +484,7 @@ def test_rows_longer_than_a_wave_of_quads(gpu_device):
         assert info['fused'] == 1 and info['P'] == 1
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', list(range(24)) + [100 + s for s in range(12)])
 def test_random_shapes_against_oracle(gpu_device, seed):
     """Small random matrices of every shape the layout code branches on: 1..5 column parts, few or
     many blocks (fewer blocks than teams, a single block, blocks of very different fill), rows with
@@ -506,6 +506,8 @@ def test_random_shapes_against_oracle(gpu_device, seed):
         options.append(('block_rows', int(rng.choice([64, 128, 256]))))
     if rng.rand() < 0.2:
         options.append(('em_kernel', 1))
+    if seed >= 100:                                          # round 4: the same shapes on the split layout (two light passes per iteration)
+        options = [kv for kv in options if kv[0] != 'em_kernel'] + [('split', 1), ('parts', int(rng.randint(5, 9)))]
     from oracle.telescope_oracle import OracleModel
     from telescope_amd import _lib
     from telescope_amd.likelihood import TelescopeLikelihood, score_lut
