@@ -509,9 +509,12 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
       }
     }
   }
-  for (int p = 0; p < P; ++p) {                            // padding: value 0 (buffers are zero-filled), row = last row
+  for (int p = 0; p < P; ++p) {                            // padding: value 0 (written here: the buffers of this path are not zero-filled), row = last row
     const int64_t base = sbase[p], end = sb_off[b * P + p + 1];
-    for (int64_t pos = base + total[p] + threadIdx.x; pos < end; pos += blockDim.x) prc[pos] = lastrow[p] << 16;
+    for (int64_t pos = base + total[p] + threadIdx.x; pos < end; pos += blockDim.x) {
+      prc[pos] = lastrow[p] << 16;
+      if (pcode) pcode[pos] = (uint16_t)0; else pval[pos] = 0.0;
+    }
   }
 }
 
@@ -1124,14 +1127,17 @@ int tsem_build_layout(tsem_ctx* h) {
     TSEM_FAIL(TSEM_ERR_ARG, "reproducible mode needs the fused kernel (at most 8 column parts, every row within the register tile) and a score "
                             "table of at most 2048 entries");
   pt.lap("layout: sub-block offsets");
+  // (zero-filled for the strand-transposed fill only, whose padding is whatever it does not write; the row-order fill writes
+  //  every position, padding included — 12-24 GB of memsets, ~3 ms at 2e9 entries, went away with that)
+  const bool will_sort = h->use_fused && R * P <= FILL_MAX_RP && (h->opt_sorted >= 0 ? h->opt_sorted != 0 : true) && nb > 0;
   TSEM_ALLOC(h->d_prc, off);
-  TSEM_HIP(hipMemsetAsync(h->d_prc, 0, sizeof(uint32_t) * std::max<int64_t>(1, off), h->stream));
+  if (!will_sort) TSEM_HIP(hipMemsetAsync(h->d_prc, 0, sizeof(uint32_t) * std::max<int64_t>(1, off), h->stream));
   if (h->fmt_code) {
     TSEM_ALLOC(h->d_pcode, off);
-    TSEM_HIP(hipMemsetAsync(h->d_pcode, 0, sizeof(uint16_t) * std::max<int64_t>(1, off), h->stream));   // code 0 -> Q = 0
+    if (!will_sort) TSEM_HIP(hipMemsetAsync(h->d_pcode, 0, sizeof(uint16_t) * std::max<int64_t>(1, off), h->stream));   // code 0 -> Q = 0
   } else {
     TSEM_ALLOC(h->d_pval, off);
-    TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
+    if (!will_sort) TSEM_HIP(hipMemsetAsync(h->d_pval, 0, sizeof(double) * std::max<int64_t>(1, off), h->stream));
   }
   pt.lap("layout: entry buffers (alloc + zero)");
   // Row order (row sums reduced in registers, a tenth of the LDS atomics) for every fused layout.  Score codes: 40
