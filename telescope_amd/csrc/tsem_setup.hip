@@ -783,6 +783,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   if (int rc = ensure_device(h)) return rc;
   const int64_t N = h->N;
   const int K = h->K;
+  PhaseTimer pt(h->stream);
   DevTmp t_wpart, t_fa, t_fu, t_pis, t_lg;                   // freed on every return path
   TSEM_ALLOC(h->d_row_code, N); TSEM_ALLOC(h->d_row_cls, N);   // (kept: 3 B per row; tsem_export_rowinfo)
   uint16_t* const d_code = h->d_row_code; uint8_t* const d_cls = h->d_row_cls;
@@ -802,6 +803,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   TSEM_TMP(t_lg, 64);
   unsigned long long* const d_lg = t_lg.as<unsigned long long>();
   TSEM_HIP(hipMemsetAsync(d_lg, 0, 64, h->stream));
+  pt.lap("rowstats: allocations");
   if (N) {
     const double mean_len = (double)h->nnz / (double)N;    // lanes per row x 16 entries >= ~1.5 mean row lengths
     const int G = mean_len * 1.5 <= 16 ? 1 : mean_len * 1.5 <= 32 ? 2 : mean_len * 1.5 <= 64 ? 4 : mean_len * 1.5 <= 128 ? 8 : 16;
@@ -822,6 +824,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   if (stats3) { stats3[0] = wt; stats3[1] = wa; stats3[2] = (N && h->nnz) ? h->lut_host[maxcode] : 0.0; }
   if (pisum0) TSEM_HIP(hipMemcpy(pisum0, h->d_pisum0, sizeof(double) * K, hipMemcpyDeviceToHost));
 
+  pt.lap("rowstats: k_rowstats + sums");
   // column signatures (popularity + twin detection)
   if (col_count && col_hash) {
     DevTmp t_hash;
@@ -850,6 +853,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     TSEM_HIP(hipMemcpyAsync(col_hash, d_hash, sizeof(uint64_t) * K, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
   }
+  pt.lap("rowstats: column signatures");
   // compact ambiguous and unique rows
   TSEM_TMP(t_fa, 4 * (size_t)(N + 1)); TSEM_TMP(t_fu, 4 * (size_t)(N + 1));
   int32_t* const d_fa = t_fa.as<int32_t>(); int32_t* const d_fu = t_fu.as<int32_t>();
@@ -869,6 +873,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
     TSEM_HIP(hipMemcpyAsync(&nu, d_fu + N, 4, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
   }
+  pt.lap("rowstats: class flags + scans");
   h->N_amb = na; h->N_uni = nu;
   if (int rc = tsem_choose_geometry(h)) return rc;
   TSEM_ALLOC(h->d_amb_row, na);
@@ -881,6 +886,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
                                                          h->d_uni_code);
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipStreamSynchronize(h->stream));
+  pt.lap("rowstats: compact rows");
   h->have_rowstats = true;
   return TSEM_OK;
 }
