@@ -261,7 +261,7 @@ def main():
     from telescope_amd import synthetic
     from telescope_amd._lib import Engine, EMK_AUTO, EMK_FUSED, EMK_TWOPASS
     from telescope_amd.distributed import init_from_env, shard_bounds
-    from telescope_amd.likelihood import TelescopeLikelihood
+    from telescope_amd.likelihood import TelescopeLikelihood, EM_CHUNK
 
     # the engine first: without a usable GPU every rank fails HERE, loudly ("no CPU fallback"), not in the launcher
     if args.one_device:
@@ -310,7 +310,7 @@ def main():
     import logging
 
     def run(n):
-        # `TelescopeLikelihood.em()` itself (likelihood.py), n iterations at em_epsilon = 0: chunks of EM_CHUNK = 8 iterations per host
+        # `TelescopeLikelihood.em()` itself (likelihood.py), n iterations at em_epsilon = 0: chunks of EM_CHUNK (16) iterations per host
         # synchronisation — pass, in-library RCCL all-reduce (N > 1 / --force-comm), update, the device-side convergence test (never
         # true at epsilon 0) — or, on the fall-back transport, one torch.distributed all-reduce and one host round trip per
         # iteration with the time-out recovery.  Only the log-likelihood pass AFTER the loop (model.py:800-801) is left out: a step
@@ -386,7 +386,7 @@ def main():
         'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'nnz_per_sec': nnz_total * args.steps / elapsed,
         'check': check,
-        'timed_call': 'TelescopeLikelihood.em(final_lnl=False): chunks of 8 iterations per host synchronisation',
+        'timed_call': 'TelescopeLikelihood.em(final_lnl=False): chunks of %d iterations per host synchronisation' % EM_CHUNK,
         'whole_em_call': whole,
         'config': {
             'workload': 'synthetic %dM fragments x %dk loci, ~%g nnz/row, %s columns, fp64 arithmetic, '

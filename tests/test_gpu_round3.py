@@ -47,7 +47,7 @@ def _run_ranks(world, fn):
 def test_chunked_protocol_between_two_ranks(gpu_device, name, fail_rank, fmt):
     """Two engines (rows split by nnz) as two threads with the in-process transport: the loop body is the shipped
     `tsem_em_chunk` — k_em_fused, k_colreduce, all-reduce of K+2 doubles, k_update, (lnl pass, all-reduce of 2
-    doubles, k_lnl_check) per iteration, the device-side stop flag, one host synchronisation per chunk of 8.  Both
+    doubles, k_lnl_check) per iteration, the device-side stop flag, one host synchronisation per chunk of EM_CHUNK.  Both
     ranks must stop in the reference's iteration with bit-identical parameters.  `fail_rank`: that rank's fused EM
     pass (and, with use_likelihood, its lnl pass) behaves like a hand-off time-out (fused_dbg bits 5 / 6): nobody
     commits, the failing rank alone rebuilds for the two-pass kernels, every rank redoes the iteration."""

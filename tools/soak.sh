@@ -14,3 +14,7 @@ run 8000 --value-format auto --rows 6250000
 run 4000 --value-format auto --rows 20000000 --cols 50000 --nnz-row 20
 run 4000 --value-format auto --rows 20000000 --cols 50000 --nnz-row 40
 run 3000 --value-format f64 --rows 20000000 --cols 45000 --nnz-row 30
+# round 4: the split layout (K > 61 440: a row-sum pass and a scatter pass per iteration, no team exchange)
+run 3000 --value-format auto --rows 10000000 --cols 100000 --nnz-row 40
+run 3000 --value-format f64 --rows 4000000 --cols 122880 --nnz-row 100
+run 3000 --value-format auto --rows 20000000 --cols 70000 --nnz-row 18
