@@ -274,6 +274,10 @@ def init_from_env(backend=None, force=False):
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('LOCAL_RANK', '0')
+    if os.environ.get('MASTER_ADDR', '') in ('127.0.0.1', 'localhost', '::1'):
+        # a single-node job: RCCL's bootstrap sockets (torch's communicator and the library's) need not guess an interface in a
+        # container whose other interfaces may be unusable; the data path is xGMI / P2P either way
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
     import torch
     import torch.distributed as dist
     if backend is None:
