@@ -28,12 +28,12 @@ class EngineError(RuntimeError):
 
 # host / ABI, set-up, EM support, report / row passes, collectives, CSR primitives (telescope_amd/csrc/tsem_internal.h)
 LIB_UNITS = ('tsem_host', 'tsem_setup', 'tsem_em', 'tsem_report', 'tsem_comm', 'tsem_csr')
-FZ_UNITS = ('tsem_fz_p1', 'tsem_fz_p2', 'tsem_fz_p3', 'tsem_fz_p4', 'tsem_fz_p56', 'tsem_fz_p78')
+FZ_UNITS = tuple('tsem_fz_p%d' % p for p in range(1, 9))
 
 
 def build_library(force=False, verbose=False, extra_flags=(), out=None):
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU).  Twelve translation units — the six of
-    LIB_UNITS and the six that instantiate the fused kernel for one or two team sizes each (most of the build time) — are compiled
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU).  Fourteen translation units — the six of
+    LIB_UNITS and the eight that instantiate the fused kernel for one team size each (most of the build time) — are compiled
     in parallel and linked into one shared object."""
     from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(HERE, 'csrc')

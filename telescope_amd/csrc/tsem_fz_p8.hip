@@ -1,0 +1,11 @@
+// Fused-kernel instantiations for teams of 8 members (one of eight such translation units compiled in parallel, telescope_amd/_lib.py).
+#include "tsem_fused_inst.h"
+
+fz_fn tsem_fz_kernel_p8(int P, int mode, int fmt, int geo) {
+#ifdef TSEM_FAST_BUILD                                     // kernel experiments (tools/ab.sh): teams of 4 only
+  (void)P; (void)mode; (void)fmt; (void)geo;
+  return nullptr;
+#else
+  return P == 8 ? fz_pick<8>(mode, fmt, geo) : nullptr;
+#endif
+}

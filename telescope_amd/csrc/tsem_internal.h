@@ -6,7 +6,7 @@
 //   tsem_report.hip  CSR row passes: z export, best hits, reassign, the streaming report pass, per-barcode sums
 //   tsem_comm.hip    collectives: RCCL resolved at run time, the in-process transport, the communicator ABI
 //   tsem_csr.hip     csr_matrix_plus primitives on fp64 CSR, numpy's legacy random draw
-//   tsem_fz_p*.hip   instantiations of the fused kernel (tsem_fused.h), one or two team sizes per unit
+//   tsem_fz_p*.hip   instantiations of the fused kernel (tsem_fused.h), one team size per unit
 //
 // A kernel is launched only from the unit that defines it; other units go through the host functions declared here.
 #pragma once
@@ -114,22 +114,24 @@ static inline int ensure_device(tsem_ctx* h) {
 }
 
 // The fused kernel's instantiations (team size x mode x entry format x geometry: ~200 kernels, most of the library's build time)
-// live in six translation units compiled in parallel (tsem_fz_p1.hip ... tsem_fz_p78.hip, tsem_fused_inst.h); each exports one
+// live in eight translation units compiled in parallel (tsem_fz_p1.hip ... tsem_fz_p8.hip, tsem_fused_inst.h); each exports one
 // look-up function.  The host launches through the pointer.
 typedef void (*fz_fn)(FusedArgs);
 fz_fn tsem_fz_kernel_p1(int P, int mode, int fmt, int geo);
 fz_fn tsem_fz_kernel_p2(int P, int mode, int fmt, int geo);
 fz_fn tsem_fz_kernel_p3(int P, int mode, int fmt, int geo);
 fz_fn tsem_fz_kernel_p4(int P, int mode, int fmt, int geo);
-fz_fn tsem_fz_kernel_p56(int P, int mode, int fmt, int geo);
-fz_fn tsem_fz_kernel_p78(int P, int mode, int fmt, int geo);
+fz_fn tsem_fz_kernel_p5(int P, int mode, int fmt, int geo);
+fz_fn tsem_fz_kernel_p6(int P, int mode, int fmt, int geo);
+fz_fn tsem_fz_kernel_p7(int P, int mode, int fmt, int geo);
+fz_fn tsem_fz_kernel_p8(int P, int mode, int fmt, int geo);
 static inline int fz_fmt(const tsem_ctx* h) { return h->fmt_code ? 1 : (h->fmt_wcode ? 2 : 0); }
 static inline fz_fn fz_kernel(int P, int mode, int fmt, int geo) {
   switch (P) {
     case 1: return tsem_fz_kernel_p1(P, mode, fmt, geo); case 2: return tsem_fz_kernel_p2(P, mode, fmt, geo);
     case 3: return tsem_fz_kernel_p3(P, mode, fmt, geo); case 4: return tsem_fz_kernel_p4(P, mode, fmt, geo);
-    case 5: case 6: return tsem_fz_kernel_p56(P, mode, fmt, geo);
-    case 7: case 8: return tsem_fz_kernel_p78(P, mode, fmt, geo);
+    case 5: return tsem_fz_kernel_p5(P, mode, fmt, geo); case 6: return tsem_fz_kernel_p6(P, mode, fmt, geo);
+    case 7: return tsem_fz_kernel_p7(P, mode, fmt, geo); case 8: return tsem_fz_kernel_p8(P, mode, fmt, geo);
     default: return nullptr;
   }
 }
