@@ -124,7 +124,14 @@ def configure_logging(opts):
     """utils/__init__.py:84-104 — same format string."""
     level = lg.DEBUG if opts.debug else (lg.WARNING if opts.quiet else lg.INFO)
     fmt = '%(asctime)s %(levelname)-8s %(message)-60s (from %(funcName)s in %(filename)s:%(lineno)d)'
-    lg.basicConfig(level=level, format=fmt, datefmt='%Y-%m-%d %H:%M:%S', stream=opts.logfile, force=True)
+    stream = opts.logfile
+    if int(os.environ.get('RANK', '0')) != 0:
+        # a rank other than 0 of a `torch.distributed.run` launch: ONE copy of the progress lines (rank 0's), and only rank 0 keeps
+        # the --logfile (argparse opened it for appending on every rank: the others go back to stderr, warnings and errors only)
+        level = max(level, lg.WARNING)
+        if stream is not None and stream not in (sys.stderr, sys.stdout):
+            stream = sys.stderr
+    lg.basicConfig(level=level, format=fmt, datefmt='%Y-%m-%d %H:%M:%S', stream=stream, force=True)
 
 
 def build_model(raw_scores, opts):
