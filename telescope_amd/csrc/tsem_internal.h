@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <type_traits>
 
 #include "tsem_common.h"
 #include "tsem_device.h"
@@ -90,6 +91,14 @@ struct DevTmp {
   ~DevTmp() { if (p) (void)hipFree(p); }
   template <typename T> T* as() const { return static_cast<T*>(p); }
 };
+// ... and the same for a plain local pointer filled by TSEM_ALLOC / hipMalloc:  T* d_x = nullptr; TSEM_SCOPED(d_x);  — freed at scope
+// exit on every return path (the manual hipFree at the end of a function is skipped by every early `return rc`)
+template <typename T> struct DevScope {
+  T*& p;
+  explicit DevScope(T*& r) : p(r) {}
+  ~DevScope() { if (p) { (void)hipFree(p); p = nullptr; } }
+};
+#define TSEM_SCOPED(ptr) DevScope<std::remove_pointer<decltype(ptr)>::type> tsem_scope_##ptr(ptr)
 #define TSEM_TMP(tmp, bytes) do { if (hipMalloc(&(tmp).p, std::max<size_t>(1, (size_t)(bytes))) != hipSuccess) { \
     (tmp).p = nullptr; TSEM_FAIL(TSEM_ERR_NOMEM, "hipMalloc(" + std::to_string((size_t)(bytes)) + " B) failed"); } } while (0)
 

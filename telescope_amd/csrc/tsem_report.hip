@@ -768,13 +768,13 @@ int tsem_rowpass_grid(tsem_ctx* h) { return (int)std::min<int64_t>(8192, std::ma
 
 static int export_z_with(tsem_ctx* h, RowPassArgs& A, double* z) {
   double* d_z = nullptr;
+  TSEM_SCOPED(d_z);
   TSEM_ALLOC(d_z, h->nnz);
   A.zout = d_z;
   if (h->N) k_rowpass<RP_EXPORT_Z><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
   if (h->nnz) TSEM_HIP(hipMemcpyAsync(z, d_z, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_z);
   return TSEM_OK;
 }
 
@@ -813,13 +813,13 @@ int tsem_best_counts(tsem_ctx* h, int which, int32_t* nbest) {
   RowPassArgs A;
   if (int rc = rowpass_args(h, which, A)) return rc;
   int32_t* d_nb = nullptr;
+  TSEM_SCOPED(d_nb);
   TSEM_ALLOC(d_nb, h->N);
   A.nbest = d_nb;
   if (h->N) k_rowpass<RP_BEST><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
   if (h->N) TSEM_HIP(hipMemcpyAsync(nbest, d_nb, sizeof(int32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_nb);
   return TSEM_OK;
 }
 
@@ -841,6 +841,8 @@ int tsem_best_ties(tsem_ctx* h, int which, int64_t cap, int32_t* rows, int32_t* 
   if (int rc = rowpass_args(h, which, A)) return rc;
   int32_t *d_nb = nullptr, *d_rows = nullptr, *d_cnt = nullptr;
   unsigned long long* d_n = nullptr;
+  void* tmp = nullptr;
+  TSEM_SCOPED(d_nb); TSEM_SCOPED(d_rows); TSEM_SCOPED(d_cnt); TSEM_SCOPED(d_n); TSEM_SCOPED(tmp);
   TSEM_ALLOC(d_nb, h->N); TSEM_ALLOC(d_rows, h->N); TSEM_ALLOC(d_n, 1);
   A.nbest = d_nb;
   k_rowpass<RP_BEST><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
@@ -849,13 +851,11 @@ int tsem_best_ties(tsem_ctx* h, int which, int64_t cap, int32_t* rows, int32_t* 
   TiedRow pred{d_nb};
   rocprim::counting_iterator<int32_t> first(0);
   TSEM_HIP(rocprim::select(nullptr, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
-  void* tmp = nullptr;
   TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
   TSEM_HIP(rocprim::select(tmp, tb, first, d_rows, d_n, (size_t)h->N, pred, h->stream));
   unsigned long long n = 0;
   TSEM_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(tmp);
   *n_out = (int64_t)n;
   int rc = TSEM_OK;
   if ((int64_t)n > cap) {
@@ -868,8 +868,6 @@ int tsem_best_ties(tsem_ctx* h, int which, int64_t cap, int32_t* rows, int32_t* 
     TSEM_HIP(hipMemcpyAsync(counts, d_cnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
   }
-  (void)hipFree(d_nb); (void)hipFree(d_rows); (void)hipFree(d_n);
-  if (d_cnt) (void)hipFree(d_cnt);
   return rc;
 }
 
@@ -888,8 +886,7 @@ static int rowpass_lo_end(tsem_ctx* h, double* sums, double* lo, int64_t n) {
   k_add_lo<<<cdiv64(n, 256), 256, 0, h->stream>>>(n, sums, lo);
   TSEM_HIP(hipGetLastError());
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(lo);
-  return TSEM_OK;
+  return TSEM_OK;                                          // (the caller's scope guard frees `lo`)
 }
 
 int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32_t* picks, double* colsums,
@@ -926,6 +923,7 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
   A.method = method; A.thresh = thresh;
   double *d_cs = nullptr, *d_mask = nullptr;
   int32_t* d_picks = nullptr;
+  TSEM_SCOPED(d_cs); TSEM_SCOPED(d_mask); TSEM_SCOPED(d_picks);
   TSEM_ALLOC(d_cs, h->K);
   TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
   if (mask) TSEM_ALLOC(d_mask, h->nnz);
@@ -935,6 +933,7 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
   }
   A.colsums = d_cs; A.zout = d_mask; A.picks = d_picks;
   double* d_lo = nullptr;
+  TSEM_SCOPED(d_lo);                                    // (the low pieces of the exact sums: freed on every return path)
   if (int rc = rowpass_lo_begin(h, A, h->K, &d_lo)) return rc;
   if (h->N && h->d_colmap && h->d_col_of_pc && h->P > 0) {
     // hot slots of every part in LDS.  `all` emits one value per stored entry, so it wants as many slots as fit: one
@@ -964,9 +963,6 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
   TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
   if (mask && h->nnz) TSEM_HIP(hipMemcpyAsync(mask, d_mask, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_cs);
-  if (d_mask) (void)hipFree(d_mask);
-  if (d_picks) (void)hipFree(d_picks);
   return TSEM_OK;
 }
 
@@ -981,6 +977,7 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
   if (n_ties) *n_ties = 0;
   const int K = h->K;
   double* d_cs = nullptr;
+  TSEM_SCOPED(d_cs);
   TSEM_ALLOC(d_cs, 3 * (int64_t)K);
   TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * 3 * K, h->stream));
   if (h->N) {
@@ -1000,6 +997,7 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       R.lut = h->d_lut; R.lut_len = A.lut_len; R.cnat2 = nullptr; R.thresh = thresh; R.nbest = d_nb;
       const bool init = A.pi == nullptr;
       double *d_g = nullptr, *d_c2 = nullptr;
+      TSEM_SCOPED(d_g); TSEM_SCOPED(d_c2);
       const bool exact = h->opt_reproducible != 0;
       TSEM_ALLOC(d_g, 6 * (int64_t)IDN);
       TSEM_HIP(hipMemsetAsync(d_g, 0, sizeof(double) * 6 * IDN, h->stream));
@@ -1041,20 +1039,20 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       k_report_finish<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, K, h->d_col_of_id, R.g_conf, R.g_n1, R.g_n2, R.g_avgt, R.g_conf_lo, R.g_avgt_lo, d_cs);
       TSEM_HIP(hipGetLastError());
       TSEM_HIP(hipStreamSynchronize(h->stream));
-      (void)hipFree(d_g);
-      if (d_c2) (void)hipFree(d_c2);
     } else if (h->d_colmap && h->d_col_of_pc && h->P > 0) {
       const int wgs = h->opt_rowpass_wgs < 2 ? 1 : 2;
       A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;
       A.Hs = std::max(0, std::min(h->Kp, (int)((TS_LDS_MAX / wgs - 8192 / wgs - 1024 - A.lut_len * 8) / 8 / h->P / 3)));
       TSEM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
       double* d_lo = nullptr;
+      TSEM_SCOPED(d_lo);                                    // (the low pieces of the exact sums: freed on every return path)
       if (int rc = rowpass_lo_begin(h, A, 3 * (int64_t)K, &d_lo)) return rc;
       kern<<<h->n_cu * wgs, 1024, (size_t)(3 * A.P * A.Hs + A.lut_len) * 8, h->stream>>>(A);
       TSEM_HIP(hipGetLastError());
       if (int rc = rowpass_lo_end(h, d_cs, d_lo, 3 * (int64_t)K)) return rc;
     } else {
       double* d_lo = nullptr;
+      TSEM_SCOPED(d_lo);                                    // (the low pieces of the exact sums: freed on every return path)
       if (int rc = rowpass_lo_begin(h, A, 3 * (int64_t)K, &d_lo)) return rc;
       kern<<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
       TSEM_HIP(hipGetLastError());
@@ -1088,7 +1086,6 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
   } else {
     for (int64_t j = 0; j < 3 * (int64_t)K; ++j) out3K[j] = 0.0;
   }
-  (void)hipFree(d_cs);
   return TSEM_OK;
 }
 
@@ -1121,6 +1118,7 @@ int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const 
       if (rows[i] < 0 || rows[i] >= h->N) TSEM_FAIL(TSEM_ERR_ARG, "tsem_reassign_rows: row out of range");
   double* d_cs = nullptr;
   int32_t *d_rows = nullptr, *d_picks = nullptr;
+  TSEM_SCOPED(d_cs); TSEM_SCOPED(d_rows); TSEM_SCOPED(d_picks);
   TSEM_ALLOC(d_cs, h->K);
   TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
   if (rows) {
@@ -1135,15 +1133,13 @@ int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const 
   A.rowlist = rows ? d_rows : h->d_tie_rows; A.nlist = n;
   const int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + 15) / 16));
   double* d_lo = nullptr;
+  TSEM_SCOPED(d_lo);                                    // (the low pieces of the exact sums: freed on every return path)
   if (int rc = rowpass_lo_begin(h, A, h->K, &d_lo)) return rc;
   k_rowpass<RP_REASSIGN><<<grid, 256, (size_t)A.lut_len * 8, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
   if (int rc = rowpass_lo_end(h, d_cs, d_lo, h->K)) return rc;
   TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_cs);
-  if (d_rows) (void)hipFree(d_rows);
-  if (d_picks) (void)hipFree(d_picks);
   return TSEM_OK;
 }
 
@@ -1287,6 +1283,7 @@ int tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat) 
   RowPassArgs A;
   if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
   double *d_z = nullptr, *d_cs = nullptr;
+  TSEM_SCOPED(d_z); TSEM_SCOPED(d_cs);
   TSEM_ALLOC(d_z, h->nnz);
   TSEM_ALLOC(d_cs, h->K);
   if (h->nnz) TSEM_HIP(hipMemcpyAsync(d_z, z, sizeof(double) * h->nnz, hipMemcpyHostToDevice, h->stream));
@@ -1294,7 +1291,7 @@ int tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat) 
   A.colsums = d_cs;
   if (h->N) k_mstep_rows<<<tsem_rowpass_grid(h), 256, 0, h->stream>>>(A, d_z);
   if (tsem_comm_on(h)) {                                         // row-sharded: thetasum over all ranks (model.py:731)
-    if (int rc = tsem_comm_allreduce_dev(h->comm, d_cs, (size_t)h->K, 0, h->stream, h->err)) { (void)hipFree(d_z); (void)hipFree(d_cs); return rc; }
+    if (int rc = tsem_comm_allreduce_dev(h->comm, d_cs, (size_t)h->K, 0, h->stream, h->err)) return rc;
   }
   const double tpw = h->theta_prior * h->w_max, ppw = h->pi_prior * h->w_max;
   k_hats<<<cdiv64(h->K, 256), 256, 0, h->stream>>>(h->K, d_cs, h->d_pisum0, tpw, h->W_amb + tpw * h->K, ppw,
@@ -1303,7 +1300,6 @@ int tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat) 
   TSEM_HIP(hipMemcpyAsync(pi_hat, h->d_tmp_pi, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipMemcpyAsync(theta_hat, h->d_tmp_theta, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_z); (void)hipFree(d_cs);
   return TSEM_OK;
 }
 
@@ -1313,6 +1309,7 @@ int tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* 
   RowPassArgs A;
   if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
   double* d_z = nullptr;
+  TSEM_SCOPED(d_z);
   TSEM_ALLOC(d_z, h->nnz);
   if (h->nnz) TSEM_HIP(hipMemcpyAsync(d_z, z, sizeof(double) * h->nnz, hipMemcpyHostToDevice, h->stream));
   TSEM_HIP(hipMemcpyAsync(h->d_tmp_pi, pi, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
@@ -1323,11 +1320,10 @@ int tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* 
   if (int rc = tsem_sum_parts(h, h->d_lnl_part, h->N ? grid : 0, h->d_lnl_part, 0, h->d_lnl_part + 8000)) return rc;
   TSEM_HIP(hipGetLastError());
   if (tsem_comm_on(h)) {
-    if (int rc = tsem_comm_allreduce_dev(h->comm, h->d_lnl_part + 8000, 1, 0, h->stream, h->err)) { (void)hipFree(d_z); return rc; }
+    if (int rc = tsem_comm_allreduce_dev(h->comm, h->d_lnl_part + 8000, 1, 0, h->stream, h->err)) return rc;
   }
   TSEM_HIP(hipMemcpyAsync(lnl, h->d_lnl_part + 8000, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_z);
   return TSEM_OK;
 }
 

@@ -998,6 +998,7 @@ int tsem_build_layout(tsem_ctx* h) {
   int64_t nb = 0;
   int64_t* d_bs = nullptr;                                 // first compact row of every block, [nb + 1]
   unsigned long long* d_pc = nullptr;                      // per-row part counts (fused layout only)
+  TSEM_SCOPED(d_bs); TSEM_SCOPED(d_pc);                    // (temporaries of this function: freed on every return path)
   bool rid_amb_done = false;
   if (h->use_fused && na > 0 && P <= FZ_MAX_P) {
     TSEM_ALLOC(d_pc, 2 * na);
@@ -1037,6 +1038,7 @@ int tsem_build_layout(tsem_ctx* h) {
     const int64_t nch = (na + L - 1) / L;
     int64_t *d_cnt = nullptr, *d_off = nullptr;
     int* d_flag = nullptr;
+    TSEM_SCOPED(d_cnt); TSEM_SCOPED(d_off); TSEM_SCOPED(d_flag);
     TSEM_ALLOC(d_cnt, nch + 1); TSEM_ALLOC(d_off, nch + 1); TSEM_ALLOC(d_flag, 1);
     TSEM_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), h->stream));
     TSEM_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int64_t) * (nch + 1), h->stream));
@@ -1046,13 +1048,13 @@ int tsem_build_layout(tsem_ctx* h) {
       size_t tb = 0;
       TSEM_HIP(rocprim::exclusive_scan(nullptr, tb, d_cnt, d_off, (int64_t)0, (size_t)(nch + 1), rocprim::plus<int64_t>(), h->stream));
       void* tmp = nullptr;
+      TSEM_SCOPED(tmp);
       TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
       TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_cnt, d_off, (int64_t)0, (size_t)(nch + 1), rocprim::plus<int64_t>(), h->stream));
       int flag = 0;
       TSEM_HIP(hipMemcpyAsync(&nb, d_off + nch, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
       TSEM_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       TSEM_HIP(hipStreamSynchronize(h->stream));
-      (void)hipFree(tmp);
       if (flag) { h->use_fused = false; nb = 0; }          // one row overflows the register tile
     }
     if (h->use_fused) {
@@ -1062,7 +1064,6 @@ int tsem_build_layout(tsem_ctx* h) {
       TSEM_HIP(hipMemcpyAsync(d_bs + nb, &na, sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
       TSEM_HIP(hipStreamSynchronize(h->stream));
     }
-    (void)hipFree(d_cnt); (void)hipFree(d_off); (void)hipFree(d_flag);
     if (!h->use_fused) { (void)hipFree(d_pc); d_pc = nullptr; }
   }
   if (!d_bs) {                                             // two-pass layout: R rows per block
@@ -1091,13 +1092,13 @@ int tsem_build_layout(tsem_ctx* h) {
   std::vector<int64_t> sb(nb * P + 1, 0);
   if (nb) {
     int64_t* d_cnt = nullptr;
+    TSEM_SCOPED(d_cnt);
     TSEM_ALLOC(d_cnt, nb * P);
     if (d_pc) k_sb_count_pc<<<(unsigned)nb, 64, 0, h->stream>>>(nb, P, d_bs, d_pc, d_cnt);
     else k_sb_count<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_colmap, d_cnt);
     TSEM_HIP(hipGetLastError());
     TSEM_HIP(hipMemcpyAsync(sb.data(), d_cnt, sizeof(int64_t) * nb * P, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
-    (void)hipFree(d_cnt);
   }
   if (h->use_fused) {
     int64_t mx = 0;
@@ -1159,6 +1160,7 @@ int tsem_build_layout(tsem_ctx* h) {
     // k_rid16_rows above) and the split columns' ids fit the small table
     const uint16_t* rid_fill = nullptr;
     uint8_t* d_lgtab = nullptr;
+    TSEM_SCOPED(d_lgtab);
     int nsplit = 0;
     if (h->d_rid16 && P <= 8) {
       std::vector<uint8_t> lgt;
@@ -1179,13 +1181,14 @@ int tsem_build_layout(tsem_ctx* h) {
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
                                                          d_pc ? d_bs : nullptr, d_pc, rid_fill, magicP, nsplit, d_lgtab);
     TSEM_HIP(hipGetLastError());
-    if (d_lgtab) { TSEM_HIP(hipStreamSynchronize(h->stream)); (void)hipFree(d_lgtab); }
+    if (d_lgtab) TSEM_HIP(hipStreamSynchronize(h->stream));   // (the fill reads the table; its scope guard frees it)
     TSEM_HIP(hipGetLastError());
     // (reproducible mode keeps the row order: a row's entries in a sub-block then form ONE run, which ends in at most two LDS
     // atomics on its row sum — two additions commute, three need not)
     if (h->fmt_code && h->opt_deconflict != 0 && !h->opt_reproducible && off >= 64) {
       const int64_t n_win = off / 64;
       uint32_t* prc2 = nullptr; uint16_t* code2 = nullptr;
+      TSEM_SCOPED(prc2); TSEM_SCOPED(code2);
       TSEM_ALLOC(prc2, off); TSEM_ALLOC(code2, off);
       k_sb_deconflict<<<(unsigned)std::min<int64_t>(n_win / DC_NT + 1, (int64_t)h->n_cu * 32), DC_NT, 0, h->stream>>>(
           n_win, h->d_prc, h->d_pcode, prc2, code2);
@@ -1193,6 +1196,7 @@ int tsem_build_layout(tsem_ctx* h) {
       TSEM_HIP(hipStreamSynchronize(h->stream));
       (void)hipFree(h->d_prc); (void)hipFree(h->d_pcode);
       h->d_prc = prc2; h->d_pcode = code2;
+      prc2 = nullptr; code2 = nullptr;                     // (ownership moved to the context)
     }
   } else if (nb) {
     k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
@@ -1200,8 +1204,6 @@ int tsem_build_layout(tsem_ctx* h) {
     TSEM_HIP(hipGetLastError());
   }
   TSEM_HIP(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_bs);
-  if (d_pc) (void)hipFree(d_pc);
   pt.lap("layout: fill + conflict-aware order");
   if (!h->use_fused) TSEM_ALLOC(h->d_ypart, (int64_t)P * h->N_amb_pad);   // partial row sums of the two-pass kernels
   // launch geometry
