@@ -297,6 +297,13 @@ int  tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out /* 3
 int  tsem_report_ties(tsem_ctx* h, int64_t cap, int32_t* rows, int32_t* counts);
 int  tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const int32_t* rows,
                         const int32_t* picks, int64_t n, double* colsums);
+/* z[ridx, fidx] and reassign(method, thresh)[ridx, fidx] for the entries of a LIST of rows: what Telescope.update_sam reads per
+ * alignment (model.py:483,508-511 — `prob = tl.z[ridx, fidx]`, `mat[ridx, fidx] > 0`), without the N x K matrices.  Row rows[i]'s
+ * entries (CSR order) go to z_out / mask_out [out_off[i], out_off[i + 1]) (out_off[n] = total; the slices must have the rows'
+ * lengths: TSEM_ERR_ARG otherwise).  z_out: -1 where the reference drops the entry from z's pattern.  picks[i] (choose) belongs to
+ * list row i.  Either output may be NULL. */
+int  tsem_rows_lookup(tsem_ctx* h, int which, int method, double thresh, int64_t n, const int32_t* rows, const int32_t* picks,
+                      const int64_t* out_off, double* z_out, double* mask_out);
 /* The random picks of `choose` (sparse_plus.py:140-154: np.random.choice per row with several best hits) in numpy's
  * LEGACY stream, on the host: out[i] = the draw np.random.randint(0, counts[i]) would return, taken in order from the
  * MT19937 state (key624, *pos) = np.random.get_state()[1:3]; the state is advanced exactly as numpy advances it, so

@@ -185,6 +185,7 @@ def lib():
     L.tsem_report_ties.argtypes = [vp, i64, vp, vp]
     L.tsem_reassign_rows.argtypes = [vp, C.c_int, C.c_double, C.c_int, vp, vp, i64, vp]
     L.tsem_reassign.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, vp]
+    L.tsem_rows_lookup.argtypes = [vp, C.c_int, C.c_int, dbl, i64, vp, vp, vp, vp, vp]
     L.tsem_reassign_groups.argtypes = [vp, C.c_int, dbl, C.c_int, vp, vp, C.c_int32, vp]
     L.tsem_set_groups.argtypes = [vp, vp, C.c_int32]
     L.tsem_csr_norm_rows.argtypes = [C.c_int, i64, vp, vp, vp]
@@ -497,6 +498,18 @@ class Engine(object):
         self._ck(self._L.tsem_reassign(self._h, RA_CODE[method], float(thresh), which, ptr(picks), ptr(cs),
                                        ptr(mask)))
         return cs, mask
+
+    def rows_lookup(self, method, thresh, which, rows, out_off, picks=None, want_z=True, want_mask=True):
+        """(z, mask) of the entries of the listed rows, compact (tsem_rows_lookup): row rows[i] -> [out_off[i], out_off[i + 1])."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        out_off = np.ascontiguousarray(out_off, dtype=np.int64)
+        total = int(out_off[-1]) if len(out_off) else 0
+        z = np.zeros(total) if want_z else None
+        m = np.zeros(total) if want_mask else None
+        pk = None if picks is None else np.ascontiguousarray(picks, dtype=np.int32)
+        self._ck(self._L.tsem_rows_lookup(self._h, which, RA_CODE[method], float(thresh), len(rows), ptr(rows), ptr(pk), ptr(out_off),
+                                          ptr(z), ptr(m)))
+        return z, m
 
     def set_groups(self, group_of_row, n_groups):
         """Row -> group map of the per-group sums, copied to the device once (None drops it)."""

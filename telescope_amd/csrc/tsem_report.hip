@@ -18,6 +18,11 @@ __device__ __forceinline__ void exact_split01(double v, double& hi, double& lo) 
   hi = (v + m1) - m1;
   lo = ((v - hi) + 0.75) - 0.75;                            // ulp(0.75) = 2^-53
 }
+__global__ void k_check_offsets(int64_t n, const int32_t* __restrict__ rows, const int64_t* __restrict__ off, const int64_t* __restrict__ indptr,
+                                uint32_t* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && off[i + 1] - off[i] != indptr[rows[i] + 1] - indptr[rows[i]]) *bad = 1u;
+}
 __global__ void k_add_lo(int64_t n, double* __restrict__ a, const double* __restrict__ lo) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] += lo[i];
@@ -43,7 +48,8 @@ struct RowPassArgs {
   double* colsums;
   const int32_t* group;  // REASSIGN: optional row -> group map; colsums is then [g1 - g0][K], rows of other groups (or -1) are skipped
   int32_t g0 = 0, g1 = 0x7FFFFFFF;
-  const int32_t* rowlist; int64_t nlist;   // REASSIGN: optional list of rows to visit (picks[] is then indexed by list position)
+  const int32_t* rowlist; int64_t nlist;   // REASSIGN / EXPORT_Z: optional list of rows to visit (picks[] is then indexed by list position)
+  const int64_t* out_off = nullptr;        // with a row list: zout is COMPACT — the entries of list row i go to zout[out_off[i] ...] (tsem_rows_lookup)
   // REPORT: conf, exclude and average in ONE pass -> colsums[0..K), [K..2K), [2K..3K); best-hit counts -> nbest
   // REASSIGN without groups: the Hs most popular slots of every column part are summed in LDS per
   // workgroup and flushed once (global fp64 atomics: 22 G/s, 2 G/s on a popular column)
@@ -68,10 +74,12 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
   for (int t = threadIdx.x; t < A.lut_len; t += blockDim.x) lutS[t] = A.lut[t];
   for (int t = threadIdx.x; t < nhot; t += blockDim.x) hot[t] = 0.0;
   __syncthreads();
-  const int64_t n_visit = (MODE == RP_REASSIGN && A.rowlist) ? A.nlist : A.N;
+  const bool listed = (MODE == RP_REASSIGN || MODE == RP_EXPORT_Z) && A.rowlist;
+  const int64_t n_visit = listed ? A.nlist : A.N;
   for (int64_t idx = (int64_t)blockIdx.x * subs + sub; idx < n_visit; idx += (int64_t)gridDim.x * subs) {
-    const int64_t row = (MODE == RP_REASSIGN && A.rowlist) ? (int64_t)A.rowlist[idx] : idx;
+    const int64_t row = listed ? (int64_t)A.rowlist[idx] : idx;
     const int64_t s = A.indptr[row], e = A.indptr[row + 1];
+    const int64_t zo = (listed && A.out_off) ? A.out_off[idx] - s : 0;      // where entry k of this row goes in zout: k + zo
     const bool amb = (e - s) > 1;
     // one value of report column m (0 for a plain reassign) for column `col`: popular columns in LDS, the rest global
     auto emit = [&](int m, int col, uint32_t cm, double val, int64_t grp_off) {
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       cnt = sg_sum_i<RP_SUB>(cnt);
       if (MODE == RP_EXPORT_Z) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (vld[i]) A.zout[s + lane + i * RP_SUB] = inp[i] ? n[i] * r : -1.0;
+        for (int i = 0; i < 4; ++i) if (vld[i]) A.zout[s + lane + i * RP_SUB + zo] = inp[i] ? n[i] * r : -1.0;
         continue;
       }
       int nb = 0;
@@ -169,8 +177,8 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
           case TSEM_RA_ALL:     val = (inp[i] && z > 0.0) ? 1.0 : 0.0; break;
         }
         if (vld[i]) {
-          if (A.zout) A.zout[k] = val;
-          if (val != 0.0 && grp_off >= 0) {
+          if (A.zout) A.zout[k + zo] = val;
+          if (val != 0.0 && grp_off >= 0 && A.colsums) {
             const int col = A.indices[k];
             emit(0, col, nhot1 ? A.colmap[col] : 0xFFFFFFFFu, val, grp_off);
           }
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       for (int64_t k = s + lane; k < e; k += RP_SUB) {
         double n = numer(k);
         bool inpat = A.zin ? !isnan(n) : (initial || (n != 0.0));
-        A.zout[k] = inpat ? n * r : -1.0;   // -1 marks an entry the reference drops from z's pattern
+        A.zout[k + zo] = inpat ? n * r : -1.0;   // -1 marks an entry the reference drops from z's pattern
       }
       continue;
     }
@@ -265,8 +273,8 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
         case TSEM_RA_ALL:     val = (inpat && z > 0.0) ? 1.0 : 0.0; break;
       }
       if (valid) {
-        if (A.zout) A.zout[k] = val;
-        if (val != 0.0 && grp_off >= 0) {
+        if (A.zout) A.zout[k + zo] = val;
+        if (val != 0.0 && grp_off >= 0 && A.colsums) {
           const int col = A.indices[k];
           emit(0, col, nhot1 ? A.colmap[col] : 0xFFFFFFFFu, val, grp_off);
         }
@@ -1139,6 +1147,60 @@ int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const 
   TSEM_HIP(hipGetLastError());
   if (int rc = rowpass_lo_end(h, d_cs, d_lo, h->K)) return rc;
   TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  return TSEM_OK;
+}
+
+// z[ridx, fidx] and reassign(method)[ridx, fidx] for the entries of a LIST of rows — what Telescope.update_sam asks per alignment
+// (model.py:483,508-511) — without materialising the N x K matrices: two row passes over the listed rows only, compact outputs.
+// out_off[i] = where list row i's entries start in z_out / mask_out (out_off[n] = their total; the caller knows the row lengths:
+// it holds the CSR it loaded).  z_out: -1 where the reference drops the entry from z's pattern; mask_out: the assignment value.
+// picks[i] (choose): ordinal of the chosen best hit of list row i.
+int tsem_rows_lookup(tsem_ctx* h, int which, int method, double thresh, int64_t n, const int32_t* rows, const int32_t* picks,
+                     const int64_t* out_off, double* z_out, double* mask_out) {
+  if (!h || !h->d_indptr || n < 0 || (n && (!rows || !out_off)) || (!z_out && !mask_out)) return TSEM_ERR_ARG;
+  if (method < TSEM_RA_EXCLUDE || method > TSEM_RA_ALL) TSEM_FAIL(TSEM_ERR_ARG, "bad reassign method");
+  if (int rc = ensure_device(h)) return rc;
+  if (n == 0) return TSEM_OK;
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
+  const int64_t total = out_off[n];
+  for (int64_t i = 0; i < n; ++i)
+    if (rows[i] < 0 || rows[i] >= h->N || out_off[i] < 0 || out_off[i + 1] < out_off[i]) TSEM_FAIL(TSEM_ERR_ARG, "tsem_rows_lookup: bad row or offset");
+  int32_t *d_rows = nullptr, *d_picks = nullptr;
+  int64_t* d_off = nullptr;
+  double *d_z = nullptr, *d_m = nullptr;
+  uint32_t* d_bad = nullptr;
+  TSEM_SCOPED(d_rows); TSEM_SCOPED(d_picks); TSEM_SCOPED(d_off); TSEM_SCOPED(d_z); TSEM_SCOPED(d_m); TSEM_SCOPED(d_bad);
+  TSEM_ALLOC(d_rows, n); TSEM_ALLOC(d_off, n + 1); TSEM_ALLOC(d_bad, 1);
+  TSEM_HIP(hipMemcpyAsync(d_rows, rows, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemcpyAsync(d_off, out_off, sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipMemsetAsync(d_bad, 0, 4, h->stream));
+  k_check_offsets<<<cdiv64(n, 256), 256, 0, h->stream>>>(n, d_rows, d_off, h->d_indptr, d_bad);   // every row's slice holds exactly its entries
+  uint32_t bad = 0;
+  TSEM_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  if (bad) TSEM_FAIL(TSEM_ERR_ARG, "tsem_rows_lookup: out_off does not follow the listed rows' lengths");
+  if (method == TSEM_RA_CHOOSE && picks) {
+    TSEM_ALLOC(d_picks, n);
+    TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  }
+  A.rowlist = d_rows; A.nlist = n; A.out_off = d_off;
+  const int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + 15) / 16));
+  if (z_out) {
+    TSEM_ALLOC(d_z, total);
+    A.zout = d_z;
+    k_rowpass<RP_EXPORT_Z><<<grid, 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+    TSEM_HIP(hipGetLastError());
+    if (total) TSEM_HIP(hipMemcpyAsync(z_out, d_z, sizeof(double) * total, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (mask_out) {
+    TSEM_ALLOC(d_m, total);
+    A.zout = d_m; A.method = method; A.thresh = thresh; A.picks = d_picks; A.colsums = nullptr;
+    k_rowpass<RP_REASSIGN><<<grid, 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+    TSEM_HIP(hipGetLastError());
+    if (total) TSEM_HIP(hipMemcpyAsync(mask_out, d_m, sizeof(double) * total, hipMemcpyDeviceToHost, h->stream));
+  }
   TSEM_HIP(hipStreamSynchronize(h->stream));
   return TSEM_OK;
 }

@@ -549,6 +549,56 @@ class TelescopeLikelihood(object):
         self._groups_on_device = None
         return layers, n_groups
 
+    def lookup(self, ridx, fidx, method='exclude', thresh=0.9, initial=False, assignment=None):
+        """`(tl.z[ridx, fidx], tl.reassign(method, thresh)[ridx, fidx])` for arrays of (fragment, locus) pairs — what
+        `Telescope.update_sam` reads per alignment (model.py:483,508-511: `prob = tl.z[ridx, fidx]`, `mat[ridx, fidx] > 0`) — from
+        two device passes over the DISTINCT rows asked for, without materialising either N x K matrix (`tl.z` alone is 16 GB of
+        values at 2e9 stored entries).  `prob` is the z of the last E-step (0 where the pair is not in z's pattern), like `tl.z`;
+        `initial` only selects the z the ASSIGNMENT is made from.  Pass `assignment=tl.reassign('choose', ...)` to look up the
+        picks that object drew (a fresh `choose` draws its own, consuming the caller's RNG stream like `reassign`)."""
+        if method not in REASSIGN_METHODS:
+            raise ValueError('Argument "method" should be one of (exclude, choose, average, conf, unique, all)')
+        ridx = np.asarray(ridx, dtype=np.int64).ravel()
+        fidx = np.asarray(fidx, dtype=np.int64).ravel()
+        if ridx.shape != fidx.shape:
+            raise ValueError('ridx and fidx must have the same length')
+        if ridx.size and (ridx.min() < 0 or ridx.max() >= self.N or fidx.min() < 0 or fidx.max() >= self.K):
+            raise IndexError('index out of range')
+        which_a = self._which(initial)
+        which_z = self._which(False)
+        picks = None
+        if method == 'choose':
+            picks = assignment._args[3] if assignment is not None else self._picks(which_a)
+        r = self._need_raw()
+        rows, inv = np.unique(ridx, return_inverse=True)
+        lens = (r.indptr[rows + 1] - r.indptr[rows]).astype(np.int64)
+        off = np.zeros(len(rows) + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        pk = None
+        if picks is not None and len(picks[0]):                  # sparse (tied rows, picks) -> one pick per listed row
+            pk = np.zeros(len(rows), np.int32)
+            pos = np.searchsorted(picks[0], rows)
+            hit = (pos < len(picks[0])) & (np.asarray(picks[0])[np.minimum(pos, len(picks[0]) - 1)] == rows)
+            pk[hit] = np.asarray(picks[1])[pos[hit]]
+        eng = self._eng
+        if which_a == which_z:
+            z, m = eng.rows_lookup(method, thresh, which_a, rows, off, pk)
+        else:
+            z, _ = eng.rows_lookup(method, thresh, which_z, rows, off, None, want_mask=False)
+            _, m = eng.rows_lookup(method, thresh, which_a, rows, off, pk, want_z=False)
+        # the pair's position inside its row (CSR rows are sorted): a vectorised search over the rows' slices
+        key_q = inv.astype(np.int64) * self.K + fidx
+        cols = np.concatenate([r.indices[r.indptr[i]:r.indptr[i + 1]] for i in rows]) if len(rows) else np.zeros(0, np.int64)
+        key_e = np.repeat(np.arange(len(rows), dtype=np.int64), lens) * self.K + cols
+        pos = np.searchsorted(key_e, key_q)
+        found = (pos < len(key_e)) & (key_e[np.minimum(pos, max(len(key_e) - 1, 0))] == key_q) if len(key_e) else np.zeros(len(key_q), bool)
+        prob = np.zeros(len(ridx))
+        val = np.zeros(len(ridx))
+        zf = z[pos[found]]
+        prob[found] = np.where(zf < 0, 0.0, zf)                   # -1: dropped from z's pattern (an implicit zero of the CSR)
+        val[found] = m[pos[found]]
+        return prob, val.astype(_MASK_DTYPE[method])
+
     def reassign(self, method, thresh=0.9, initial=False):
         """model.py:808-865 — the assignment matrix.  Returned as an `Assignment`: `.sum(0)` (all the
         reference's `output_report` asks of it, model.py:435-457) is answered by one device pass over

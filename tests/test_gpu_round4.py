@@ -368,3 +368,71 @@ def test_any_number_of_loci(gpu_device):
     assert np.array_equal(tl.reassign_colsums('exclude'), np.asarray(om.reassign('exclude').sum(0)).ravel())
     assert np.allclose(tl.reassign_colsums('conf', 0.9), np.asarray(om.reassign('conf', 0.9).sum(0)).ravel(), rtol=RTOL, atol=1e-12)
     assert np.array_equal(tl.reassign_colsums('unique'), np.asarray(om.reassign('unique').sum(0)).ravel())
+
+
+# ---- z / assignment look-ups for update_sam without the N x K matrices ----------------------------------------
+
+@pytest.mark.parametrize('name', case_names(full_only=True))
+def test_lookups_for_update_sam_match_the_reference(gpu_device, name):
+    """`Telescope.update_sam` reads `tl.z[ridx, fidx]` and `mat[ridx, fidx]` per alignment (model.py:483,508-511).  `tl.lookup`
+    answers arrays of such pairs from two device passes over the distinct rows asked for (tsem_rows_lookup) — here EVERY stored
+    pair of the golden case plus pairs outside the pattern, all six methods, final and initial z: the posterior against the
+    reference's z, the assignment values against the reference's assignment matrices (integer modes exactly; `choose` with the
+    reference's RNG stream), and phred(prob) of helpers.py:14-37."""
+    import scipy.sparse as sp
+    from telescope_amd.likelihood import TelescopeLikelihood
+    c = load_case(name)
+    raw = case_matrix(c)
+    tl = TelescopeLikelihood(raw, Opts(c))
+    tl.em(use_likelihood=bool(c['use_likelihood']))
+    n, k = raw.shape
+    rows, cols = raw.nonzero()
+    rng = np.random.RandomState(3)
+    xr, xc = rng.randint(0, n, 200), rng.randint(0, k, 200)                      # mostly pairs that are NOT stored
+    ridx, fidx = np.concatenate([rows, xr]), np.concatenate([cols, xc])
+    perm = rng.permutation(len(ridx))                                            # any order, repeated rows
+    ridx, fidx = ridx[perm], fidx[perm]
+    zref = sp.csr_matrix((c['z_data'], c['z_indices'], c['z_indptr']), shape=raw.shape)
+    want_z = np.asarray(zref[ridx, fidx]).ravel()
+    for initial in (False, True):
+        for meth in ('exclude', 'choose', 'average', 'conf', 'unique', 'all'):
+            np.random.seed(int(c['seed']))
+            prob, val = tl.lookup(ridx, fidx, meth, 0.9, initial)
+            tag = 'ra_%s_%d_' % (meth, int(initial))
+            ref = sp.csr_matrix((c[tag + 'data'], c[tag + 'indices'], c[tag + 'indptr']), shape=raw.shape)
+            want = np.asarray(ref[ridx, fidx]).ravel()
+            assert np.allclose(prob, want_z, rtol=RTOL, atol=1e-300), (meth, initial)
+            if meth in ('average', 'conf'):
+                assert np.allclose(val, want, rtol=RTOL, atol=1e-12), (meth, initial)
+            else:
+                assert np.array_equal(val, want), (meth, initial)
+            assert str(val.dtype) == str(c[tag + 'dtype'])
+    # phred(prob) (helpers.py:14-37: -10 log10(1 - P)) — compared before the rounding to an integer, where the posterior leaves room for it:
+    # for P within 1e-6 of 1 the score hangs on the last bits of P in the reference itself
+    sel = want_z < 1.0 - 1e-6
+    assert np.allclose(-10 * np.log10(1 - prob[sel]), -10 * np.log10(1 - want_z[sel]), rtol=0, atol=1e-6)
+    assert np.array_equal(prob >= 1.0 - 1e-9, want_z >= 1.0 - 1e-9)              # phred 255 territory (P == 1.0 itself is a last-bit matter)
+    # the object `reassign` returned and the look-up agree on the picks `choose` drew
+    np.random.seed(7)
+    a = tl.reassign('choose', 0.9)
+    _, val = tl.lookup(ridx, fidx, 'choose', 0.9, assignment=a)
+    m = a.tocsr()
+    assert np.array_equal(val, np.asarray(m[ridx, fidx]).ravel())
+
+
+def test_lookups_at_scale(gpu_device):
+    """2M fragments x 30k loci: look-ups for 300 000 alignments spread over the matrix against the full export (`tl.z`, the full
+    assignment matrix), which this call exists to avoid."""
+    tl = _synthetic_tl(2_000_000, 30_000, 20, 'zipf', uniq=0.05, opts=Opts(max_iter=5, em_epsilon=0.0))
+    tl.em()
+    r = tl._need_raw()
+    rng = np.random.RandomState(5)
+    e = np.sort(rng.choice(r.nnz, 300_000, replace=False))
+    ridx = np.searchsorted(r.indptr, e, side='right') - 1
+    fidx = r.indices[e]
+    prob, val = tl.lookup(ridx, fidx, 'exclude', 0.9)
+    z = tl.z
+    assert np.allclose(prob, np.where(z.data[e] < 0, 0, z.data[e]) if z.nnz == r.nnz else np.asarray(z[ridx, fidx]).ravel(), rtol=1e-12, atol=0)
+    m = tl.reassign('exclude', 0.9).tocsr()
+    assert np.array_equal(val, np.asarray(m[ridx, fidx]).ravel())
+    assert val.sum() > 0.5 * len(e) / 20                                         # (a fair share of the sampled entries are best hits)
