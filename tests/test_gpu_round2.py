@@ -349,6 +349,29 @@ def test_config5_per_gpu_shard_properties(gpu_device):
         assert np.allclose(r[1], res[0][1], rtol=1e-10, atol=0) and np.array_equal(r[2], res[0][2])
 
 
+def test_config5_per_gpu_shard_against_the_c_oracle(gpu_device):
+    """Round 4: the same shard (25M x 50k x ~100, 2.5e9 stored entries — more than 2^31) against oracle/em_fused.c on all host cores
+    over the SAME matrix: pi, theta, pi_init and lnl to 1e-9, the per-locus `exclude` counts bit for bit, `conf` and `average` to
+    summation order — the last BASELINE configuration that had only properties at full size."""
+    from oracle import em_fused as oc
+    from telescope_amd._lib import Z_PREV
+    n, k = 25_000_000, 50_000
+    tl = _synthetic_tl(n, k, 100, 'zipf', uniq=0.02, opts=Opts(max_iter=3, em_epsilon=0.0))
+    tl.em()
+    ip, ix, rw = tl._eng.export_csr()
+    assert len(ix) > 2 ** 31
+    ref = oc.em_fused_arrays(ip, ix, rw, k, 0, 200000, 0.0, 3)
+    assert ref['n_iter'] == tl.n_iter == 3
+    assert abs(tl.lnl - ref['lnl']) <= RTOL * abs(ref['lnl'])
+    assert np.allclose(tl.pi, ref['pi'], rtol=RTOL, atol=0) and np.allclose(tl.theta, ref['theta'], rtol=RTOL, atol=0)
+    assert np.allclose(tl.pi_init, ref['pi_init'], rtol=RTOL, atol=0)
+    pp, tp = tl._eng.get_params(Z_PREV)
+    conf, excl, avg = oc.report_sums(ip, ix, rw, k, pp, tp, 0.9, False, max_score=tl.max_score)
+    assert np.array_equal(tl.reassign_colsums('exclude'), excl)
+    assert np.allclose(tl.reassign_colsums('conf', 0.9), conf, rtol=RTOL, atol=1e-9)
+    assert np.allclose(tl.reassign_colsums('average'), avg, rtol=RTOL, atol=1e-9)
+
+
 # ---------------------------------------------------------------------------------------------------
 # config 4 at FULL size against the C oracle
 # ---------------------------------------------------------------------------------------------------
