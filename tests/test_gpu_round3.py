@@ -235,7 +235,7 @@ def test_report_pass_falls_back_beyond_65536_slots(gpu_device, split):
     from telescope_amd import _lib
     from telescope_amd.likelihood import TelescopeLikelihood, score_lut
     rng = np.random.RandomState(5)
-    n, k = 20000, 70000
+    n, k = 8000, 70000
     lens = np.where(rng.rand(n) < 0.1, 1, rng.randint(2, 30, n))
     indptr = np.concatenate([[0], np.cumsum(lens)])
     indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
