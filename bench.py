@@ -310,7 +310,7 @@ def main():
     import logging
 
     def run(n):
-        # `TelescopeLikelihood.em()` itself (likelihood.py), n iterations at em_epsilon = 0: chunks of EM_CHUNK (16) iterations per host
+        # `TelescopeLikelihood.em()` itself (likelihood.py), n iterations at em_epsilon = 0: chunks of EM_CHUNK (32) iterations per host
         # synchronisation — pass, in-library RCCL all-reduce (N > 1 / --force-comm), update, the device-side convergence test (never
         # true at epsilon 0) — or, on the fall-back transport, one torch.distributed all-reduce and one host round trip per
         # iteration with the time-out recovery.  Only the log-likelihood pass AFTER the loop (model.py:800-801) is left out: a step

@@ -47,8 +47,9 @@ def score_lut(max_score, scale_factor=100., mantissa_bits=53):
     return q
 
 
-EM_CHUNK = 16     # iterations enqueued per host synchronisation (Engine.em_chunk decides convergence on the device; kernels behind the converging
-                  # iteration return at once: ~5 us each.  8 -> 16 in round 4: the synchronisation costs ~80 us, 2 % of a 0.45 ms shard iteration)
+EM_CHUNK = 32     # iterations enqueued per host synchronisation (Engine.em_chunk decides convergence on the device; kernels behind the converging
+                  # iteration return at once: ~4 us each).  8 -> 32 in round 4: a synchronisation costs ~0.1-0.2 ms of host time, 2-3 % of a
+                  # 20-iteration run of the 0.55 ms 8-GPU shard; a run that stops early pays at most 31 no-op iterations (~0.4 ms)
 
 
 class _NullComm(object):
