@@ -7,7 +7,7 @@ TAG=${1:-lds}; shift
 OUT=gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-precision-sweep $*"
+B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-precision-sweep --no-reproducible-leg $*"
 timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/lds -- $B > $OUT/lds.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/sq -- $B > $OUT/sq.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_ATOMIC_RETURN SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_LDS --kernel-trace --output-format csv -d $OUT/lds2 -- $B > $OUT/lds2.log 2>&1
