@@ -30,6 +30,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+# The parameters after W + K iterations of the DEFAULT workload (50M x 30k x ~40, zipf, seed 42, fp64 entries, 1 GPU), folded to the
+# three numbers of the `check` block — measured on MI355X (BENCH_r04.json: 25 iterations; profiles/r05_bench.json: 23).  The rows are
+# generated from their GLOBAL index, so N ranks hold the same matrix: a run at any N must reproduce them to summation order
+# (CHECK_RTOL).  `check.matches_n1` compares with the N = 1 run made in the same process when N > 1, with this table at N = 1.
+CHECK_RTOL = 1e-11
+EMBEDDED_CHECK = {
+    25: dict(pi_sum=0.9999999999999775, pi_weighted=0.05583806323813835, theta_weighted=0.49818481912061724),
+}
+PHASE_ITERS = 8         # iterations timed phase by phase (HIP events between the kernels) after the timed region
+
 
 class Opts(object):
     def __init__(self, max_iter, em_epsilon=0.0):
@@ -86,6 +96,8 @@ def parse():
     ap.add_argument('--fail-rank', type=int, default=-1,
                     help='TEST HOOK: the persistent kernel of this rank reports a hand-off time-out in its first EM pass (fused_dbg bit 5); '
                          'every rank must refuse to commit, this rank falls back to the two-pass kernels, all redo the iteration')
+    ap.add_argument('--no-n1-reference', action='store_true',
+                    help='N > 1: skip the N = 1 run of the whole problem on rank 0\'s GPU (speedup_vs_n1, check.matches_n1)')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the multi-rank code path (RCCL group, per-iteration all-reduce) even at world size 1')
     return ap.parse_args()
@@ -340,16 +352,83 @@ def main():
     if comm is not None:
         elapsed = float(comm.max_array(np.array([elapsed]))[0])
         nnz_total = int(comm.sum_array(np.array([float(nnz_local)]))[0])
+
+    # the parameters every rank now holds, folded to three numbers: the same for every N at strong scaling (the rows are generated
+    # from their GLOBAL index, so N ranks hold the same matrix) — what a run at N > 1 is checked against
+    wts = np.arange(1, args.cols + 1, dtype=np.float64) / args.cols
+
+    def fold(e, iterations):
+        pi_, theta_ = e.get_params()
+        return dict(iterations=iterations, pi_sum=float(pi_.sum()), pi_weighted=float(np.dot(pi_, wts)),
+                    theta_weighted=float(np.dot(theta_, wts)))
+
+    def same(a, b):
+        return all(abs(a[k] - b[k]) <= CHECK_RTOL * max(abs(b[k]), 1e-300) for k in ('pi_sum', 'pi_weighted', 'theta_weighted'))
+
+    check = fold(eng, args.warmup + args.steps) if rank == 0 else None
+
+    # ---- where an iteration's time goes: PHASE_ITERS more iterations on EVERY rank (the all-reduce is collective) with a HIP event at
+    # every phase boundary — pass | column reduce | all-reduce | update | gap to the next pass.  Outside the timed region; the events
+    # cost the stream a few microseconds each, so the phases add up to slightly more than `ms_per_step`.
+    eng.set_option('kernel_timing', 0)
+    eng.set_option('phase_timing', 1)
+    eng.phase_times(reset=True)
+    run(PHASE_ITERS)
+    fence()
+    phases = eng.phase_times(reset=True)
+    eng.set_option('phase_timing', 0)
+    eng.set_option('kernel_timing', args.kernel_timing)
     if rank != 0:
         _shutdown(comm)
         return
 
-    # the parameters every rank now holds, folded to three numbers: the same for every N at strong scaling (the rows are generated
-    # from their GLOBAL index, so N ranks hold the same matrix) — what a run at N > 1 can be checked against
-    pi_now, theta_now = eng.get_params()
-    wts = np.arange(1, args.cols + 1, dtype=np.float64) / args.cols
-    check = dict(iterations=args.warmup + args.steps, pi_sum=float(pi_now.sum()), pi_weighted=float(np.dot(pi_now, wts)),
-                 theta_weighted=float(np.dot(theta_now, wts)))
+    n1 = None
+    if world > 1 and args.scaling == 'strong' and not args.no_n1_reference:
+        # the N = 1 reference in THIS process: the whole problem on rank 0's GPU (it fits: 24 GB of entries), same options, same
+        # warm-up + steps, no communicator — its time is what `speedup_vs_n1` divides by, its parameters what `check.matches_n1`
+        # compares with.  (The other ranks have left; nothing here is collective.)
+        try:
+            e1 = Engine(local)
+            for k_, v_ in getattr(eng, 'options', {}).items():
+                if k_ not in ('row_offset', 'fused_dbg', 'phase_timing', 'kernel_timing', 'em_kernel'):
+                    e1.set_option(k_, v_)
+            e1.set_option('em_kernel', EMK_TWOPASS if args.one_device and args.em_kernel == 'auto' else
+                          {'auto': EMK_AUTO, 'twopass': EMK_TWOPASS, 'fused': EMK_FUSED}[args.em_kernel])
+            e1.set_option('kernel_timing', args.kernel_timing)
+            e1.generate(0, total_rows, args.cols, cdf, args.seed, dist_code, args.uniq_frac)
+            tl1 = TelescopeLikelihood.from_engine(e1, Opts(args.steps), None)
+            tl1.keep_kernel_timing = True
+            if args.warmup:
+                tl1.max_iter, tl1.epsilon = args.warmup, 0.0
+                tl1.em(loglev=logging.DEBUG, final_lnl=False)
+            e1.kernel_stats(reset=True)
+            e1.synchronize()
+            tl1.max_iter, tl1.epsilon = args.steps, 0.0
+            t1 = time.perf_counter()
+            tl1.em(loglev=logging.DEBUG, final_lnl=False)
+            e1.synchronize()
+            el1 = time.perf_counter() - t1
+            ks1 = e1.kernel_stats()
+            n1 = dict(ms_per_step=el1 / args.steps * 1e3, kernel_ms=ks1['em_ms'] / max(1, ks1['em_launches']),
+                      check=fold(e1, args.warmup + args.steps),
+                      how='the whole problem (%d rows) on rank 0\'s GPU in this process, same options, no communicator' % total_rows)
+            e1.close()
+            del tl1
+        except Exception as e:   # noqa: BLE001 — the reference leg must never cost the result line
+            n1 = dict(error=repr(e))
+    emb = EMBEDDED_CHECK.get(check['iterations']) if _is_default_workload(args, total_rows) else None
+    if n1 is not None and 'check' in n1:
+        check['matches_n1'] = same(check, n1['check'])
+        check['n1'] = n1['check']
+        check['matches_n1_how'] = 'against the N = 1 run of the same workload made in this process on rank 0\'s GPU, rtol %g' % CHECK_RTOL
+    elif emb is not None:
+        check['matches_n1'] = same(check, emb)
+        check['matches_n1_how'] = 'against the N = 1 values embedded in bench.py (EMBEDDED_CHECK), rtol %g' % CHECK_RTOL
+    else:
+        check['matches_n1'] = None
+        check['matches_n1_how'] = 'no N = 1 reference for this workload / iteration count'
+    if emb is not None:
+        check['matches_embedded'] = same(check, emb)
     whole = None
     if world == 1:
         # the same call as a user makes it: `steps` iterations and the final log-likelihood pass (model.py:800-801)
@@ -386,6 +465,10 @@ def main():
         'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'nnz_per_sec': nnz_total * args.steps / elapsed,
         'check': check,
+        'phase_us': dict(phases, how='HIP events at the phase boundaries of %d iterations AFTER the timed region (rank 0): EM pass kernel(s) | '
+                                     'k_colreduce | all-reduce of K+2 doubles | k_update | gap to the next pass' % PHASE_ITERS) if phases else None,
+        'n1_reference': n1,
+        'speedup_vs_n1': (n1['ms_per_step'] / (elapsed / args.steps * 1e3)) if (n1 and 'ms_per_step' in n1) else None,
         'timed_call': 'TelescopeLikelihood.em(final_lnl=False): chunks of %d iterations per host synchronisation' % EM_CHUNK,
         'whole_em_call': whole,
         'config': {
@@ -541,6 +624,11 @@ def reproducible_leg(device, rows, args, cdf, dist_code, iters=10):
                 form='one pass, three tables per part' if a[4] else 'two passes (three tables per part do not fit / rows too short for teams of 5-8)',
                 two_runs_bit_identical=bool((a[1] == b[1]).all() and (a[2] == b[2]).all()),
                 pi_max_rel_delta_vs_default=float(abs(a[1] - d[1]).max() / d[1].max()))
+
+
+def _is_default_workload(args, total_rows):
+    return (total_rows, args.cols, args.nnz_row, args.dist, args.uniq_frac, args.seed, args.value_format) == \
+        (50_000_000, 30_000, 40.0, 'zipf', 0.0, 42, 'f64') and args.em_kernel in ('auto', 'fused') and not args.fused_dbg
 
 
 def _pmc_traffic(total_rows, args, world, value_bytes):

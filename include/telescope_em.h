@@ -314,7 +314,8 @@ int  tsem_legacy_randint(uint32_t* key624, int32_t* pos, const int32_t* counts, 
  * [0, n_groups) or -1 (row in no group); out is row-major [n_groups][K], caller-allocated.
  * tsem_set_groups copies the map to the device once (range-checked there) — the six methods of a report
  * then pass group_of_row = NULL; a non-NULL map is set first.  The device computes the groups in tiles
- * of at most 1 GB of output (option "group_tile_bytes"), one pass over the matrix per tile: n_groups x K
+ * of at most 1 GB of device scratch (option "group_tile_bytes": the tile by column plus, for the streaming
+ * kernel, the same tile by id), one pass over the matrix per tile: n_groups x K
  * doubles only have to fit the caller's `out`.  exclude / average / conf (conf_prob > 0.5) stream the
  * 4-byte id + score-code arrays like tsem_report_colsums; the other methods take the generic row pass. */
 int  tsem_set_groups(tsem_ctx* h, const int32_t* group_of_row /* N, or NULL to drop */, int32_t n_groups);
@@ -336,6 +337,11 @@ int  tsem_csr_scale(int device, int mode, int64_t n_rows, int32_t n_cols, const 
  * algorithmic bytes one EM pass reads.  */
 int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launches,
                        int64_t* algo_bytes_per_pass);
+/* Option "phase_timing" = 1: tsem_em_chunk records a HIP event at every phase boundary of every iteration it enqueues (a
+ * diagnostic: ~5 events per iteration on the engine's stream).  ms6 = summed milliseconds over *n_iter iterations of
+ * { EM pass | column reduce | all-reduce of the K+2 sums (0 without a communicator) | update | gap to the next iteration's
+ * pass | first mark to last mark }.  What bench.py prints as `phase_us`. */
+int  tsem_phase_times(tsem_ctx* h, int reset, double* ms6, int64_t* n_iter);
 int  tsem_layout_info(tsem_ctx* h, int64_t* info32 /* 27 values written */);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);

@@ -192,6 +192,7 @@ def lib():
     L.tsem_csr_binmax_rows.argtypes = [C.c_int, i64, i32, vp, vp, vp]
     L.tsem_csr_scale.argtypes = [C.c_int, C.c_int, i64, i32, vp, vp, vp]
     L.tsem_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
+    L.tsem_phase_times.argtypes = [vp, C.c_int, vp, C.POINTER(i64)]
     L.tsem_layout_info.argtypes = [vp, vp]
     L.tsem_debug_fused_prof.argtypes = [vp, vp]
     L.tsem_debug_fused_startup.argtypes = [vp, vp]
@@ -513,6 +514,7 @@ class Engine(object):
 
     def set_groups(self, group_of_row, n_groups):
         """Row -> group map of the per-group sums, copied to the device once (None drops it)."""
+        self.groups_token = None          # whoever sets a map may tag it afterwards (TelescopeLikelihood: a digest of the grouping)
         if group_of_row is None:
             self._ck(self._L.tsem_set_groups(self._h, None, 0))
             return
@@ -527,6 +529,7 @@ class Engine(object):
         n, k, _ = self.dims()
         grp = None
         if group_of_row is not None:
+            self.groups_token = None      # the call replaces the resident map
             grp = np.ascontiguousarray(group_of_row, dtype=np.int32)
             if grp.shape != (n,):
                 raise ValueError('group_of_row must have one entry per row')
@@ -543,6 +546,16 @@ class Engine(object):
         ms, n, b = C.c_double(), C.c_int64(), C.c_int64()
         self._ck(self._L.tsem_kernel_stats(self._h, int(reset), C.byref(ms), C.byref(n), C.byref(b)))
         return dict(em_ms=ms.value, em_launches=n.value, algo_bytes_per_pass=b.value)
+
+    def phase_times(self, reset=False):
+        """Option 'phase_timing': mean microseconds per chunked iteration of pass / column reduce / all-reduce / update, the gap
+        to the next iteration, and first-to-last mark; None when nothing was timed."""
+        ms, n = np.zeros(6), C.c_int64()
+        self._ck(self._L.tsem_phase_times(self._h, int(reset), ptr(ms), C.byref(n)))
+        if n.value == 0:
+            return None
+        us = ms * 1e3 / n.value
+        return dict(iterations=int(n.value), **{k: float(v) for k, v in zip(('pass', 'colreduce', 'allreduce', 'update', 'gaps', 'iteration'), us)})
 
     def fused_prof(self):
         out = np.zeros((64, 16), np.uint64)

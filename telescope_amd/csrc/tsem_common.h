@@ -131,6 +131,7 @@ struct tsem_ctx {
   int64_t opt_lnl_fused = 0;        // option "use_likelihood" = 1: lay the matrix out so that the EM pass can sum the previous iteration's log-likelihood
                                     //    as well (fused kernel MODE 4: three tables per part in LDS, tsem_fused.h); tsem_em_chunk then needs no lnl pass per iteration
   bool lnl3 = false;                // the current layout allows it
+  bool lnl3_declined = false;       // tsem_prepare_likelihood asked once and the geometry said no (reset with the matrix)
   bool em_rows = false;             // K beyond 64 x 7680 columns: no blocked layout at all, the EM pass and the log-likelihood are plain CSR row passes
                                     // with global gathers and fp64 atomics (any K; slow: a completeness path, tsem_em.hip k_em_rows)
   int64_t n_single_part = 0;        // ambiguous rows with all their entries in one column part (layout statistic, tsem_layout_info[25])
@@ -215,6 +216,12 @@ struct tsem_ctx {
   tsem_comm* comm = nullptr;
 
   // ---- instrumentation ----
+  int64_t opt_phase = 0;            // option "phase_timing": HIP events between the phases of every iteration of tsem_em_chunk (tsem_phase_times)
+  std::vector<hipEvent_t> pev;      // TS_PHASE_MARKS events per iteration of the current chunk
+  std::vector<uint8_t> pev_set;     // ... which of them were recorded
+  int pev_iter = -1;                // iteration of the chunk being enqueued (-1: outside tsem_em_chunk, nothing is marked)
+  double phase_ms[6] = {0, 0, 0, 0, 0, 0};   // pass | column reduce | all-reduce | update | gap to the next iteration | first mark to last mark
+  int64_t phase_n = 0;              // iterations summed into phase_ms
   std::vector<hipEvent_t> ev;       // pairs
   size_t ev_used = 0;
   double em_ms_acc = 0;
@@ -222,6 +229,7 @@ struct tsem_ctx {
 };
 
 constexpr int TS_DIFF_RING = 65536;
+constexpr int TS_PHASE_MARKS = 5;   // before the pass | after it | after the column reduce | after the all-reduce | after the update
 constexpr int TS_PROF_WORDS = 64 * 16 + 512 * 8;   // option "fused_prof": per-step slots of team 0 + start-up stamps of up to 512 workgroups
 
 struct tsem_local_group;            // in-process transport: several handles on ONE device (tsem_comm_create_local)

@@ -476,6 +476,47 @@ static int begin_timing(tsem_ctx* h, hipEvent_t** pair) {
   return TSEM_OK;
 }
 
+// option "phase_timing": one HIP event per phase boundary of every iteration a chunk enqueues (tsem_em_chunk sets pev_iter and reads
+// the events back after its synchronisation).  Marks: 0 before the pass, 1 after it, 2 after the column reduce, 3 after the
+// all-reduce, 4 after the update.  A diagnostic (bench.py's `phase_us`): each event costs the stream a few microseconds.
+static int phase_mark(tsem_ctx* h, int k) {
+  if (h->opt_phase <= 0 || h->pev_iter < 0) return TSEM_OK;
+  const size_t idx = (size_t)h->pev_iter * TS_PHASE_MARKS + (size_t)k;
+  while (h->pev.size() <= idx) {
+    hipEvent_t e;
+    TSEM_HIP(hipEventCreate(&e));
+    h->pev.push_back(e);
+  }
+  if (h->pev_set.size() <= idx) h->pev_set.resize(idx + 1, 0);
+  TSEM_HIP(hipEventRecord(h->pev[idx], h->stream));
+  h->pev_set[idx] = 1;
+  return TSEM_OK;
+}
+// ... read back after the chunk's synchronisation: n iterations were enqueued (all of them ran unless the device stopped the chunk:
+// kernels behind a stop return at once, their phases then measure launch overhead only — callers time fixed-length chunks)
+static void phase_harvest(tsem_ctx* h, int n) {
+  if (h->opt_phase <= 0) return;
+  auto el = [&](size_t a, size_t b, double* out) -> bool {
+    if (a >= h->pev_set.size() || b >= h->pev_set.size() || !h->pev_set[a] || !h->pev_set[b]) return false;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->pev[a], h->pev[b]) != hipSuccess) return false;
+    *out = ms;
+    return true;
+  };
+  for (int i = 0; i < n; ++i) {
+    const size_t b = (size_t)i * TS_PHASE_MARKS;
+    double pass = 0, cr = 0, ar = 0, up = 0, tot = 0, gap = 0;
+    if (!el(b, b + 4, &tot)) continue;
+    if (!el(b, b + 1, &pass) || !el(b + 1, b + 2, &cr)) { pass = 0; cr = 0; (void)el(b, b + 2, &pass); }   // (no mark between pass and reduce)
+    (void)el(b + 2, b + 3, &ar);
+    (void)el(b + 3, b + 4, &up);
+    h->phase_ms[0] += pass; h->phase_ms[1] += cr; h->phase_ms[2] += ar; h->phase_ms[3] += up; h->phase_ms[5] += tot;
+    if (i + 1 < n && el(b + 4, b + TS_PHASE_MARKS, &gap)) h->phase_ms[4] += gap;
+    h->phase_n += 1;
+  }
+  std::fill(h->pev_set.begin(), h->pev_set.end(), 0);
+}
+
 // One launch of the persistent fused kernel.  mode 0: EM pass (column sums of w*z into d_fpartial);
 // mode 1: log-likelihood of the ambiguous rows (one partial per workgroup into d_lnl_part).
 static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
@@ -620,10 +661,19 @@ static bool lag_capable(const tsem_ctx* h) { return h->lnl3 && h->use_fused && h
 static int em_pass(tsem_ctx* h, bool lag);
 int tsem_em_pass(tsem_ctx* h) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
-  return em_pass(h, false);
+  h->pev_iter = h->opt_phase > 0 ? 0 : -1;                 // host-driven iterations (fall-back transports): marks 0-2 here, 3-4 in tsem_em_update
+  const int rc = em_pass(h, false);
+  h->pev_iter = -1;
+  return rc;
 }
 
+static int em_pass_impl(tsem_ctx* h, bool lag);
 static int em_pass(tsem_ctx* h, bool lag) {
+  if (int rc = phase_mark(h, 0)) return rc;
+  if (int rc = em_pass_impl(h, lag)) return rc;
+  return phase_mark(h, 2);
+}
+static int em_pass_impl(tsem_ctx* h, bool lag) {
   if (int rc = ensure_device(h)) return rc;
   if (h->opt_precision == 1) return em_pass_f32(h);
   hipEvent_t* pair = nullptr;
@@ -706,6 +756,7 @@ static int em_pass(tsem_ctx* h, bool lag) {
       if (int rc = launch_fused(h, 7, nullptr)) return rc;
       if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
       h->em_launches += 1;
+      if (int rc = phase_mark(h, 1)) return rc;
       k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
                                                               h->d_xflags, h->P, h->d_ctl,
                                                               reinterpret_cast<unsigned long long*>(h->d_xchg), (int64_t)h->fz_teams * FZ_XS * h->P * h->R,
@@ -716,6 +767,7 @@ static int em_pass(tsem_ctx* h, bool lag) {
     if (int rc = launch_fused(h, lag ? 4 : 0, pair)) return rc;
     if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
     h->em_launches += 1;
+    if (int rc = phase_mark(h, 1)) return rc;
     k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->fz_teams, h->d_fpartial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
                                                             h->d_xflags, h->P, h->d_ctl,
                                                             h->P > 1 ? reinterpret_cast<unsigned long long*>(h->d_xchg) : nullptr,
@@ -736,6 +788,7 @@ static int em_pass(tsem_ctx* h, bool lag) {
   }
   if (pair) TSEM_HIP(hipEventRecord(pair[1], h->stream));
   h->em_launches += 1;
+  if (int rc = phase_mark(h, 1)) return rc;
   if (h->nb > 0) {
     k_colreduce<<<cdiv64(h->Kpad, 32), 256, 0, h->stream>>>(h->Kpad, h->G2, h->d_partial, h->d_col_of_pc, h->d_colmap, h->d_red, h->K,
                                                             nullptr, h->P, h->d_ctl, nullptr, 0, nullptr, nullptr, 0);
@@ -853,12 +906,17 @@ int tsem_recover_timeout(tsem_ctx* h, int32_t* switched) {
 int tsem_em_update(tsem_ctx* h, double* diff_est) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
-  if (int rc = launch_update(h, h->d_diffs)) return rc;
+  h->pev_iter = h->opt_phase > 0 ? 0 : -1;
+  if (int rc = phase_mark(h, 3)) return rc;                // (whatever moved the reduce buffer between the pass and this call is the "all-reduce" phase)
+  if (int rc = launch_update(h, h->d_diffs)) { h->pev_iter = -1; return rc; }
+  if (int rc = phase_mark(h, 4)) return rc;
+  h->pev_iter = -1;
   h->first_pending = false;
   h->lag_valid = false;
   if (diff_est) {
     TSEM_HIP(hipMemcpyAsync(diff_est, h->d_diffs, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
+    phase_harvest(h, 1);
     // negative: the (all-reduced) error flag was up, so no rank committed this iteration
     if (*diff_est < 0.0)
       TSEM_FAIL(TSEM_ERR_TIMEOUT, "EM pass: the hand-off watchdog of the fused kernel fired on some rank; parameters "
@@ -990,10 +1048,14 @@ int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likeli
     }
     const bool owed_before = h->lag_valid;
     for (int i = 0; i < want; ++i) {
-      if (int rc = em_pass(h, lag)) return rc;
-      if (int rc = tsem_comm_allreduce_red(h, 0, h->K + 2)) return rc;
+      h->pev_iter = (h->opt_phase > 0 && i < 256) ? i : -1;
+      if (int rc = em_pass(h, lag)) { h->pev_iter = -1; return rc; }
+      if (int rc = tsem_comm_allreduce_red(h, 0, h->K + 2)) { h->pev_iter = -1; return rc; }
+      if (int rc = phase_mark(h, 3)) return rc;
       double* lag_slot = (lag && h->lag_valid) ? (base + i > 0 ? h->d_lnls + base + i - 1 : d_carry) : nullptr;
-      if (int rc = launch_update(h, h->d_diffs + base + i, true, epsilon, use_likelihood, lag_slot)) return rc;
+      if (int rc = launch_update(h, h->d_diffs + base + i, true, epsilon, use_likelihood, lag_slot)) { h->pev_iter = -1; return rc; }
+      if (int rc = phase_mark(h, 4)) return rc;
+      h->pev_iter = -1;
       h->first_pending = false;                            // (a failed first update is redone below with the flag restored)
       if (lag) h->lag_valid = true;
       else if (use_likelihood) {
@@ -1005,6 +1067,7 @@ int tsem_em_chunk(tsem_ctx* h, int32_t n_max, double epsilon, int32_t use_likeli
     uint32_t ctl[2] = {0, 0};
     TSEM_HIP(hipMemcpyAsync(ctl, h->d_ctl, 8, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
+    phase_harvest(h, std::min(want, 256));
     done = base + (int)ctl[1];
     lnl_pending = false;
     if (ctl[0] == 1u) {                                    // converged (lagged scheme: in the iteration committed last, whose lnl is known now)

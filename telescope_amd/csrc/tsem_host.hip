@@ -118,6 +118,7 @@ void tsem_free_matrix(tsem_ctx* h) {
   h->have_rowstats = h->have_model = false;
   h->N = h->nnz = 0; h->K = 0;
   h->max_code = -1;
+  h->lnl3_declined = false;
 }
 
 
@@ -158,6 +159,7 @@ void tsem_destroy(tsem_ctx* h) {
   tsem_free_matrix(h);
   dfree(h->d_diffs); dfree(h->d_lnl_part); dfree(h->d_maxcode); dfree(h->d_xerr);
   for (auto& ev : h->ev) (void)hipEventDestroy(ev);
+  for (auto& ev : h->pev) (void)hipEventDestroy(ev);
   delete h;
 }
 
@@ -187,6 +189,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "reproducible") h->opt_reproducible = v;
   else if (k == "em_precision") h->opt_precision = v;
   else if (k == "kernel_timing") h->opt_timing = v;
+  else if (k == "phase_timing") h->opt_phase = v;          // HIP events between the phases of every chunked iteration (tsem_phase_times); a diagnostic: ~5 events per iteration
   else if (k == "report_shortcuts") h->opt_shortcuts = v;
   else if (k == "rowpass_wgs") h->opt_rowpass_wgs = v;
   else if (k == "report_kernel") h->opt_report_kernel = v;   // 0: the generic row pass (k_rowpass<RP_REPORT>) instead of k_report_rows
@@ -423,6 +426,14 @@ int tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launche
   // + 2 B row weight code per row
   if (algo_bytes) *algo_bytes = h->nnz_amb * (h->fmt_code ? 6 : 12) + h->N_amb * 2;
   if (reset) { h->em_ms_acc = 0; h->em_launches = 0; h->em_timed = 0; }
+  return TSEM_OK;
+}
+
+int tsem_phase_times(tsem_ctx* h, int reset, double* ms6, int64_t* n_iter) {
+  if (!h) return TSEM_ERR_ARG;
+  if (ms6) for (int i = 0; i < 6; ++i) ms6[i] = h->phase_ms[i];
+  if (n_iter) *n_iter = h->phase_n;
+  if (reset) { for (double& v : h->phase_ms) v = 0.0; h->phase_n = 0; }
   return TSEM_OK;
 }
 

@@ -1248,10 +1248,11 @@ int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, cons
   const int K = h->K, IDN = h->Kpad;
   if (n_groups == 0 || K == 0) return TSEM_OK;
   const int64_t budget = h->opt_group_tile > 0 ? h->opt_group_tile : ((int64_t)1 << 30);
-  const int tile = (int)std::max<int64_t>(1, std::min<int64_t>(n_groups, budget / ((int64_t)K * 8)));
   const bool stream_ok = (method == TSEM_RA_EXCLUDE || method == TSEM_RA_AVERAGE || method == TSEM_RA_ALL || (method == TSEM_RA_CONF && thresh > 0.51)) &&
                          h->opt_report_kernel != 0 && which != TSEM_Z_USER && h->d_rid16 && h->d_col_of_id && A.lut_len > 0 &&
                          !h->opt_reproducible && h->N > 0;
+  // the budget covers BOTH copies of a tile the streaming kernel needs (by column for the caller, by id for the kernel)
+  const int tile = (int)std::max<int64_t>(1, std::min<int64_t>(n_groups, budget / (((int64_t)K + (stream_ok ? IDN : 0)) * 8)));
   // scratch kept between calls: the tile by column (what the caller gets) and, for the streaming kernel, the tile by id
   const size_t out_bytes = (size_t)tile * K * 8, id_bytes = stream_ok ? (size_t)tile * IDN * 8 : 0;
   if (h->gtile_bytes < out_bytes + id_bytes || !h->d_gtile) {
@@ -1303,8 +1304,9 @@ int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, cons
          gm == 4 ? (init ? k_report_slow<true, 4> : k_report_slow<false, 4>) : (init ? k_report_slow<true, 3> : k_report_slow<false, 3>);
     TSEM_HIP(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
     if (!h->d_rep_nb) { TSEM_ALLOC(h->d_rep_nb, h->N); TSEM_ALLOC(h->d_rep_rows, h->N); TSEM_ALLOC(h->d_rep_n, 1); }
+    // (d_rep_rows / d_rep_n are only scratch here: the tie list of the last tsem_report_colsums lives in its own d_tie_rows / d_tie_cnt,
+    //  which tsem_reassign_rows(rows = NULL) and `choose` still use after this call — ADVICE r4)
     R.defer_rows = h->d_rep_rows; R.defer_n = h->d_rep_n; R.group = h->d_group;
-    dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;   // (d_rep_rows was the last report's tie list)
   } else if (h->opt_reproducible) {
     TSEM_TMP(t_lo, out_bytes);
   }

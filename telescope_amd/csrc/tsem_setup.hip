@@ -1348,10 +1348,15 @@ int tsem_make_ctabs(tsem_ctx* h) {
 int tsem_prepare_likelihood(tsem_ctx* h) {
   if (!h || !h->have_model) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
-  if (h->lnl3 || !h->use_fused || h->nb == 0 || !lnl3_possible(h)) return TSEM_OK;
+  if (h->lnl3 || h->lnl3_declined || !h->use_fused || h->nb == 0 || !lnl3_possible(h)) return TSEM_OK;
   h->opt_lnl_fused = 1;
   TSEM_HIP(hipStreamSynchronize(h->stream));
   if (int rc = tsem_choose_geometry(h)) return rc;
+  if (!h->lnl3) {                                          // the geometry declined it (e.g. the split layout): nothing to rebuild, now or later
+    h->lnl3_declined = true;
+    h->opt_lnl_fused = 0;
+    return TSEM_OK;
+  }
   if (int rc = tsem_build_layout(h)) return rc;
   TSEM_ALLOC(h->d_ctab, h->Kpad); TSEM_ALLOC(h->d_ctab_prev, h->Kpad);
   TSEM_HIP(hipMemsetAsync(h->d_ctab, 0, sizeof(double) * h->Kpad, h->stream));

@@ -390,11 +390,15 @@ class TelescopeLikelihood(object):
         self._z, self._z_which = None, Z_PREV   # z of the last E-step, exported on demand
         self._report_cache = {}
         _con = 'converged' if converged else 'terminated'
-        if not use_likelihood and final_lnl:
-            self.lnl = eng.final_lnl() if chunked else self._device_lnl()
+        if not use_likelihood:
+            if final_lnl:
+                self.lnl = eng.final_lnl() if chunked else self._device_lnl()
+            else:
+                self.lnl = float('nan')          # not computed (never a stale value: the next em() would seed its lnl test with it)
         self.n_iter, self.converged = inum, converged
         lg.log(loglev, 'EM {:s} after {:d} iterations.'.format(_con, inum))
-        lg.log(loglev, 'Final log-likelihood: {:f}.'.format(self.lnl))
+        if use_likelihood or final_lnl:
+            lg.log(loglev, 'Final log-likelihood: {:f}.'.format(self.lnl))
         return
 
     def _device_lnl(self):
@@ -503,14 +507,15 @@ class TelescopeLikelihood(object):
             raise ValueError('Argument "method" should be one of (exclude, choose, average, conf, unique, all)')
         which = self._which(initial)
         picks = self._picks(which) if method == 'choose' else None
-        layers, n_groups = self._group_layers(group_rows)
+        layers, n_groups, digest = self._group_layers(group_rows)
         out = np.zeros((n_groups, self.K))
         for li, grp in enumerate(layers):
-            # the map of a layer goes to the device once and serves every method asked of it (a report asks for up to six)
-            key = (id(group_rows), n_groups, li)
-            if getattr(self, '_groups_on_device', None) != key:
+            # the map of a layer goes to the device once and serves every method asked of it (a report asks for up to six); the engine
+            # keeps the tag of the map it holds (dropped by anyone else's set_groups): the CONTENT of the grouping, not its identity
+            key = (digest, n_groups, li)
+            if getattr(self._eng, 'groups_token', None) != key:
                 self._eng.set_groups(grp, n_groups)
-                self._groups_on_device = key
+                self._eng.groups_token = key
             if li == 0:
                 self._eng.reassign_groups(method, thresh, which, None, n_groups, self._dense_picks(picks), out=out)
             else:
@@ -522,15 +527,18 @@ class TelescopeLikelihood(object):
 
     def _group_layers(self, group_rows):
         """Row -> group maps for `reassign_group_sums`, one per LAYER: within a layer every row belongs to at most one group; the
-        k-th listing of a row (over all groups, duplicates inside a group included) goes to layer k.  Built once per `group_rows`
-        object (vectorised: one stable sort of the listings)."""
-        cached = getattr(self, '_group_layer_cache', None)
-        if cached is not None and cached[0] is group_rows:
-            return cached[1], cached[2]
+        k-th listing of a row (over all groups, duplicates inside a group included) goes to layer k.  Built once per grouping
+        (vectorised: one stable sort of the listings)."""
+        import hashlib
         groups = [np.asarray(list(g) if not isinstance(g, np.ndarray) else g, dtype=np.int64) for g in group_rows]
         n_groups = len(groups)
         lens = np.array([len(g) for g in groups], dtype=np.int64)
         rows = np.concatenate(groups) if n_groups and lens.sum() else np.zeros(0, np.int64)
+        # keyed on the grouping's CONTENT (a caller may refill the same list object between two reports)
+        digest = hashlib.blake2b(lens.tobytes() + np.ascontiguousarray(rows).tobytes(), digest_size=16).hexdigest()
+        cached = getattr(self, '_group_layer_cache', None)
+        if cached is not None and cached[0] == digest:
+            return cached[1], cached[2], digest
         gid = np.repeat(np.arange(n_groups, dtype=np.int32), lens)
         keep = (rows >= 0) & (rows < self.N)
         rows, gid = rows[keep], gid[keep]
@@ -546,9 +554,8 @@ class TelescopeLikelihood(object):
             sel = rank == l
             grp[rs[sel]] = gs[sel]
             layers.append(grp)
-        self._group_layer_cache = (group_rows, layers, n_groups)
-        self._groups_on_device = None
-        return layers, n_groups
+        self._group_layer_cache = (digest, layers, n_groups)
+        return layers, n_groups, digest
 
     def lookup(self, ridx, fidx, method='exclude', thresh=0.9, initial=False, assignment=None):
         """`(tl.z[ridx, fidx], tl.reassign(method, thresh)[ridx, fidx])` for arrays of (fragment, locus) pairs — what

@@ -93,6 +93,24 @@ def test_bench_two_gpus_on_rccl(two_gpus, launcher):
     assert ('self' in two['config']['launcher']) == (launcher == 'self')
     _same_check(two, one, 8)
     assert two['value'] > 0 and two['config']['layout']['fallbacks'] == 0
+    _self_validating(two, 2)
+
+
+def _self_validating(line, n):
+    """What makes a scaling run diagnose itself: the line's own N = 1 reference (the whole problem on rank 0's GPU in
+    the same process) agrees with the N-rank parameters, the speed-up is quoted against it, the transport is the library's RCCL (a
+    silent fall-back to torch collectives turns this red, not just slow), and every phase of an iteration was timed."""
+    assert 'in-library RCCL all-reduce' in line['config']['parallelism'], line['config']['parallelism']
+    assert line['check']['matches_n1'] is True, line['check']
+    assert line['n1_reference'] and line['n1_reference']['check']['iterations'] == line['check']['iterations']
+    assert line['speedup_vs_n1'] and line['speedup_vs_n1'] > 0.5, line['speedup_vs_n1']     # (a 4M-row test matrix: start-up bound)
+    ph = line['phase_us']
+    assert ph and ph['iterations'] >= 4
+    for key in ('pass', 'colreduce', 'allreduce', 'update', 'gaps', 'iteration'):
+        assert ph[key] >= 0.0, (key, ph)
+    assert ph['pass'] > 0 and ph['allreduce'] > 0 and ph['update'] > 0, ph
+    assert abs(ph['pass'] + ph['colreduce'] + ph['allreduce'] + ph['update'] - ph['iteration']) <= 0.05 * ph['iteration'] + 5.0, ph
+    assert line['roofline']['frac'] > 0 and 'rank 0' in line['roofline']['kernel']
 
 
 def test_bench_on_every_gpu_of_the_box(two_gpus):
@@ -104,6 +122,7 @@ def test_bench_on_every_gpu_of_the_box(two_gpus):
     many, _ = _bench('all', _torchrun(n), ['--gpus', str(n)])
     assert many['n_gpus'] == n and many['config']['nnz'] == one['config']['nnz']
     _same_check(many, one, 8)
+    _self_validating(many, n)
 
 
 def test_time_out_on_one_rank_is_survived_by_all(two_gpus):

@@ -522,6 +522,15 @@ def test_bench_two_ranks_dry_run_on_one_gpu(gpu_device, launcher):
     for key in ('pi_sum', 'pi_weighted', 'theta_weighted'):
         assert abs(two['check'][key] - one['check'][key]) <= 1e-11 * abs(one['check'][key]), key
     assert two['value'] > 0 and two['ms_per_step'] > 0
+    # round 5: the line validates and diagnoses itself — its own N = 1 reference (whole problem on rank 0's GPU, same process) agrees
+    # with the two-rank parameters; the phases of an iteration were timed on rank 0 (here: the host-driven fall-back transport)
+    assert two['check']['matches_n1'] is True and two['n1_reference']['check']['iterations'] == 8, two['check']
+    assert two['speedup_vs_n1'] is not None and two['speedup_vs_n1'] > 0
+    for line in (one, two):
+        ph = line['phase_us']
+        assert ph and ph['iterations'] >= 4 and ph['pass'] > 0 and ph['update'] > 0, ph
+    assert two['phase_us']['allreduce'] > 0 and one['phase_us']['allreduce'] < 50.0
+    assert one['check']['matches_n1'] is None                      # (not the default workload: no embedded reference)
 
 
 def test_reproducible_one_pass_and_two_pass_forms(gpu_device):
