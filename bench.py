@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 CHECK_RTOL = 1e-11
 EMBEDDED_CHECK = {
     25: dict(pi_sum=0.9999999999999775, pi_weighted=0.05583806323813835, theta_weighted=0.49818481912061724),
+    23: dict(pi_sum=0.9999999999999775, pi_weighted=0.055838211628101916, theta_weighted=0.49818481973259593),
 }
 PHASE_ITERS = 8         # iterations timed phase by phase (HIP events between the kernels) after the timed region
 
@@ -435,6 +436,7 @@ def main():
         eng.set_option('kernel_timing', 0)
         tl.keep_kernel_timing = False
         eng.final_lnl()                     # (the first launch of the lnl kernel loads its code object: ~80 ms, once per process)
+        tl.max_iter, tl.epsilon = args.steps, 0.0
         w_ms = []
         for _ in range(2):                  # (twice: the first call after the timed region pays ~40 ms of one-off costs; both are reported)
             fence()
