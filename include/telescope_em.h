@@ -342,7 +342,7 @@ int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launch
  * { EM pass | column reduce | all-reduce of the K+2 sums (0 without a communicator) | update | gap to the next iteration's
  * pass | first mark to last mark }.  What bench.py prints as `phase_us`. */
 int  tsem_phase_times(tsem_ctx* h, int reset, double* ms6, int64_t* n_iter);
-int  tsem_layout_info(tsem_ctx* h, int64_t* info32 /* 27 values written */);
+int  tsem_layout_info(tsem_ctx* h, int64_t* info32 /* 28 values written */);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
 /* the same option's start-up timeline: per workgroup b (up to 512), out[8 b ..] = 100 MHz wall clock at entry / tickets counted /
@@ -357,6 +357,9 @@ int  tsem_debug_log1p(int device, int32_t n, const double* x, double* y);
 int  tsem_debug_stream_read(int device, int64_t bytes, int32_t reps, double* gbs);
 /* the same for the table-driven log1p of the fused lnl pass (64-entry table in LDS, ~1e-16 absolute error per evaluation) */
 int  tsem_debug_log1p_tab(int device, int32_t n, const double* x, double* y);
+/* ... and of the log-table form of the lnl passes (round 5): log1p(q c) from lq = log q and lc = log c — L + exp(-L) for
+ * L = lq + lc >= 18.715, 0 below -40, the table-driven log1p of the exact product q * c between */
+int  tsem_debug_log1p_of_log(int device, int32_t n, const double* lq, const double* lc, const double* q, const double* c, double* y);
 
 #ifdef __cplusplus
 }

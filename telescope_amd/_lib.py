@@ -198,6 +198,7 @@ def lib():
     L.tsem_debug_fused_startup.argtypes = [vp, vp]
     L.tsem_debug_log1p.argtypes = [C.c_int, C.c_int32, vp, vp]
     L.tsem_debug_log1p_tab.argtypes = [C.c_int, C.c_int32, vp, vp]
+    L.tsem_debug_log1p_of_log.argtypes = [C.c_int, C.c_int32, vp, vp, vp, vp, vp]
     L.tsem_debug_stream_read.argtypes = [C.c_int, i64, i32, C.POINTER(dbl)]
     L.tsem_debug_subblock.argtypes = [vp, C.c_int64, C.c_int32, vp, C.c_int64]
     for name in exported_symbols():
@@ -581,7 +582,7 @@ class Engine(object):
         self._ck(self._L.tsem_layout_info(self._h, ptr(info)))
         return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad', 'twin_cols',
                          'G1', 'G2', 'fused', 'slow_path', 'max_subblock', 'value_bytes', 'hot_cols',
-                         'lds_bytes', 'row_order', 'geometry', 'fallbacks', 'bin_repeats', 'reproducible', 'exact_single', 'lnl_fused', 'split', 'single_part_rows', 'row_pass_em'), info.tolist()))
+                         'lds_bytes', 'row_order', 'geometry', 'fallbacks', 'bin_repeats', 'reproducible', 'exact_single', 'lnl_fused', 'split', 'single_part_rows', 'row_pass_em', 'lnl_tables'), info.tolist()))
 
 
 def legacy_randint(counts):
@@ -682,6 +683,19 @@ def debug_log1p(x, device=0, table=False):
     rc = (lib().tsem_debug_log1p_tab if table else lib().tsem_debug_log1p)(device, len(x), ptr(x), ptr(y))
     if rc != OK:
         raise EngineError('tsem_debug_log1p failed (%d)' % rc)
+    return y
+
+
+def debug_log1p_of_log(q, c, device=0):
+    """log1p(q * c) as the log-table lnl passes form it from log q and log c (tsem_fused.h, fz_log1p_of_log)."""
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    with np.errstate(divide='ignore'):
+        lq, lc = np.log(q), np.log(c)
+    y = np.zeros_like(q)
+    rc = lib().tsem_debug_log1p_of_log(device, len(q), ptr(lq), ptr(lc), ptr(q), ptr(c), ptr(y))
+    if rc != OK:
+        raise EngineError('tsem_debug_log1p_of_log failed (%d)' % rc)
     return y
 
 

@@ -138,6 +138,12 @@ struct tsem_ctx {
   bool split = false;               // SPLIT layout (K > 8 x 7680 on the fused path): parts of up to 15 424 columns, one LDS table per pass — a row-sum pass and a
                                     // scatter pass per iteration (tsem_fused.h MODE 5 / 7), the log-likelihood over column halves (MODE 8)
   double* d_rinv = nullptr;         // [N_amb_pad] recip0(row sum) of the last MODE 4 pass (what the next one needs of its E-step)
+  // log tables of the log-likelihood passes (round 5): log1p(Q c) = log Q + log c + 1 / (Q c) for Q c >= 2^27 — one add and a table
+  // look-up instead of a logarithm per stored entry (tsem_fused.h, fz_lnl_term)
+  double* d_lctab = nullptr;        // [Kpad] log(pi * theta), permuted like d_ctab; rebuilt before every pass that reads it
+  double* d_lqtab = nullptr;        // [lq_n] log Q: per score code (code entries), or indexed by the top bits of Q (fp64 entries)
+  int lq_n = 0, lq_shift = 0, lq_base = 0;   // fp64 entries: index = (high word of Q >> lq_shift) - lq_base
+  bool lq_tried = false;            // the tables were attempted for this layout (lq_n == 0 afterwards: they do not fit / do not apply)
   bool lag_agreed = false;          // row-sharded runs: EVERY rank can run MODE 4 (decided once per run, dropped for good after a time-out anywhere)
   bool lag_valid = false;           // the iteration committed last still owes its lnl, and d_rinv / d_ctab_prev are what the next MODE 4 pass needs for it
   bool exact_single = false;        // reproducible: both pieces in ONE pass (three tables per part fit the LDS with <= 8 parts)

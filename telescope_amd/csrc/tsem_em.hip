@@ -517,6 +517,66 @@ static void phase_harvest(tsem_ctx* h, int n) {
   std::fill(h->pev_set.begin(), h->pev_set.end(), 0);
 }
 
+// ---- log tables of the log-likelihood passes (tsem_fused.h, fz_log1p_of_log) ----
+__global__ void k_log_tab(int n, const double* __restrict__ c, double* __restrict__ lc) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) lc[t] = log(c[t]);                            // log 0 = -inf: the kernel's "zero" range
+}
+// log Q, built once per layout and score table.  Code entries: one value per code.  fp64 entries: a direct-index table on the top bits
+// of Q — the fewest mantissa bits that keep the codes 1 .. max apart — provided it fits the LDS the layout leaves.  lq_n stays 0 when
+// the tables do not apply (no score table in LDS) or do not fit: the passes then evaluate the logarithm per entry as before.
+static int ensure_log_tables(tsem_ctx* h) {
+  if (h->lq_tried) return TSEM_OK;
+  h->lq_tried = true;
+  h->lq_n = 0;
+  const int fmt = fz_fmt(h);
+  if (fmt == 0 || !h->use_fused || h->split || h->lut_len <= 1 || (int)h->lut_host.size() != h->lut_len) return TSEM_OK;
+  const size_t room = (size_t)(TS_LDS_MAX - 1024) - fz_lds_bytes(h, true);
+  std::vector<double> tab;
+  if (fmt == 1) {
+    if ((size_t)h->lut_len * 8 > room) return TSEM_OK;
+    tab.resize(h->lut_len);
+    for (int i = 0; i < h->lut_len; ++i) tab[i] = std::log(h->lut_host[i]);   // (log 0 = -inf)
+    h->lq_shift = 0; h->lq_base = 0;
+  } else {
+    auto hi = [](double q) { int64_t b; std::memcpy(&b, &q, 8); return (int)(b >> 32); };
+    bool ok = false;
+    for (int bits = 0; bits <= 8 && !ok; ++bits) {
+      const int shift = 20 - bits;
+      int lo = INT32_MAX, top = INT32_MIN;
+      for (int i = 0; i < h->lut_len; ++i) {
+        const double q = h->lut_host[i];
+        if (!(q > 0.0) || !std::isfinite(q)) continue;
+        lo = std::min(lo, hi(q) >> shift); top = std::max(top, hi(q) >> shift);
+      }
+      if (lo > top) return TSEM_OK;
+      const int64_t n = (int64_t)top - lo + 1;
+      if (n <= 0 || (size_t)n * 8 > room) break;            // more bits only make it larger
+      std::vector<double> t((size_t)n, 0.0);
+      std::vector<uint8_t> used((size_t)n, 0);
+      bool unique = true;
+      for (int i = 0; i < h->lut_len && unique; ++i) {
+        const double q = h->lut_host[i];
+        if (!(q > 0.0) || !std::isfinite(q)) continue;
+        const int k = (hi(q) >> shift) - lo;
+        if (used[k] && t[k] != std::log(q)) unique = false;
+        used[k] = 1; t[k] = std::log(q);
+      }
+      if (unique) { tab.swap(t); h->lq_shift = shift; h->lq_base = lo; ok = true; }
+    }
+    if (!ok) return TSEM_OK;
+  }
+  TSEM_ALLOC(h->d_lqtab, tab.size());
+  TSEM_HIP(hipMemcpyAsync(h->d_lqtab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));               // (tab is a local)
+  fz_fn f9 = fz_kernel(h->P, 9, fmt, h->geo);
+  if (!f9) return TSEM_OK;
+  TSEM_HIP(hipFuncSetAttribute((const void*)f9, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+  TSEM_ALLOC(h->d_lctab, h->Kpad);
+  h->lq_n = (int)tab.size();
+  return TSEM_OK;
+}
+
 // One launch of the persistent fused kernel.  mode 0: EM pass (column sums of w*z into d_fpartial);
 // mode 1: log-likelihood of the ambiguous rows (one partial per workgroup into d_lnl_part).
 static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
@@ -527,6 +587,7 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
     if (h->P > 1) TSEM_HIP(hipMemsetAsync(h->d_xchg, 0, sizeof(double) * (size_t)h->fz_teams * FZ_XS * h->P * h->R, h->stream));
   }
   h->fz_clean = false;
+  int kmode = mode;                                        // the instantiation launched (9 = mode 1 with log tables)
   if (mode == 1 || mode == 8)                              // teams that do not form write nothing
     TSEM_HIP(hipMemsetAsync(h->d_lnl_part + (mode == 8 ? (size_t)bin * h->fz_grid : 0), 0, sizeof(double) * (size_t)h->fz_grid, h->stream));
   FusedArgs A;
@@ -545,9 +606,20 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
   A.ebias = h->d_ebias; A.bin = bin; A.ovf = h->d_ovf; A.partial2 = h->d_fpartial2;
 
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
-  const size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
+  size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
+  A.lctab = nullptr; A.lqtab = nullptr; A.lq_n = 0; A.lq_shift = 0; A.lq_base = 0;
+  if (mode == 1 && !(h->opt_dbg & 8192)) {                  // (fused_dbg bit 13: the per-entry logarithm, for A/B timing and tests)
+    if (int rc = ensure_log_tables(h)) return rc;
+    if (h->lq_n > 0) {
+      k_log_tab<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->d_ctab, h->d_lctab);
+      TSEM_HIP(hipGetLastError());
+      A.lctab = h->d_lctab; A.lqtab = h->d_lqtab; A.lq_n = h->lq_n; A.lq_shift = h->lq_shift; A.lq_base = h->lq_base;
+      ldsf += (size_t)h->lq_n * 8;
+      kmode = 9;
+    }
+  }
   if ((lnl || mode == 8) && h->fz_grid > 2048) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: more workgroups than partial slots");
-  fz_fn fn = fz_kernel(h->P, mode, fz_fmt(h), h->geo);
+  fz_fn fn = fz_kernel(h->P, kmode, fz_fmt(h), h->geo);
   if (!fn) TSEM_FAIL(TSEM_ERR_ARG, mode >= 2 ? "reproducible mode needs the fused kernel with a score table of at most 2048 entries"
                                                : "fused kernel supports at most 8 column parts");
   if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets

@@ -125,6 +125,10 @@ struct FusedArgs {
   int Kh, koff;           // MODE 8: columns per half, first local column of this launch's half
   double* ypart;          // MODE 5: [P][N_amb_pad] partial row sums
   int lag;                // 0: rinv holds nothing yet (first pass of a run): the lnl partials of this launch are zero
+  // log tables (round 5; MODE 1 and MODE 4 with the score table in LDS): log1p(Q c) = log Q + log c + 1 / (Q c) wherever Q c >= 2^27
+  const double* lctab;    // [P*Kp] log(pi * theta) of the parameters whose log1p the pass takes (MODE 1: takes ctab2's place in LDS; MODE 4: a fourth table)
+  const double* lqtab;    // [lq_n] log Q — FMT 1: per score code; FMT 2: index = (high word of Q >> lq_shift) - lq_base
+  int lq_n, lq_shift, lq_base;   // lq_n == 0: no log tables, every term goes through fz_log1p_tab
   int dbg;              // bit0: skip partner loads (timing experiments only; wrong results)
                         // bit5 / bit6: behave like a hand-off time-out in the EM / lnl pass (tests of the recovery path)
   unsigned long long* prof;   // optional per-step timestamps of team 0 / member 0
@@ -243,6 +247,37 @@ __device__ __forceinline__ double fz_log1p_tab(double x, const double2* __restri
   return fma(dk, ln2_hi, t.y + fma(r, p, fma(dk, ln2_lo, cerr)));
 }
 
+// log1p(x) for x = Q c given L = log Q + log c (both from tables: a score has a few hundred distinct values, a part a few thousand
+// columns; 2e9 logarithms per pass become 2e9 additions).  Three ranges of L:
+//   L >= 18.715 (x >= 2^27): log1p(x) = L + 1/x - 1/(2 x^2) + ..., the third term is below 2.8e-17.  1/x = exp(-L) needs a RELATIVE
+//     accuracy of 1e-7 to be right to 1e-16 absolute: fp32 (v_exp_f32 of an fp32 product; 18.7 <= L: no overflow, flushes to 0 beyond 87);
+//   L < -40 (x < 4.3e-18): log1p(x) = x - ... is below 4.3e-18 — absolute accuracy is what a SUM of z * log1p with terms of 20-100
+//     needs: 0 (this is also where a column with pi * theta == 0 lands: log 0 = -inf);
+//   between (a column that is dying under a zero prior passes through here for a few dozen iterations): the table-driven log1p of
+//     the exact x, which the caller produces on demand (`exact_x()`: the numerator it holds, or Q times a pi*theta fetched from
+//     global memory).  A wave-uniform branch: no lane of a wave takes it in the bench workload, few waves do on converged real data
+//     (Q >= e^46 for alignment scores: x < 2^27 needs pi * theta < 1e-12).  (exp(L) instead of the fetch: the inlined fp64 exp,
+//     four times per lane, spilled 116 VGPRs in the fp64-entry kernel.)
+constexpr double FZ_L_FAST = 18.715, FZ_L_ZERO = -40.0;
+template <bool CERR, class F>
+__device__ __forceinline__ double fz_log1p_of_log(double L, F&& exact_x, const double2* __restrict__ tab) {
+  double v = L + (double)__expf(-(float)L);                // (L = -inf: NaN, replaced below)
+  const bool slow = L < FZ_L_FAST;                         // ONE compare on the fast path; everything else hides behind the wave-uniform branch
+  if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {
+    const bool mid = slow & (L >= FZ_L_ZERO);
+    if (slow) v = 0.0;
+    if (__builtin_amdgcn_ballot_w64(mid) != 0ull) {
+      if (mid) v = fz_log1p_tab<CERR>(exact_x(), tab);
+    }
+  }
+  return v;                                                // always finite: callers need no `z != 0` guard (0 * v = 0)
+}
+// FMT 2 (fp64 entries, score table in LDS): log Q from Q's top bits — the host proved the index unique over the score table
+__device__ __forceinline__ double fz_logq_of(double q, const double* __restrict__ lqS, int lq_n, int lq_shift, int lq_base) {
+  const unsigned idx = (unsigned)((__double2hiint(q) >> lq_shift) - lq_base);
+  return lqS[min(idx, (unsigned)(lq_n - 1))];              // (Q = 0, the padding: some finite entry; its z is 0)
+}
+
 struct FzRegs {            // 4 entries per thread: 12 VGPRs (FMT 1: 6 until phase 1 turns the codes into numerators)
   uint4 rc;
   double2 v0, v1;
@@ -264,6 +299,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
   constexpr int FZ_RP = fz_rp(GEO);
   constexpr int FZ_YR = fz_yr(GEO);
   constexpr bool OWNREG = GEO == 3;                            // own partial sums travel in registers from publish to combine
+  constexpr bool LNL1 = MODE == 1 || MODE == 9;                // the dedicated log-likelihood pass (9: with log tables, see fz_log1p_of_log)
   constexpr bool SPA = MODE == 5;                              // split layout: row-sum pass (the partial sums go to A.ypart, no exchange)
   constexpr bool SPS = MODE == 7 || MODE == 8;                 // split layout: no exchange, the s ring is staged from A.rinv
   constexpr bool NOX = SPA || SPS;
@@ -308,7 +344,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
       for (int j = 0; j < FZ_RP; ++j)
         g.rpv[j] = fz_as_double2(__builtin_amdgcn_raw_buffer_load_b128(rr, (unsigned)(rlo + 2 * (lane + 64 * j)) * 8, 0, 0));
     }
-    if (MODE != 1 && !NOX) {                                    // row weights (the lnl pass uses w = 1)
+    if (!LNL1 && !NOX) {                                        // row weights (the lnl pass uses w = 1)
       if (FMT != 0) {
         __amdgpu_buffer_rsrc_t wr = fz_rsrc(A.wcode, blk * R * 2, kv ? (unsigned)R * 2 : 0);
 #pragma unroll
@@ -406,7 +442,7 @@ __device__ __forceinline__ void fz_xchg(const FusedArgs& A, const FzX& X) {
           ys1 += __longlong_as_double((long long)v.y);
         }
         double2 w = make_double2(1.0, 1.0);
-        if (MODE != 1) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
+        if (!LNL1) w = FMT != 0 ? make_double2(X.lut[g.wc[j] & 0xFFFFu], X.lut[g.wc[j] >> 16]) : g.w[j];
         // z = n * recip0(rowsum) (sparse_plus.py:52), weighted by w_i (model.py:730).  (The exchange wave computes 4-6 of these IEEE
         // divisions per lane and step, on the critical path of a short-row step.  v_rcp_f64 + two fma-corrected Newton steps
         // instead: -3 % at 10 entries per row, -1.5 % at 40 with score codes when written without any special-case handling;
@@ -548,6 +584,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   const int Kp = A.Kp, R = A.R;
   constexpr bool EXACT = MODE == 2 || MODE == 3;   // option "reproducible"
   constexpr bool LAG = MODE == 4;                  // EM pass + the log-likelihood of the previous iteration
+  constexpr bool LNL1 = MODE == 1 || MODE == 9;    // the dedicated log-likelihood pass; MODE 9: log tables in LDS (score table in LDS: FMT 1, 2)
   constexpr bool SPA = MODE == 5, SPB = MODE == 7, SPL = MODE == 8;   // split layout (see FusedArgs): ONE table of Kp entries, or two of Kh
   const int KT = SPL ? A.Kh : Kp;                  // entries per LDS table
   double* c = reinterpret_cast<double*>(smem);
@@ -566,7 +603,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   // zeroed / tables loaded / loop start / loop end / exit, behind the per-step slots of team 0
   unsigned long long* const sprof = (A.prof && tid == 0) ? A.prof + 64 * FZ_PROF_SLOTS + (size_t)blockIdx.x * 8 : nullptr;
   if (sprof) sprof[0] = wall_clock64();
-  if (A.dbg & ((MODE != 1 && MODE != 8) ? 32 : 64)) {     // test hook: what a watchdog time-out leaves behind
+  if (A.dbg & ((!LNL1 && MODE != 8) ? 32 : 64)) {     // test hook: what a watchdog time-out leaves behind
     if (blockIdx.x == 0 && tid == 0) atomicOr(err, 2u);
     return;
   }
@@ -593,9 +630,14 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   if (FMT != 0)
     for (int t = tid; t < A.lut_len; t += FZ_NT) lutS[t] = A.lut[t];
   uint16_t* const eS = reinterpret_cast<uint16_t*>(lutS + A.lut_len);   // MODE 2: [Kp] the slots' exponent bounds
-  // MODE 1: [FZ_LOGTAB] (1 / c_i, log c_i) for fz_log1p_tab, in the same place (the two modes never share a launch)
-  double2* const logtab = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(lutS + A.lut_len) + 15) & ~(uintptr_t)15);
-  if ((MODE == 1 || LAG || SPL) && tid < FZ_LOGTAB) {
+  // MODE 1 / 4 with log tables: log Q behind the score table [lq_n]
+  constexpr bool LT = MODE == 9;
+  double* const lqS = lutS + A.lut_len;
+  if (LT)
+    for (int t = tid; t < A.lq_n; t += FZ_NT) lqS[t] = A.lqtab[t];
+  // MODE 1: [FZ_LOGTAB] (1 / c_i, log c_i) for fz_log1p_tab, in the same place as MODE 2's table (the two modes never share a launch)
+  double2* const logtab = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(lutS + A.lut_len + (LT ? A.lq_n : 0)) + 15) & ~(uintptr_t)15);
+  if ((LNL1 || LAG || SPL) && tid < FZ_LOGTAB) {
     const double ci = 1.0 + (double)tid * (1.0 / FZ_LOGTAB);
     logtab[tid] = make_double2(1.0 / ci, ts_log1p_pos((double)tid * (1.0 / FZ_LOGTAB)));
   }
@@ -612,8 +654,10 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   } else if (!SPB) {
     for (int t = tid; t < Kp; t += FZ_NT) c[t] = A.ctab[p * Kp + t];
   }
-  if (MODE == 1)
-    for (int t = tid; t < Kp; t += FZ_NT) acc[t] = A.ctab2[p * Kp + t];
+  if (LNL1) {                                              // the table the log1p is taken of: pi*theta of the current parameters, or its logarithm
+    const double* const src = LT ? A.lctab : A.ctab2;
+    for (int t = tid; t < Kp; t += FZ_NT) acc[t] = src[p * Kp + t];
+  }
   if (LAG)
     for (int t = tid; t < Kp; t += FZ_NT) cprev[t] = A.ctab2[p * Kp + t];
   if (EXACT)
@@ -722,7 +766,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
     // A lane whose quad is all zeros (past the end of the sub-block, or a step without a block) marks
     // itself idle in rc.x and skips both phases: zeros added to y[0] / acc[0] by every idle lane
     // would serialise on one LDS address.
-    constexpr bool lnl = MODE == 1 || SPL;
+    constexpr bool lnl = LNL1 || SPL;
     auto phase1 = [&](FzRegs& rr, int64_t k) {
       const bool idle = FMT == 1 ? (rr.cd.x | rr.cd.y) == 0u
                                  : (rr.v0.x == 0.0) & (rr.v0.y == 0.0) & (rr.v1.x == 0.0) & (rr.v1.y == 0.0);
@@ -768,6 +812,40 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
           const double z = (q * c[rc & 0xFFFF]) * sb[rc >> 16];
           if (z != 0.0) lsum += z * fz_log1p_tab(q * acc[rc & 0xFFFF], logtab);
         };
+        if constexpr (LT) {
+          // log tables: acc[] holds log(pi*theta) of the current parameters, lqS[] log Q: an addition instead of a logarithm per
+          // entry.  The gathers of several entries first — one LDS round trip (each term ends in a wave-uniform branch, across which
+          // the compiler moves no load: term by term it was four round trips) — then their arithmetic: all four entries with score
+          // codes, two and two with fp64 entries (whose six register sets of 12 leave no room for four: 56 VGPRs spilled).
+          const double* const cg = A.ctab2 + p * Kp;     // pi*theta of the current parameters in global memory (the rare range only)
+          auto pair = [&](double qa, double qb, double la, double lb, uint32_t rca, uint32_t rcb) {
+            const uint32_t ja = rca & 0xFFFF, jb = rcb & 0xFFFF;
+            const double za = (qa * c[ja]) * sb[rca >> 16], zb = (qb * c[jb]) * sb[rcb >> 16];
+            const double La = la + acc[ja], Lb = lb + acc[jb];
+            __builtin_amdgcn_sched_barrier(0);
+            lsum = fma(za, fz_log1p_of_log<true>(La, [&]() { return qa * cg[ja]; }, logtab), lsum);   // (always finite; padding has z = 0)
+            lsum = fma(zb, fz_log1p_of_log<true>(Lb, [&]() { return qb * cg[jb]; }, logtab), lsum);
+          };
+          if (FMT == 1) {
+            const uint32_t k0 = rr.cd.x & 0xFFFFu, k1 = rr.cd.x >> 16, k2 = rr.cd.y & 0xFFFFu, k3 = rr.cd.y >> 16;
+            const uint32_t j0 = rr.rc.x & 0xFFFF, j1 = rr.rc.y & 0xFFFF, j2 = rr.rc.z & 0xFFFF, j3 = rr.rc.w & 0xFFFF;
+            const double q0 = lutS[k0], q1 = lutS[k1], q2 = lutS[k2], q3 = lutS[k3];
+            const double z0 = (q0 * c[j0]) * sb[rr.rc.x >> 16], z1 = (q1 * c[j1]) * sb[rr.rc.y >> 16];
+            const double z2 = (q2 * c[j2]) * sb[rr.rc.z >> 16], z3 = (q3 * c[j3]) * sb[rr.rc.w >> 16];
+            const double L0 = lqS[k0] + acc[j0], L1 = lqS[k1] + acc[j1], L2 = lqS[k2] + acc[j2], L3 = lqS[k3] + acc[j3];
+            __builtin_amdgcn_sched_barrier(0);
+            lsum = fma(z0, fz_log1p_of_log<true>(L0, [&]() { return q0 * cg[j0]; }, logtab), lsum);
+            lsum = fma(z1, fz_log1p_of_log<true>(L1, [&]() { return q1 * cg[j1]; }, logtab), lsum);
+            lsum = fma(z2, fz_log1p_of_log<true>(L2, [&]() { return q2 * cg[j2]; }, logtab), lsum);
+            lsum = fma(z3, fz_log1p_of_log<true>(L3, [&]() { return q3 * cg[j3]; }, logtab), lsum);
+          } else {
+            pair(rr.v0.x, rr.v0.y, fz_logq_of(rr.v0.x, lqS, A.lq_n, A.lq_shift, A.lq_base), fz_logq_of(rr.v0.y, lqS, A.lq_n, A.lq_shift, A.lq_base),
+                 rr.rc.x, rr.rc.y);
+            pair(rr.v1.x, rr.v1.y, fz_logq_of(rr.v1.x, lqS, A.lq_n, A.lq_shift, A.lq_base), fz_logq_of(rr.v1.y, lqS, A.lq_n, A.lq_shift, A.lq_base),
+                 rr.rc.z, rr.rc.w);
+          }
+          return;
+        }
         if (FMT == 1) {
           term(lutS[rr.cd.x & 0xFFFFu], rr.rc.x); term(lutS[rr.cd.x >> 16], rr.rc.y);
           term(lutS[rr.cd.y & 0xFFFFu], rr.rc.z); term(lutS[rr.cd.y >> 16], rr.rc.w);
@@ -970,7 +1048,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       ++i;
     };
     auto step = [&](FzRegs& rs, FzRegs& rp) {
-      if (MODE == 1 || SPL) step_lnl(rs, rp); else step_em(rs, rp);
+      if (LNL1 || SPL) step_lnl(rs, rp); else step_em(rs, rp);
     };
     load_blk(r0, offs[0], offs[1], 0);
     load_blk(r1, offs[2], offs[3], 1);
@@ -999,7 +1077,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   }
   __syncthreads();
   if (sprof) sprof[5] = wall_clock64();
-  if (MODE == 1 || LAG || SPL) {                          // one partial per workgroup, summed by k_sum_parts / k_colreduce
+  if (LNL1 || LAG || SPL) {                               // one partial per workgroup, summed by k_sum_parts / k_colreduce
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
     double* wsum = y;                                     // the y ring is idle now
     if ((tid & 63) == 0) wsum[tid >> 6] = lsum;
@@ -1009,7 +1087,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       for (int w = 0; w < FZ_NT / 64; ++w) t += wsum[w];
       A.lnl_out[team * P + p] = t;
     }
-    if (MODE == 1 || SPL) return;
+    if (LNL1 || SPL) return;
   }
   if (SPA) return;                                        // the row factors are in A.rinv; no column sums from this pass
 #ifdef FZ_EXPERIMENT

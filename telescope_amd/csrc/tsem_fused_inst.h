@@ -27,6 +27,11 @@ template <int P, int GEO> static fz_fn fz_pick2(int mode, int fmt) {
     return nullptr;
 #endif
   }
+  if (mode == 9) {                                         // the log-likelihood pass with log tables: needs the score table in LDS
+    if (fmt == 1) return k_em_fused<P, 9, 1, GEO>;
+    if (fmt == 2) return k_em_fused<P, 9, 2, GEO>;
+    return nullptr;
+  }
   if (mode >= 2) {                                         // exact (binned) column sums: needs the score table in LDS (formats 1, 2)
 #ifdef TSEM_NO_REPRO
     return nullptr;

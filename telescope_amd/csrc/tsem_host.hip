@@ -97,6 +97,7 @@ void tsem_free_layout(tsem_ctx* h) {
   dfree(h->d_ebias); dfree(h->d_ovf); dfree(h->d_red_hi); dfree(h->d_binflag); dfree(h->d_ehist);
   dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_rid16); dfree(h->d_col_of_id); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_pcode); dfree(h->d_prc);
   dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fz_aux); h->fz_clean = false; dfree(h->d_fpartial); dfree(h->d_fpartial2); dfree(h->d_amb_w); dfree(h->d_sb_q32); dfree(h->d_rinv); h->lag_valid = false;
+  dfree(h->d_lctab); dfree(h->d_lqtab); h->lq_n = 0; h->lq_tried = false;
   h->fused_launched = false;
 }
 void tsem_free_matrix(tsem_ctx* h) {
@@ -220,6 +221,7 @@ static int set_lut(tsem_ctx* h, const double* lut, int32_t lut_len) {
   h->lut_len = lut_len;
   dfree(h->d_lut32); dfree(h->d_c32); dfree(h->d_cs32);      // (the fp32 diagnostic tables follow the score table)
   h->lut_host.assign(lut, lut + lut_len);
+  dfree(h->d_lqtab); h->lq_n = 0; h->lq_tried = false;       // (log Q follows the score table)
   TSEM_ALLOC(h->d_lut, lut_len);
   TSEM_HIP(hipMemcpy(h->d_lut, lut, sizeof(double) * lut_len, hipMemcpyHostToDevice));
   return TSEM_OK;
@@ -493,6 +495,32 @@ int tsem_debug_log1p_tab(int device, int32_t n, const double* x, double* y) {
   return e == hipSuccess ? TSEM_OK : TSEM_ERR_HIP;
 }
 
+__global__ void k_log1p_of_log_probe(int n, const double* lq, const double* lc, const double* q, const double* c, double* y) {
+  __shared__ double2 tab[FZ_LOGTAB];
+  if (threadIdx.x < FZ_LOGTAB) {
+    const double ci = 1.0 + (double)threadIdx.x * (1.0 / FZ_LOGTAB);
+    tab[threadIdx.x] = make_double2(1.0 / ci, ts_log1p_pos((double)threadIdx.x * (1.0 / FZ_LOGTAB)));
+  }
+  __syncthreads();
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = fz_log1p_of_log<true>(lq[i] + lc[i], [&]() { return q[i] * c[i]; }, tab);
+}
+/* log1p(Q c) as the log-table lnl passes form it (fz_log1p_of_log: log Q + log c + exp(-L) | 0 | the table-driven log1p of the exact
+ * product) on caller-supplied lq = log Q, lc = log c, q, c (accuracy test hook) */
+int tsem_debug_log1p_of_log(int device, int32_t n, const double* lq, const double* lc, const double* q, const double* c, double* y) {
+  if (!lq || !lc || !q || !c || !y || n < 0) return TSEM_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return TSEM_ERR_HIP;
+  double* d = nullptr;
+  const size_t m = (size_t)std::max(1, n);
+  if (hipMalloc((void**)&d, 8 * 5 * m) != hipSuccess) return TSEM_ERR_NOMEM;
+  (void)hipMemcpy(d, lq, 8 * (size_t)n, hipMemcpyHostToDevice); (void)hipMemcpy(d + m, lc, 8 * (size_t)n, hipMemcpyHostToDevice);
+  (void)hipMemcpy(d + 2 * m, q, 8 * (size_t)n, hipMemcpyHostToDevice); (void)hipMemcpy(d + 3 * m, c, 8 * (size_t)n, hipMemcpyHostToDevice);
+  if (n) k_log1p_of_log_probe<<<(n + 255) / 256, 256>>>(n, d, d + m, d + 2 * m, d + 3 * m, d + 4 * m);
+  hipError_t e = hipMemcpy(y, d + 4 * m, 8 * (size_t)n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return e == hipSuccess ? TSEM_OK : TSEM_ERR_HIP;
+}
+
 // What a pure streaming read reaches on this GPU: grid-stride, eight 16-byte non-temporal loads in flight per thread (the
 // best plain variant of tools/ubench/stream.hip), sum into a register, no store.  The "measured-stream peak" beside the
 // nominal 8 TB/s in bench.py's roofline block.
@@ -560,6 +588,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[26] = h->em_rows ? 1 : 0;                           // K beyond 64 column parts: plain CSR row passes (no blocked layout)
   info[25] = h->n_single_part;                             // ambiguous rows whose entries all lie in ONE column part (they would need no exchange)
   info[24] = h->split ? 1 : 0;                             // split layout: two light passes per iteration (K > 61 440)
+  info[27] = h->lq_n;                                      // entries of the log Q table of the lnl passes (0: not built yet / does not fit / does not apply)
   info[23] = h->lnl3 ? 1 : 0;                              // the layout lets the EM pass carry the previous iteration's log-likelihood (option "use_likelihood")
   return TSEM_OK;
 }

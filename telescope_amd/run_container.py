@@ -25,6 +25,68 @@ def _str2int(s):
     return s
 
 
+class NpzSlices(object):
+    """Parts of the arrays of an `.npz` without reading the file: `np.savez` (model.py:133) stores its members UNCOMPRESSED, so
+    element [a, b) of a 1-D member sits at a known offset of the archive — the local zip header, then the `.npy` header, then the
+    raw values — and is read with one seek + readinto.  A compressed member (np.savez_compressed) is read whole, once, and sliced."""
+
+    def __init__(self, filename):
+        import zipfile
+        self.filename = filename
+        self._zf = zipfile.ZipFile(filename)
+        self._whole = {}
+
+    def close(self):
+        self._zf.close()
+
+    def names(self):
+        return [n[:-4] for n in self._zf.namelist() if n.endswith('.npy')]
+
+    def _member(self, name):
+        import struct
+        import zipfile
+        info = self._zf.getinfo(name + '.npy')
+        if info.compress_type != zipfile.ZIP_STORED:
+            return None
+        with open(self.filename, 'rb') as fh:
+            fh.seek(info.header_offset)
+            hdr = fh.read(30)                                   # local file header: signature, ..., name length (26), extra length (28)
+            if hdr[:4] != b'PK\x03\x04':
+                return None
+            n_name, n_extra = struct.unpack('<HH', hdr[26:30])
+            fh.seek(info.header_offset + 30 + n_name + n_extra)
+            major, _minor = np.lib.format.read_magic(fh)
+            shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if major == 1 else np.lib.format.read_array_header_2_0(fh))
+            return fh.tell(), shape, fortran, dtype
+
+    def shape(self, name):
+        m = self._member(name)
+        return m[1] if m is not None else self.whole(name).shape
+
+    def whole(self, name):
+        if name not in self._whole:
+            with self._zf.open(name + '.npy') as fh:
+                self._whole[name] = np.lib.format.read_array(fh, allow_pickle=False)
+        return self._whole[name]
+
+    def read(self, name, start=0, stop=None):
+        """Elements [start, stop) of the 1-D member `name` (a fresh array)."""
+        m = self._member(name)
+        if m is None or len(m[1]) != 1 or m[3].hasobject:
+            a = self.whole(name)
+            return np.array(a[start:stop])
+        off, shape, _fortran, dtype = m
+        stop = shape[0] if stop is None else min(stop, shape[0])
+        start = min(max(start, 0), stop)
+        out = np.empty(stop - start, dtype=dtype)
+        with open(self.filename, 'rb') as fh:
+            fh.seek(off + start * dtype.itemsize)
+            got = fh.readinto(memoryview(out).cast('B')) if out.size else 0
+        if got != out.nbytes:
+            raise IOError('%s: member %s is shorter than its header says' % (self.filename, name))
+        return out
+
+
 class Telescope(object):
     def __init__(self, opts=None):
         self.opts = opts
@@ -33,6 +95,7 @@ class Telescope(object):
         self.read_index, self.feat_index = {}, {}
         self.shape = None
         self.raw_scores = None
+        self.row_range = None            # (r0, r1): `raw_scores` holds only these fragments (load_shard); None = all of them
 
     # ---- alignment loading (model.py:155-173, via telescope_amd/loader.py) --------
     def load_alignment(self, annotation):
@@ -78,6 +141,41 @@ class Telescope(object):
         obj.raw_scores = sp.csr_matrix((z['_raw_scores_data'], z['_raw_scores_indices'],
                                         z['_raw_scores_indptr']), shape=tuple(z['_raw_scores_shape']))
         return obj
+
+    @classmethod
+    def load_shard(cls, filename, world, rank):
+        """This rank's share of a checkpoint for a row-sharded run: the run information, the feature lists and the row pointers are
+        read whole (K- and N-sized), the stored entries only for the rank's contiguous range of fragments — balanced by entries,
+        `distributed.shard_bounds` — straight from their offsets in the archive (NpzSlices), and the fragment names (`_read_list`,
+        the largest member after the entries; nothing on the EM / report path uses them) not at all.  A rank of an 8-way run of the
+        50M-fragment checkpoint touches 1.6 GB of a 12.4 GB file instead of all of it.  `raw_scores` is the rank's (r1 - r0) x K
+        slice, `row_range` = (r0, r1), `shape` the whole matrix's (the seed rule uses it, model.py:150-153)."""
+        from .distributed import shard_bounds
+        z = NpzSlices(filename)
+        try:
+            obj = cls()
+            for k, v in z.whole('_run_info'):
+                obj.run_info[str(k)] = _str2int(str(v))
+            feats, flens = z.whole('_feat_list'), z.whole('_flen_list')
+            for f, fl in zip(feats, flens):
+                obj.feature_length[str(f)] = fl
+            obj.feat_index = {str(n): i for i, n in enumerate(feats)}
+            obj.read_index = None                                # not loaded (see above)
+            obj.shape = tuple(int(x) for x in z.whole('_shape'))
+            n_rows, n_cols = (int(x) for x in z.whole('_raw_scores_shape'))
+            if obj.shape != (n_rows, n_cols) or len(obj.feat_index) != n_cols or z.shape('_read_list')[0] != n_rows:
+                raise AssertionError('checkpoint shape %s does not match its matrix %s / name lists' % (obj.shape, (n_rows, n_cols)))
+            indptr = z.read('_raw_scores_indptr')
+            r0, r1 = shard_bounds(n_rows, world, rank, indptr=indptr)
+            e0, e1 = int(indptr[r0]), int(indptr[r1])
+            local_ptr = indptr[r0:r1 + 1] - indptr[r0]
+            del indptr
+            obj.raw_scores = sp.csr_matrix((z.read('_raw_scores_data', e0, e1), z.read('_raw_scores_indices', e0, e1), local_ptr),
+                                           shape=(r1 - r0, n_cols))
+            obj.row_range = (r0, r1)
+            return obj
+        finally:
+            z.close()
 
     def get_random_seed(self):
         """model.py:150-153 — note the precedence: (total % N) * K, then mod 2^32-1."""
