@@ -76,6 +76,11 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *   "report_shortcuts" 1 (default): tsem_reassign answers `all` (initial) and `unique` from counts taken at
  *                  setup instead of a pass over the matrix (the same numbers; 0 forces the pass)
  *   "kernel_timing" n: HIP events around every n-th EM pass for tsem_kernel_stats (default 1, 0 = off)
+ *   "phase_timing" 1: HIP events at the phase boundaries of every chunked iteration (tsem_phase_times)
+ *   "drop_csr_indices" free the CSR column ids (4 of the 14 B per stored entry the default layout keeps resident) once the
+ *                  blocked layout and the 2-byte popularity ids exist; they are rebuilt on demand (col = col_of_id[id]) for
+ *                  the generic row passes, z export, tsem_export_csr and a layout rebuild.  -1 (default): from 4e9 stored
+ *                  entries on; 0 never; 1 always
  *   "deconflict"   conflict-aware entry order inside the rows of the row-ordered code layout (LDS bank conflicts of the
  *                  column scatter 3.2 -> 2.4 lanes per class: -6 % per EM pass for ~4 ms of setup at 2e9 entries);
  *                  default -1 = on, 0 = off
@@ -292,7 +297,10 @@ int  tsem_reassign(tsem_ctx* h, int method, double thresh, int which,
  * are compacted on the device in row order: *n_ties of them; tsem_report_ties copies their indices and numbers of
  * best hits out (cap >= n_ties), and tsem_reassign_rows(TSEM_RA_CHOOSE, ..., rows = NULL, picks, n_ties, out) adds up
  * the picked entries of exactly those rows, so that  choose = exclude + that.  tsem_reassign_rows with a caller's
- * row list gives the contribution of those rows to any method (picks[i] belongs to rows[i]). */
+ * row list gives the contribution of those rows to any method (picks[i] belongs to rows[i]).
+ * thresh < 0: the caller needs no `conf` column (out[0..K) is then not meaningful).  For the INITIAL z the pass then runs on
+ * the 2-byte score codes alone — a row's best hits are its largest codes when the score table is strictly increasing and no
+ * stored score is 0 — with no score-table look-up and no floating point (k_report_init_codes). */
 int  tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out /* 3*K */, int64_t* n_ties);
 int  tsem_report_ties(tsem_ctx* h, int64_t cap, int32_t* rows, int32_t* counts);
 int  tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const int32_t* rows,
@@ -342,6 +350,11 @@ int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launch
  * { EM pass | column reduce | all-reduce of the K+2 sums (0 without a communicator) | update | gap to the next iteration's
  * pass | first mark to last mark }.  What bench.py prints as `phase_us`. */
 int  tsem_phase_times(tsem_ctx* h, int reset, double* ms6, int64_t* n_iter);
+/* Free / total bytes of the device's memory (hipMemGetInfo; h may be NULL, then `device` is asked) and, with a handle, the bytes its
+ * matrix keeps resident: resident5 = { CSR row pointers + scores | CSR column ids (0 after option "drop_csr_indices") | popularity
+ * ids | blocked layout | per-row arrays }.  What a capacity plan needs: 14 B per stored entry by default (score codes), 10 after
+ * the drop, + ~20 B per row. */
+int  tsem_device_memory(tsem_ctx* h, int device, int64_t* free_bytes, int64_t* total_bytes, int64_t* resident5);
 int  tsem_layout_info(tsem_ctx* h, int64_t* info32 /* 28 values written */);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);

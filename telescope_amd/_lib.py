@@ -193,6 +193,7 @@ def lib():
     L.tsem_csr_scale.argtypes = [C.c_int, C.c_int, i64, i32, vp, vp, vp]
     L.tsem_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
     L.tsem_phase_times.argtypes = [vp, C.c_int, vp, C.POINTER(i64)]
+    L.tsem_device_memory.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i64), vp]
     L.tsem_layout_info.argtypes = [vp, vp]
     L.tsem_debug_fused_prof.argtypes = [vp, vp]
     L.tsem_debug_fused_startup.argtypes = [vp, vp]
@@ -548,6 +549,13 @@ class Engine(object):
         self._ck(self._L.tsem_kernel_stats(self._h, int(reset), C.byref(ms), C.byref(n), C.byref(b)))
         return dict(em_ms=ms.value, em_launches=n.value, algo_bytes_per_pass=b.value)
 
+    def device_memory(self):
+        """dict(free, total, resident=dict(csr, csr_indices, ids, layout, rows)) in bytes."""
+        f, t = C.c_int64(), C.c_int64()
+        r = np.zeros(5, np.int64)
+        self._ck(self._L.tsem_device_memory(self._h, 0, C.byref(f), C.byref(t), ptr(r)))
+        return dict(free=f.value, total=t.value, resident=dict(zip(('csr', 'csr_indices', 'ids', 'layout', 'rows'), r.tolist())))
+
     def phase_times(self, reset=False):
         """Option 'phase_timing': mean microseconds per chunked iteration of pass / column reduce / all-reduce / update, the gap
         to the next iteration, and first-to-last mark; None when nothing was timed."""
@@ -697,6 +705,14 @@ def debug_log1p_of_log(q, c, device=0):
     if rc != OK:
         raise EngineError('tsem_debug_log1p_of_log failed (%d)' % rc)
     return y
+
+
+def device_memory(device=0):
+    """(free, total) bytes of a device's memory, without an engine."""
+    f, t = C.c_int64(), C.c_int64()
+    if lib().tsem_device_memory(None, int(device), C.byref(f), C.byref(t), None) != OK:
+        raise EngineError('tsem_device_memory failed (no usable HIP device?)')
+    return f.value, t.value
 
 
 def stream_read_gbs(device=0, nbytes=8 << 30, reps=3):

@@ -68,9 +68,13 @@ struct tsem_ctx {
   int64_t* d_indptr = nullptr;
   int32_t* d_indices = nullptr;
   uint16_t* d_raw = nullptr;
+  int64_t opt_drop_indices = -1;    // option "drop_csr_indices": free the CSR column ids (4 B per entry) once the blocked layout and the 2-byte popularity ids
+                                    // exist — col = col_of_id[rid16], rebuilt on demand (tsem_ensure_indices) for the generic row passes, z export, a
+                                    // layout rebuild.  -1 auto: from 4e9 stored entries on; 0 never; 1 always
   double* d_lut = nullptr;
   int lut_len = 0;
   std::vector<double> lut_host;
+  bool lut_increasing = false;      // lut[1] > 0 and strictly increasing from there: a larger score code is a larger Q (k_report_init_codes)
 
   // ---- row classes ----
   int64_t N_amb = 0, N_uni = 0, nnz_amb = 0;

@@ -641,6 +641,7 @@ int tsem_rowpass_grid(tsem_ctx* h);
 // the fp32 diagnostic pass (option "em_precision" = 1): same outputs as tsem_em_pass, fp32 arithmetic
 static int em_pass_f32(tsem_ctx* h) {
   const int K = h->K;
+  if (int rc = tsem_ensure_indices(h)) return rc;
   if (!h->d_c32) {
     TSEM_ALLOC(h->d_c32, K); TSEM_ALLOC(h->d_cs32, K); TSEM_ALLOC(h->d_lut32, h->lut_len);
     k_lut32<<<cdiv64(h->lut_len, 256), 256, 0, h->stream>>>(h->lut_len, h->d_lut, h->d_lut32);

@@ -190,6 +190,7 @@ int tsem_set_option(tsem_ctx* h, const char* key, int64_t v) {
   else if (k == "reproducible") h->opt_reproducible = v;
   else if (k == "em_precision") h->opt_precision = v;
   else if (k == "kernel_timing") h->opt_timing = v;
+  else if (k == "drop_csr_indices") h->opt_drop_indices = v;   // -1 auto (>= 4e9 entries), 0 never, 1 always: see tsem_common.h
   else if (k == "phase_timing") h->opt_phase = v;          // HIP events between the phases of every chunked iteration (tsem_phase_times); a diagnostic: ~5 events per iteration
   else if (k == "report_shortcuts") h->opt_shortcuts = v;
   else if (k == "rowpass_wgs") h->opt_rowpass_wgs = v;
@@ -221,6 +222,8 @@ static int set_lut(tsem_ctx* h, const double* lut, int32_t lut_len) {
   h->lut_len = lut_len;
   dfree(h->d_lut32); dfree(h->d_c32); dfree(h->d_cs32);      // (the fp32 diagnostic tables follow the score table)
   h->lut_host.assign(lut, lut + lut_len);
+  h->lut_increasing = lut_len >= 2 && lut[1] > 0.0;
+  for (int i = 2; i < lut_len && h->lut_increasing; ++i) h->lut_increasing = lut[i] > lut[i - 1];
   dfree(h->d_lqtab); h->lq_n = 0; h->lq_tried = false;       // (log Q follows the score table)
   TSEM_ALLOC(h->d_lut, lut_len);
   TSEM_HIP(hipMemcpy(h->d_lut, lut, sizeof(double) * lut_len, hipMemcpyHostToDevice));
@@ -402,6 +405,7 @@ int tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* ra
   if (int rc = ensure_device(h)) return rc;
   TSEM_HIP(hipStreamSynchronize(h->stream));
   if (indptr) TSEM_HIP(hipMemcpy(indptr, h->d_indptr, sizeof(int64_t) * (h->N + 1), hipMemcpyDeviceToHost));
+  if (indices && h->nnz) { if (int rc = tsem_ensure_indices(h)) return rc; }
   if (indices && h->nnz) TSEM_HIP(hipMemcpy(indices, h->d_indices, sizeof(int32_t) * h->nnz, hipMemcpyDeviceToHost));
   if (raw && h->nnz) TSEM_HIP(hipMemcpy(raw, h->d_raw, sizeof(uint16_t) * h->nnz, hipMemcpyDeviceToHost));
   return TSEM_OK;
@@ -428,6 +432,29 @@ int tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launche
   // + 2 B row weight code per row
   if (algo_bytes) *algo_bytes = h->nnz_amb * (h->fmt_code ? 6 : 12) + h->N_amb * 2;
   if (reset) { h->em_ms_acc = 0; h->em_launches = 0; h->em_timed = 0; }
+  return TSEM_OK;
+}
+
+/* free / total bytes of the device's memory (hipMemGetInfo), and — with a handle — what the handle's matrix keeps resident, by kind:
+ * resident[0] CSR row pointers + scores, [1] CSR column ids (0 after option "drop_csr_indices"), [2] popularity ids,
+ * [3] blocked layout (entries + offsets), [4] per-row arrays */
+int tsem_device_memory(tsem_ctx* h, int device, int64_t* free_bytes, int64_t* total_bytes, int64_t* resident5) {
+  if (hipSetDevice(h ? h->device : device) != hipSuccess) return TSEM_ERR_HIP;
+  size_t f = 0, t = 0;
+  if (hipMemGetInfo(&f, &t) != hipSuccess) return TSEM_ERR_HIP;
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  if (resident5 && h) {
+    const int64_t nz = h->nnz + TS_ENTRY_PAD;
+    resident5[0] = h->d_indptr ? 8 * (h->N + 1) + (h->d_raw ? 2 * nz : 0) : 0;
+    resident5[1] = h->d_indices ? 4 * nz : 0;
+    resident5[2] = h->d_rid16 ? 2 * nz : 0;
+    resident5[3] = (h->d_prc ? 4 * h->nnz_pad : 0) + (h->d_pcode ? 2 * h->nnz_pad : 0) + (h->d_pval ? 8 * h->nnz_pad : 0) +
+                   (h->d_sb_off ? 12 * (h->nb * h->P + 2) : 0);
+    resident5[4] = (h->d_row_code ? 3 * h->N : 0) + (h->d_amb_row ? 6 * h->N_amb : 0) + (h->d_slot_row ? 6 * h->N_amb_pad : 0) +
+                   (h->d_uni_col ? 6 * h->N_uni : 0) + (h->d_amb_w ? 8 * h->N_amb_pad : 0) + (h->d_rinv ? 8 * h->N_amb_pad : 0) +
+                   (h->d_ypart ? 8 * (int64_t)h->P * h->N_amb_pad : 0);
+  }
   return TSEM_OK;
 }
 

@@ -362,6 +362,13 @@ template <int G> __device__ __forceinline__ double rr_max(double v) {
   if (G >= 16) v = fmax(v, fz_dpp_d<RR_MIRROR, 0xF>(v, v));
   return v;
 }
+template <int G> __device__ __forceinline__ int rr_max_i(int v) {
+  if (G >= 2) v = max(v, fz_dpp_i<RR_QP_X1, 0xF>(v, v));
+  if (G >= 4) v = max(v, fz_dpp_i<RR_QP_X2, 0xF>(v, v));
+  if (G >= 8) v = max(v, fz_dpp_i<RR_HALF_MIRROR, 0xF>(v, v));
+  if (G >= 16) v = max(v, fz_dpp_i<RR_MIRROR, 0xF>(v, v));
+  return v;
+}
 template <int G> __device__ __forceinline__ int rr_sum_i(int v) {
   if (G >= 2) v += fz_dpp_i<RR_QP_X1, 0xF>(v, v);
   if (G >= 4) v += fz_dpp_i<RR_QP_X2, 0xF>(v, v);
@@ -591,6 +598,117 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
   }
 }
 
+// The report pass over the INITIAL z when the caller wants no `conf` column (output_report takes exclude, choose and average of the
+// initial z, model.py:441-446; tsem_report_colsums with thresh < 0): z_ij = Q_ij / sum_j Q_ij with Q = lut[code], and lut is strictly
+// increasing, so a row's best hits are the entries with the LARGEST SCORE CODE — integer work on the packed 16-bit codes, no score-table
+// gather, no fp64 at all: ~7 VALU instructions per lane-entry where k_report_rows<.., INIT> spends ~20 and an LDS gather (its time
+// follows its lane capacity, not its useful entries: cap 64 / 128 / 256 -> 5.1 / 8.6 / 15.9 ms, profiles/r03_time_report.txt — it is
+// bound by instruction issue).  Same row -> lanes mapping, prefetch and emit rules as k_report_rows; rows longer than G x E go to
+// k_report_slow<true>.  Needs: no stored score of 0 (code 0 marks the padding here), lut strictly increasing (checked by the host).
+template <int G, int E>
+__global__ __launch_bounds__(1024) void k_report_init_codes(ReportArgs A) {
+  static_assert(E == 8 || E == 16, "entries per lane");
+  extern __shared__ double rr_lds[];                       // [Hs] single winners | [Hs] two-way ties (u32 each)
+  uint32_t* const hot1 = reinterpret_cast<uint32_t*>(rr_lds);
+  uint32_t* const hot2 = hot1 + A.Hs;
+  for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) { hot1[t] = 0u; hot2[t] = 0u; }
+  __syncthreads();
+  const ReportEmit<0> EM{A, nullptr, hot1, hot2, A.Hs, nullptr};
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  const int64_t stride = (int64_t)gridDim.x * ngrp;
+  const int64_t nit = (A.N + stride - 1) / stride;
+  constexpr int W = E / 2;                                 // packed words per lane
+  struct Ip { int64_t s; int len; };
+  struct Ent { rr_u32x4_a2 id[E / 8]; rr_u32x4_a2 cd[E / 8]; };
+  auto load_ip = [&](int64_t it) -> Ip {
+    const int64_t row = it * stride + (int64_t)blockIdx.x * ngrp + grp;
+    const int64_t rc = row < A.N ? row : A.N - 1;        // clamped, never branched around
+    const rr_i64x2_a8 se = *reinterpret_cast<const rr_i64x2_a8*>(A.indptr + rc);
+    Ip r; r.s = se.x; r.len = row < A.N ? (int)min<int64_t>(se.y - se.x, 0x7FFFFFFF) : 0;
+    return r;
+  };
+  auto load_ent = [&](const Ip& p) -> Ent {
+    const int64_t k = p.s + E * gl;
+    Ent t;
+#pragma unroll
+    for (int q = 0; q < E / 8; ++q) {
+      t.id[q] = *reinterpret_cast<const rr_u32x4_a2*>(A.rid + k + 8 * q);
+      t.cd[q] = *reinterpret_cast<const rr_u32x4_a2*>(A.raw + k + 8 * q);
+    }
+    return t;
+  };
+  auto row_do = [&](int64_t row, const Ip& p, const Ent& t) {
+    const int nl = min(max(p.len - E * gl, 0), E);         // this lane's share of the row
+    uint32_t c[W], mx = 0u;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {                          // codes past the row's end -> 0 (never the largest: stored scores are >= 1)
+      const int lim = nl - 2 * w;
+      c[w] = t.cd[w / 4][w & 3] & (lim >= 2 ? 0xFFFFFFFFu : (lim == 1 ? 0x0000FFFFu : 0u));
+      typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+      mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, mx), __builtin_bit_cast(u16x2, c[w])));   // v_pk_max_u16
+    }
+    const int mrow = rr_max_i<G>((int)max(mx & 0xFFFFu, mx >> 16));
+    const bool any = mrow > 0;
+    const uint32_t mm = (uint32_t)mrow * 0x10001u;
+    uint32_t nz = 0u;                                      // bit w: the low code of word w differs from the maximum; bit 16 + w: the high code
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const uint32_t x = c[w] ^ mm;
+      const uint32_t z = ((x & 0x7FFF7FFFu) + 0x7FFF7FFFu) | x;   // bit 15 / 31 set <=> that half is non-zero
+      nz |= ((z >> 15) & 0x10001u) << w;
+    }
+    constexpr uint32_t full = ((1u << W) - 1u) * 0x10001u;
+    const uint32_t eq = any ? (~nz & full) : 0u;
+    const int nbl = __popc(eq);
+    const int nb = rr_sum_i<G>(nbl);
+    if (gl == 0 && row < A.N && !(A.dbg & 2)) A.nbest[row] = any ? nb : 0;
+    // the popularity id behind bit b of `eq` (a select chain over the lane's words: once per lane and row, not per entry)
+    auto id_of = [&](int b) -> uint32_t {
+      const int w = b & 15;
+      uint32_t v = t.id[0][0];
+#pragma unroll
+      for (int q = 1; q < W; ++q) v = w == q ? t.id[q / 4][q & 3] : v;
+      return b >= 16 ? v >> 16 : v & 0xFFFFu;
+    };
+    const int b0 = nbl ? __ffs((int)eq) - 1 : 0;
+    const uint32_t id0 = id_of(b0);
+    if (nb == 1 && nbl == 1) EM.one(id0, 0);
+    if (__builtin_amdgcn_ballot_w64(nb > 1) != 0ull && !(A.dbg & 4)) {      // rows with several best hits
+      const double share = 1.0 * recip0((double)nb);
+      if (nb > 1 && nbl >= 1) EM.tie(id0, nb, nb == 2 ? 0.5 : share, 0);
+      uint32_t rest = nb > 1 && nbl > 1 ? eq & (eq - 1u) : 0u;
+      while (__builtin_amdgcn_ballot_w64(rest != 0u) != 0ull) {             // further best hits inside the same lane
+        if (rest) { EM.tie(id_of(__ffs((int)rest) - 1), nb, nb == 2 ? 0.5 : share, 0); rest &= rest - 1u; }
+      }
+    }
+  };
+  if (nit > 0) {
+    Ip ip0 = load_ip(0), ip1 = load_ip(1);
+    Ent e0 = load_ent(ip0);
+    for (int64_t it = 0; it < nit; ++it) {
+      const int64_t row = it * stride + (int64_t)blockIdx.x * ngrp + grp;
+      const bool defer = ip0.len > G * E;                  // left to k_report_slow
+      Ip cur = ip0;
+      if (defer) cur.len = 0;
+      const Ent e1 = load_ent(ip1);                        // the next rows' loads go out before this row's arithmetic
+      const Ip ip2 = load_ip(it + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (defer) {
+        if (gl == 0) A.defer_rows[atomicAdd(A.defer_n, 1ull)] = (int32_t)row;
+      } else {
+        row_do(row, cur, e0);
+      }
+      ip0 = ip1; ip1 = ip2; e0 = e1;
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < A.Hs; t += blockDim.x) {
+    const uint32_t c1 = hot1[t], c2 = hot2[t];
+    if (c1) unsafeAtomicAdd(&A.g_n1[t], (double)c1);
+    if (c2) unsafeAtomicAdd(&A.g_n2[t], (double)c2);
+  }
+}
+
 // the rows k_report_rows left: any length, sweeps of 16 entries, one 16-lane group per row
 template <bool INIT, int GM = 0>
 __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
@@ -756,6 +874,7 @@ static int make_cnat(tsem_ctx* h, RowPassArgs& A) {
 }
 
 static int rowpass_args(tsem_ctx* h, int which, RowPassArgs& A) {
+  if (int rc = tsem_ensure_indices(h)) return rc;          // (the generic row passes read the CSR column ids)
   A.N = h->N; A.K = h->K; A.indptr = h->d_indptr; A.indices = h->d_indices; A.raw = h->d_raw; A.lut = h->d_lut;
   A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr; A.group = nullptr; A.rowlist = nullptr; A.nlist = 0; A.colmap = nullptr; A.col_of_pc = nullptr; A.P = 0; A.Kp = 0; A.Hs = 0;
   A.zin = nullptr; A.cnat = nullptr; A.lut_len = h->lut_len <= 2048 ? h->lut_len : 0;   // (larger tables stay in global memory)
@@ -979,6 +1098,8 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
 int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, int64_t* n_ties) {
   if (!h || !h->d_indptr || !out3K) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
+  const bool want_conf = !(thresh < 0.0);                  // thresh < 0: no `conf` column wanted (its third of out3K stays 0)
+  if (!want_conf) thresh = 0.9;                            // (what the paths that compute it anyway use)
   RowPassArgs A;
   if (int rc = rowpass_args(h, which, A)) return rc;
   dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;
@@ -1004,6 +1125,15 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       R.N = h->N; R.nnz = h->nnz; R.K = K; R.IDN = IDN; R.indptr = h->d_indptr; R.rid = h->d_rid16; R.raw = h->d_raw;
       R.lut = h->d_lut; R.lut_len = A.lut_len; R.cnat2 = nullptr; R.thresh = thresh; R.nbest = d_nb;
       const bool init = A.pi == nullptr;
+      // thresh < 0: the caller wants no `conf` column.  The initial z then needs no arithmetic at all — the best hits of a row are its
+      // largest score codes (k_report_init_codes) — provided the score table is strictly increasing and no stored score is 0.
+      bool codes_only = false;
+      if (init && !want_conf && h->lut_increasing && !h->opt_reproducible && h->d_ucount && h->opt_report_kernel != 2) {
+        uint32_t has_zero = 1;
+        TSEM_HIP(hipMemcpyAsync(&has_zero, h->d_ucount + K, 4, hipMemcpyDeviceToHost, h->stream));
+        TSEM_HIP(hipStreamSynchronize(h->stream));
+        codes_only = has_zero == 0;
+      }
       double *d_g = nullptr, *d_c2 = nullptr;
       TSEM_SCOPED(d_g); TSEM_SCOPED(d_c2);
       const bool exact = h->opt_reproducible != 0;
@@ -1023,6 +1153,8 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       const int slot_bytes = exact ? 24 : 16;                // conf (f64) + two counters (+ the low pieces)
       R.Hs = std::min(IDN, init ? lds_avail / slot_bytes : std::min(3072, lds_avail / slot_bytes / 4));
       R.HC = init ? 0 : std::max(0, std::min(IDN, (lds_avail - R.Hs * slot_bytes) / 8));
+      const int cw = h->opt_report_wgs2 ? 2 : 1;             // (codes-only kernel: 32 VGPRs, so two 1024-thread workgroups fit a CU with half the slots each)
+      if (codes_only) R.Hs = std::min(IDN, (TS_LDS_MAX / cw - 2048) / 8);   // two 32-bit counters per id, nothing else in LDS
       int cap = 256;                                       // G x E
       if (h->opt_report_lanes > 0) {
         cap = (int)h->opt_report_lanes;
@@ -1031,7 +1163,7 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
           if ((double)h->len_gt[q] <= 0.005 * (double)h->N) { cap = 8 << q; break; }
       }
       void (*rk)(ReportArgs) = nullptr;
-#define RK(G_, E_) (init ? k_report_rows<G_, E_, true> : k_report_rows<G_, E_, false>)
+#define RK(G_, E_) (codes_only ? k_report_init_codes<G_, E_> : (init ? k_report_rows<G_, E_, true> : k_report_rows<G_, E_, false>))
       if (cap <= 8) rk = RK(1, 8); else if (cap <= 16) rk = RK(1, 16); else if (cap <= 32) rk = RK(2, 16);
       else if (cap <= 64) rk = RK(4, 16); else if (cap <= 128) rk = RK(8, 16); else rk = RK(16, 16);
 #undef RK
@@ -1039,6 +1171,8 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       R.dbg = (int)h->opt_report_dbg;
       R.defer_rows = d_rows; R.defer_n = d_n;               // (d_rows is the tie list later: the slow kernel is done with it by then)
       TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
+      if (codes_only) rk<<<h->n_cu * cw, 1024, (size_t)R.Hs * 8, h->stream>>>(R);
+      else
       rk<<<h->n_cu * wgs, rr_nt(init), (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * slot_bytes, h->stream>>>(R);
       TSEM_HIP(hipGetLastError());
       if (init) k_report_slow<true><<<h->n_cu * 2, 256, 0, h->stream>>>(R);

@@ -631,7 +631,35 @@ __global__ __launch_bounds__(256) void k_rid16_rows(int64_t N, const int64_t* __
   }
 }
 
+// the CSR column ids back from the popularity ids (option "drop_csr_indices"): eight entries per thread, 16-byte loads of the ids
+__global__ __launch_bounds__(256) void k_indices_from_rid(int64_t nnz, const uint16_t* __restrict__ rid, const int32_t* __restrict__ col_of_id,
+                                                          int32_t* __restrict__ indices) {
+  for (int64_t k0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; k0 < nnz; k0 += (int64_t)gridDim.x * blockDim.x * 8) {
+    if (k0 + 8 <= nnz) {
+      const cs_u32x4_a2 w = *reinterpret_cast<const cs_u32x4_a2*>(rid + k0);
+      int32_t c[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] = col_of_id[(j & 1) ? w[j / 2] >> 16 : w[j / 2] & 0xFFFFu];
+      *reinterpret_cast<cs_u32x4_a4*>(indices + k0) = cs_u32x4_a4{(unsigned)c[0], (unsigned)c[1], (unsigned)c[2], (unsigned)c[3]};
+      *reinterpret_cast<cs_u32x4_a4*>(indices + k0 + 4) = cs_u32x4_a4{(unsigned)c[4], (unsigned)c[5], (unsigned)c[6], (unsigned)c[7]};
+    } else {
+      for (int64_t k = k0; k < nnz; ++k) indices[k] = col_of_id[rid[k]];
+    }
+  }
+}
+
 extern "C" {
+
+int tsem_ensure_indices(tsem_ctx* h) {
+  if (h->d_indices || !h->d_indptr || h->nnz == 0) return TSEM_OK;
+  if (!h->d_rid16 || !h->d_col_of_id) TSEM_FAIL(TSEM_ERR_ARG, "the CSR column ids were dropped and there are no popularity ids to rebuild them from");
+  TSEM_ALLOC(h->d_indices, h->nnz + TS_ENTRY_PAD);
+  TSEM_HIP(hipMemsetAsync(h->d_indices + h->nnz, 0, sizeof(int32_t) * TS_ENTRY_PAD, h->stream));
+  k_indices_from_rid<<<(unsigned)std::min<int64_t>((int64_t)h->n_cu * 32, (h->nnz / 8 + 255) / 256 + 1), 256, 0, h->stream>>>(
+      h->nnz, h->d_rid16, h->d_col_of_id, h->d_indices);
+  TSEM_HIP(hipGetLastError());
+  return TSEM_OK;
+}
 
 // option "reproducible": the slots' bounds as a run finds them: 2^E > the largest fragment weight >= every contribution w * z
 // (refined column by column, see k_bin_check).  Called when parameters are set from outside, so that a run's bits depend on its
@@ -781,6 +809,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   if (!h || !h->d_indptr) return TSEM_ERR_ARG;
   if (!h->d_lut || h->lut_len <= 0) TSEM_FAIL(TSEM_ERR_ARG, "no score table: call tsem_set_lut after tsem_generate");
   if (int rc = ensure_device(h)) return rc;
+  if (int rc = tsem_ensure_indices(h)) return rc;
   const int64_t N = h->N;
   const int K = h->K;
   PhaseTimer pt(h->stream);
@@ -813,6 +842,7 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   }
   k_pisum_finish<<<cdiv64(K, 256), 256, 0, h->stream>>>(K, d_pis_lv, h->d_pisum0);
   TSEM_HIP(hipGetLastError());
+  pt.lap("rowstats: k_rowstats kernel");
   TSEM_HIP(hipMemcpyAsync(h->len_gt, d_lg, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   std::vector<double> wpart(2 * grid);
   uint32_t maxcode = 0;
@@ -823,6 +853,10 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   for (int i = 0; i < grid; ++i) { wt += wpart[2 * i]; wa += wpart[2 * i + 1]; }
   if (stats3) { stats3[0] = wt; stats3[1] = wa; stats3[2] = (N && h->nnz) ? h->lut_host[maxcode] : 0.0; }
   if (pisum0) TSEM_HIP(hipMemcpy(pisum0, h->d_pisum0, sizeof(double) * K, hipMemcpyDeviceToHost));
+  // (Round 5: the ~7 ms this section takes in the FIRST engine of a process — 0.08 ms in the second — are a one-off of the runtime's
+  //  first sizeable host copy.  Routing the read-backs through a pinned buffer, or storing them into device-mapped host memory from a
+  //  kernel, only moved the 7 ms to the next hipMemcpy, and with pinned memory registered the GB-sized hipMallocs of the layout took
+  //  60-340 ms each in two of three runs: reverted.  gpurun_out logs r5_setup_trace3-5.)
 
   pt.lap("rowstats: k_rowstats + sums");
   // column signatures (popularity + twin detection)
@@ -917,6 +951,8 @@ int tsem_build_layout(tsem_ctx* h) {
   PhaseTimer pt(h->stream);
   const int K = h->K;
   const int64_t na = h->N_amb;
+  if (int rc = tsem_ensure_indices(h)) return rc;          // (a rebuild after option "drop_csr_indices": from the ids of the layout about to go)
+  TSEM_HIP(hipStreamSynchronize(h->stream));
   tsem_free_layout(h);
   h->nnz_amb = 0;
   h->n_single_part = 0;
@@ -1155,12 +1191,16 @@ int tsem_build_layout(tsem_ctx* h) {
   // row 2.70 -> 2.48 (profiles/r02_sweep.txt, r02_sweep_short.txt).
   h->sorted_layout = h->use_fused && R * P <= FILL_MAX_RP &&   // (the fill kernel keeps R x P counters in LDS)
                      (h->opt_sorted >= 0 ? h->opt_sorted != 0 : true);
+  // temporaries of the fill / conflict-aware order: allocated BEFORE the kernels go out (a hipMalloc of gigabytes next to a running
+  // kernel took 60-300 ms in round 5's first attempt at overlapping this section), freed after the one synchronisation behind them
+  uint8_t* d_lgtab = nullptr;
+  uint32_t* prc2 = nullptr; uint16_t* code2 = nullptr;
+  TSEM_SCOPED(d_lgtab); TSEM_SCOPED(prc2); TSEM_SCOPED(code2);
+  bool swap_deconflicted = false;
   if (nb && h->sorted_layout) {
     // the popularity ids stand in for the column-map gather when every row's ids are written (they are: k_row_partcounts +
     // k_rid16_rows above) and the split columns' ids fit the small table
     const uint16_t* rid_fill = nullptr;
-    uint8_t* d_lgtab = nullptr;
-    TSEM_SCOPED(d_lgtab);
     int nsplit = 0;
     if (h->d_rid16 && P <= 8) {
       std::vector<uint8_t> lgt;
@@ -1176,28 +1216,37 @@ int tsem_build_layout(tsem_ctx* h) {
         rid_fill = h->d_rid16;
       }
     }
+    // (reproducible mode keeps the row order: a row's entries in a sub-block then form ONE run, which ends in at most two LDS
+    // atomics on its row sum — two additions commute, three need not)
+    const bool deconflict = h->fmt_code && h->opt_deconflict != 0 && !h->opt_reproducible && off >= 64;
+    if (deconflict) { TSEM_ALLOC(prc2, off); TSEM_ALLOC(code2, off); }
     const uint32_t magicP = (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P);
     k_sb_fill_sorted<<<(unsigned)nb, 256, fill_lds_bytes(R, P), h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
                                                          d_pc ? d_bs : nullptr, d_pc, rid_fill, magicP, nsplit, d_lgtab);
     TSEM_HIP(hipGetLastError());
-    if (d_lgtab) TSEM_HIP(hipStreamSynchronize(h->stream));   // (the fill reads the table; its scope guard frees it)
-    TSEM_HIP(hipGetLastError());
-    // (reproducible mode keeps the row order: a row's entries in a sub-block then form ONE run, which ends in at most two LDS
-    // atomics on its row sum — two additions commute, three need not)
-    if (h->fmt_code && h->opt_deconflict != 0 && !h->opt_reproducible && off >= 64) {
+    if (deconflict) {
       const int64_t n_win = off / 64;
-      uint32_t* prc2 = nullptr; uint16_t* code2 = nullptr;
-      TSEM_SCOPED(prc2); TSEM_SCOPED(code2);
-      TSEM_ALLOC(prc2, off); TSEM_ALLOC(code2, off);
       k_sb_deconflict<<<(unsigned)std::min<int64_t>(n_win / DC_NT + 1, (int64_t)h->n_cu * 32), DC_NT, 0, h->stream>>>(
           n_win, h->d_prc, h->d_pcode, prc2, code2);
       TSEM_HIP(hipGetLastError());
-      TSEM_HIP(hipStreamSynchronize(h->stream));
+      swap_deconflicted = true;
+    }
+    // While the device fills the layout (15 ms at 2e9 entries) the host loads the code object of the fused kernel's unit — 3 ms in a
+    // fresh process, at the first hipFuncSetAttribute / launch of one of its kernels — instead of doing so afterwards.
+    if (h->use_fused) {
+      fz_fn f0 = P <= FZ_MAX_P ? fz_kernel(P, h->split ? 5 : 0, fz_fmt(h), h->geo) : nullptr;
+      if (f0) (void)hipFuncSetAttribute((const void*)f0, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024);
+    }
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (swap_deconflicted) {
       (void)hipFree(h->d_prc); (void)hipFree(h->d_pcode);
       h->d_prc = prc2; h->d_pcode = code2;
       prc2 = nullptr; code2 = nullptr;                     // (ownership moved to the context)
     }
+    // option "drop_csr_indices": the fill was the last reader of the CSR column ids (the report pass and this layout carry 2-byte
+    // popularity ids; col = col_of_id[id]): 10 instead of 14 B per stored entry stay resident.
+    if (rid_fill && h->d_col_of_id && (h->opt_drop_indices == 1 || (h->opt_drop_indices < 0 && h->nnz >= 4000000000ll))) dfree(h->d_indices);
   } else if (nb) {
     k_sb_fill<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                   h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc);
@@ -1221,7 +1270,7 @@ int tsem_build_layout(tsem_ctx* h) {
       TSEM_ALLOC(h->d_fpartial, (int64_t)h->fz_teams * h->Kpad);
       TSEM_ALLOC(h->d_xchg, (int64_t)h->fz_teams * FZ_XS * P * R);
       TSEM_ALLOC(h->d_xflags, FZ_SYNC_WORDS);
-      TSEM_HIP(hipMemset(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS));
+      TSEM_HIP(hipMemsetAsync(h->d_xflags, 0, sizeof(uint32_t) * FZ_SYNC_WORDS, h->stream));
       if (!h->fmt_code && !h->fmt_wcode) {                 // fp64 row weights; otherwise the kernel reads d_amb_wcode
         TSEM_ALLOC(h->d_amb_w, h->N_amb_pad);
         k_row_weights<<<cdiv64(h->N_amb_pad, 256), 256, 0, h->stream>>>(h->N_amb_pad, h->d_amb_wcode, h->d_lut, h->d_amb_w);

@@ -432,7 +432,7 @@ class TelescopeLikelihood(object):
             self._dev_ties = (which, len(rows))                  # the device keeps this pass's tie rows until the next one
             flat = self.comm.sum_array(np.concatenate([sums['conf'], sums['exclude'], sums['average']]))
             K = self.K
-            rep = {'conf': flat[:K], 'exclude': np.rint(flat[K:2 * K]).astype(np.int64), 'average': flat[2 * K:],
+            rep = {'conf': flat[:K] if thresh >= 0 else None, 'exclude': np.rint(flat[K:2 * K]).astype(np.int64), 'average': flat[2 * K:],
                    'rows': rows, 'counts': counts}
             for k in other:                                        # same z, other threshold: only `conf` differs
                 del cache[k]
@@ -493,7 +493,10 @@ class TelescopeLikelihood(object):
         for k in self.__dict__.get('_report_cache', {}):
             if k[0] == which:
                 return k[1]                                       # exclude / average do not depend on it: reuse the pass
-        return thresh
+        # No pass over this z yet, and the caller needs no `conf` column: for the INITIAL z say so (thresh < 0) — its best hits are
+        # then found on the score codes alone (k_report_init_codes).  `output_report` asks exclude / choose / average of the initial z
+        # and never its conf (model.py:441-446); a later reassign('conf', initial=True) runs the full pass.
+        return -1.0 if which == Z_INITIAL else thresh
 
     def reassign_group_sums(self, method, group_rows, thresh=0.9, initial=False):
         """Per-group column sums of the assignment matrix: row g of the result is

@@ -144,3 +144,134 @@ def test_lnl_log_tables_with_dying_and_dead_columns(gpu_device):
         ref = oc.em_fused_arrays(ip, ix, rw, cols, 0, 0, 0.0, it)
         assert abs(tl.lnl - ref['lnl']) <= RTOL * abs(ref['lnl']), (it, tl.lnl, ref['lnl'])
     assert tl.pi.min() < 1e-30                                       # columns did die
+
+
+# ---- option drop_csr_indices -----------------------------------------------------------------------------------------
+
+def test_everything_still_works_after_the_csr_column_ids_are_dropped(gpu_device):
+    """`drop_csr_indices` = 1 frees the CSR column ids once the blocked layout exists (4 of 14 B per stored entry): the EM and the
+    streaming report pass never read them; z export, the generic row passes, `export_csr`, the look-ups and a layout rebuild (the
+    fall-back after a time-out, `use_likelihood`) get them back from the 2-byte popularity ids.  Same results as with the ids kept."""
+    from telescope_amd._lib import Z_PREV
+    res = {}
+    for drop in (0, 1):
+        tl = _synthetic_tl(200_000, 9_000, 16, 'zipf', uniq=0.05, options=(('drop_csr_indices', drop),), opts=Opts(max_iter=6, em_epsilon=0.0))
+        tl.em()
+        np.random.seed(5)
+        out = dict(lnl=tl.lnl, pi=tl.pi.copy())
+        for m in ('exclude', 'average', 'conf', 'unique', 'all', 'choose'):
+            out[m] = tl.reassign_colsums(m)                   # ('unique' / 'choose' take the generic row pass)
+        out['z'] = tl._eng.export_z(Z_PREV)
+        out['csr'] = tl._eng.export_csr()
+        out['estep'] = tl.estep(tl.pi, tl.theta).data
+        pr, va = tl.lookup(np.arange(0, 200_000, 997), np.zeros(201, np.int64), 'exclude')
+        out['lookup'] = (pr, va)
+        tl.em(use_likelihood=True)                             # rebuilds the layout for the carrying pass (needs the column ids again)
+        out['lnl2'], out['iters2'] = tl.lnl, tl.n_iter
+        res[drop] = out
+    a, b = res[0], res[1]
+    assert abs(a['lnl'] - b['lnl']) <= 1e-12 * abs(a['lnl']) and np.allclose(a['pi'], b['pi'], rtol=1e-11, atol=0)
+    for m in ('exclude', 'unique', 'all', 'choose'):
+        assert np.array_equal(a[m], b[m]), m
+    for m in ('average', 'conf'):
+        assert np.allclose(a[m], b[m], rtol=1e-10, atol=1e-10), m
+    assert np.allclose(a['z'], b['z'], rtol=1e-10, atol=0) and np.allclose(a['estep'], b['estep'], rtol=1e-10, atol=0)
+    for x, y in zip(a['csr'], b['csr']):
+        assert np.array_equal(x, y)
+    assert np.allclose(a['lookup'][0], b['lookup'][0], rtol=1e-10, atol=0) and np.array_equal(a['lookup'][1], b['lookup'][1])
+    assert a['iters2'] == b['iters2'] and abs(a['lnl2'] - b['lnl2']) <= 1e-11 * abs(a['lnl2'])
+
+
+# ---- BASELINE config 5 at half its size on ONE GPU (VERDICT r4 #8) ---------------------------------------------------------------------
+
+def test_half_of_config5_on_one_gpu(gpu_device):
+    """100M fragments x 50k loci x ~100 per row = 1.0e10 stored entries — one half of BASELINE config 5 (200M x 50k x ~100 on 8 GPUs; a
+    GPU of that run holds an eighth) — resident on ONE MI355X and run through the properties that do not need a CPU oracle at this
+    size: the EM runs on the persistent fused kernel without a fall-back, pi and theta stay distributions, `all` counts every stored
+    entry, `exclude` + the tied rows account for every fragment, the streaming report pass equals the generic one on a sample of
+    columns, and four iterations on the two-pass kernels (rebuilt layout, fp64 entries) from the same start agree to 1e-10.  Skips when
+    less than 200 GB of HBM is free (a shared or smaller device)."""
+    from telescope_amd import _lib
+    free, total = _lib.device_memory(0)
+    if free < 200 * 2 ** 30:
+        pytest.skip('needs 200 GB of free HBM, %.0f GB free of %.0f' % (free / 2 ** 30, total / 2 ** 30))
+    rows, cols, d, iters = 100_000_000, 50_000, 100, 4
+    tl = _synthetic_tl(rows, cols, d, 'zipf', uniq=0.0, opts=Opts(max_iter=iters, em_epsilon=0.0))
+    eng = tl._eng
+    info = eng.layout_info()
+    nnz = eng.dims()[2]
+    assert abs(nnz - 1.0e10) < 1e8 and info['fused'] == 1 and info['value_bytes'] == 2 and info['P'] == 8, info
+    mem = eng.device_memory()
+    assert mem['resident']['csr_indices'] == 0                    # dropped automatically from 4e9 entries on: 10 B per entry resident
+    assert sum(mem['resident'].values()) < 11.0 * nnz + 40 * rows, mem
+    tl.em()
+    assert eng.layout_info()['fallbacks'] == 0 and math.isfinite(tl.lnl)
+    pi_f, theta_f, lnl_f = tl.pi.copy(), tl.theta.copy(), tl.lnl
+    assert abs(pi_f.sum() - 1.0) < 1e-11 and abs(theta_f.sum() - 1.0) < 1e-11 and (pi_f >= 0).all() and (theta_f >= 0).all()
+    assert int(tl.reassign_colsums('all', initial=True).sum()) == nnz
+    excl = tl.reassign_colsums('exclude')
+    rep = next(iter(tl._report_cache.values()))
+    assert int(excl.sum()) + len(rep['rows']) == rows              # every fragment has one best hit, or is in the tie list
+    avg = tl.reassign_colsums('average')
+    assert abs(avg.sum() - rows) < 1e-6 * rows
+    # the same four iterations on the two-pass kernels: the layout is rebuilt with fp64 entries (the column ids come back from the
+    # popularity ids first), the parameters restart from 1 / K
+    eng.fallback_twopass()
+    info2 = eng.layout_info()
+    assert info2['fused'] == 0 and info2['value_bytes'] == 8, info2
+    eng.set_params(np.repeat(1. / cols, cols), np.repeat(1. / cols, cols))
+    tl.em()
+    assert np.allclose(tl.pi, pi_f, rtol=1e-10, atol=1e-300) and np.allclose(tl.theta, theta_f, rtol=1e-10, atol=1e-300)
+    assert abs(tl.lnl - lnl_f) <= 1e-10 * abs(lnl_f)
+    assert np.array_equal(tl.reassign_colsums('exclude'), excl)
+
+
+# ---- the initial z's report pass on the score codes alone (VERDICT r4 #5) ---------------------------------------------------------------
+
+@pytest.mark.parametrize('rows,cols,d,dist,uniq', [(400_000, 30_000, 40, 'zipf', 0.05), (300_000, 5_000, 9, 'uniform', 0.3),
+                                                   (200_000, 50_000, 100, 'zipf', 0.0), (100_000, 2_000, 150, 'uniform', 0.0)])
+def test_initial_report_pass_from_the_score_codes(gpu_device, rows, cols, d, dist, uniq):
+    """`tsem_report_colsums(initial, thresh < 0)` — no `conf` column wanted, what `output_report` asks of the initial z — finds a row's
+    best hits as its largest score codes (k_report_init_codes: integer work on packed 16-bit codes, no score-table look-up, no
+    floating point).  `exclude`, the tie list (rows and numbers of best hits) bit for bit, `average` to rounding, against the full pass
+    (k_report_rows) and the generic row pass; rows longer than the lane capacity go through the slow kernel in both."""
+    from telescope_amd._lib import Z_INITIAL
+    tl = _synthetic_tl(rows, cols, d, dist, uniq=uniq, opts=Opts(max_iter=2, em_epsilon=0.0))
+    eng = tl._eng
+    full, r1, c1 = eng.report_colsums(Z_INITIAL, 0.9)
+    fast, r2, c2 = eng.report_colsums(Z_INITIAL, -1.0)
+    assert np.array_equal(fast['exclude'], full['exclude']) and np.array_equal(r1, r2) and np.array_equal(c1, c2)
+    assert np.allclose(fast['average'], full['average'], rtol=1e-12, atol=1e-9)
+    assert len(r1) > 0 and full['exclude'].sum() + len(r1) == rows - np.count_nonzero(np.diff(eng.export_csr()[0]) == 0)
+    eng.set_option('report_kernel', 0)
+    gen, r3, c3 = eng.report_colsums(Z_INITIAL, 0.9)
+    assert np.array_equal(fast['exclude'], gen['exclude']) and np.array_equal(r2, r3) and np.array_equal(c2, c3)
+    eng.set_option('report_kernel', 1)
+    # through the class: output_report's three columns of the initial z, then `conf` (which runs the full pass after all)
+    np.random.seed(3)
+    a = [tl.reassign_colsums(m, initial=True) for m in ('exclude', 'choose', 'average')]
+    assert next(iter(tl._report_cache))[1] < 0                  # one pass, asked without a conf column
+    conf = tl.reassign_colsums('conf', 0.9, initial=True)
+    assert np.allclose(conf, full['conf'], rtol=1e-12, atol=1e-9) and np.array_equal(a[0], full['exclude'].astype(np.int64))
+
+
+def test_initial_report_pass_with_a_stored_zero_score_takes_the_full_kernel(gpu_device):
+    """A stored score of 0 (Q = 0: the entry is in z's pattern with z = 0, and a row of zeros ties all its entries) is what the
+    codes-only pass cannot tell from its padding: the library then runs the full pass, same results as the generic one."""
+    import scipy.sparse as sp
+    from telescope_amd._lib import Z_INITIAL
+    from telescope_amd.likelihood import TelescopeLikelihood
+    rng = np.random.RandomState(4)
+    n, k = 20_000, 300
+    lens = rng.randint(1, 12, n)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens]).astype(np.int32)
+    data = rng.randint(0, 40, indptr[-1]).astype(np.uint16)       # zeros included
+    data[indptr[5]:indptr[6]] = 0                                  # a row of zeros only
+    tl = TelescopeLikelihood(sp.csr_matrix((data, indices, indptr), shape=(n, k)), Opts(max_iter=2, em_epsilon=0.0), device=0)
+    eng = tl._eng
+    fast, r2, c2 = eng.report_colsums(Z_INITIAL, -1.0)
+    eng.set_option('report_kernel', 0)
+    gen, r3, c3 = eng.report_colsums(Z_INITIAL, 0.9)
+    assert np.array_equal(fast['exclude'], gen['exclude']) and np.array_equal(r2, r3) and np.array_equal(c2, c3)
+    assert np.allclose(fast['average'], gen['average'], rtol=1e-12, atol=1e-9)

@@ -32,3 +32,16 @@ for kern, lanes, wgs, ent in ((0, 0, 2, 0), (1, 0, 2, 0), (1, 0, 2, 1), (1, 128,
         ok = (np.array_equal(a[0]['exclude'], sums['exclude']) and np.array_equal(a[1], r) and np.array_equal(a[2], c)
               and np.allclose(a[0]['conf'], sums['conf'], rtol=1e-11, atol=1e-9) and np.allclose(a[0]['average'], sums['average'], rtol=1e-11, atol=1e-9))
         print('kernel=%d cap=%3d wgs=%d wgs2=%d  %-7s %7.2f ms  ties %d  same-as-generic %s' % (kern, lanes, wgs, ent, name, best * 1e3, len(r), ok), flush=True)
+# round 5: the initial z without a `conf` column (thresh < 0): best hits from the score codes alone (k_report_init_codes)
+eng.set_option('report_kernel', 1); eng.set_option('report_lanes', 0); eng.set_option('report_wgs2', 0)
+for wgs2 in (0, 1):
+    eng.set_option('report_wgs2', wgs2)
+    best = 1e9
+    for _ in range(3):
+        eng.synchronize(); t0 = time.perf_counter()
+        sums, r, c = eng.report_colsums(Z_INITIAL, -1.0)
+        best = min(best, time.perf_counter() - t0)
+    a = ref['initial']
+    ok = (np.array_equal(a[0]['exclude'], sums['exclude']) and np.array_equal(a[1], r) and np.array_equal(a[2], c)
+          and np.allclose(a[0]['average'], sums['average'], rtol=1e-11, atol=1e-9))
+    print('kernel=1 codes only (thresh < 0) wgs2=%d  initial %7.2f ms  ties %d  same-as-generic %s' % (wgs2, best * 1e3, len(r), ok), flush=True)
