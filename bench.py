@@ -496,7 +496,7 @@ def main():
             'kernel': 'EM pass k_em_fused (rank 0 shard)', 'kernel_ms': k_ms, 'kernel_launches_timed': ks['em_launches'],
             'limiter': ('LDS atomics/gathers (2-byte score codes halve the HBM bytes)'
                         if info.get('value_bytes') == 2 else
-                        'HBM stream (83-87 % of what a pure streaming read reaches on this part); the LDS work of a step is next (DESIGN.md 9.2)'),
+                        'HBM stream (83-87 % of what a pure streaming read reaches on this part); the LDS work of a step is next (profiles/HISTORY.md 9.2)'),
             'algo_bytes_per_launch': ks['algo_bytes_per_pass'],
         },
     }
@@ -580,7 +580,7 @@ def main():
         except Exception as e:   # noqa: BLE001 — never let the extra block break the bench line
             out['precision_sweep'] = dict(error=repr(e))
     if world == 1 and not args.no_reproducible_leg:
-        # option `reproducible` (exact, order-independent sums) on a 10M-row sample of the workload: what it costs
+        # option `reproducible` (exact, order-independent sums, profiles/HISTORY.md 5.1) on a 10M-row sample of the workload: what it costs
         # per EM pass and whether two independent contexts agree bit for bit (the default mode is timed beside it)
         try:
             out['reproducible_mode'] = reproducible_leg(local, min(10_000_000, args.rows), args, cdf, dist_code)

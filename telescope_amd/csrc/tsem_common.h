@@ -128,7 +128,7 @@ struct tsem_ctx {
   int64_t opt_precision = 0;        // 1: the EM pass in fp32 arithmetic (diagnostic for the config-3 tolerance sweep)
   float *d_c32 = nullptr, *d_cs32 = nullptr, *d_lut32 = nullptr;
   int64_t opt_reproducible = 0;     // 1: order-independent (exact, binned) column sums in the fused EM pass: pi / theta / lnl bit-identical from run to run,
-                                    //    two passes per iteration
+                                    //    two passes per iteration (profiles/HISTORY.md 5.1)
   uint16_t* d_ebias = nullptr;      // [Kpad] per slot: biased exponent of the bound 2^E of its contributions
   uint8_t* d_ovf = nullptr;         // [Kpad] a contribution reached its slot's bound in the last pass
   double* d_red_hi = nullptr;       // [K+2] column sums of the high pieces

@@ -2,7 +2,7 @@
 // read of the matrix) for the column-partitioned blocked-COO layout.
 //
 // Why it looks like this (measurements: profiles/r01_primitives_ubench.log,
-// profiles/r01_ring_ubench.log, profiles/r01_fused_timeline.txt):
+// profiles/r01_ring_ubench.log, profiles/r01_fused_timeline.txt; profiles/HISTORY.md 4.3):
 //   * per-entry gathers of pi*theta and scatter-adds of the column sums only keep
 //     up with the HBM stream when they hit LDS (global fp64 atomics: 22 G/s, LDS:
 //     >500 G/s); K*16 B does not fit one CU's 160 KB, so columns are split in P
@@ -101,7 +101,7 @@ struct FusedArgs {
   uint32_t* sync;       // zero-filled before launch
   const uint32_t* ctl;  // device-side loop control (tsem_em_chunk): ctl[0] != 0 -> the run has stopped, return at once
   // MODE 2 (option "reproducible"): the column scatter adds pre-rounded pieces of w*z, so that every LDS accumulator sums EXACTLY
-  // and the order in which the hardware serves the atomics stops mattering
+  // and the order in which the hardware serves the atomics stops mattering (profiles/HISTORY.md 5.1)
   const uint16_t* ebias;  // [P*Kp] biased exponent eb of the slot's bound 2^E (every contribution of the slot is < 2^E)
   int bin;                // 1: the high piece (multiples of 2^(E-30)), 2: the low piece (the remainder in multiples of 2^(E-60))
   double* partial2;       // MODE 3 (both pieces in ONE pass, a second accumulator table in LDS): the low pieces' team partials
@@ -144,7 +144,7 @@ __device__ __forceinline__ uint32_t fz_ld_u32(const uint32_t* p) {
 // hardware returns zeros (loads) or drops the write (stores).  With no branch around a load the
 // compiler can count: a use of block i's registers waits with `s_waitcnt vmcnt(n)`, n = the loads
 // issued since — with exec-masked or skipped loads it has to assume vmcnt(0), which drains the
-// memory pipe twice per step (measured: 6.09 -> 5.04 ms per pass).
+// memory pipe twice per step (measured: 6.09 -> 5.04 ms per pass, profiles/HISTORY.md 4.1).
 typedef unsigned int fz_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int fz_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int FZ_RSRC_FLAGS = 0x00027000;
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       // A WAVE whose lanes hold nothing in either set — the tail waves of a sub-block that short rows cannot fill: at
       // 10 entries per row 768 row slots fill 58 % of the register tile — skips the step's LDS work altogether.  The
       // step has a floor of LDS instruction ISSUE (~22 wave-instructions per data wave, ~8 clk each even with every lane
-      // masked); idle waves used to pay it in full.  (Wave-uniform branch around LDS operations only: the
+      // masked, profiles/HISTORY.md 9.2); idle waves used to pay it in full.  (Wave-uniform branch around LDS operations only: the
       // streaming loads below stay unconditional.)
       const bool wave_idle = FZ_SKIP_IDLE_WAVES && GEO >= 2 && !LAG &&   // (only the short-row geometry leaves whole waves idle; elsewhere the branch costs 1.5 %; MODE 4: it costs registers the log1p needs)
                              (__builtin_amdgcn_ballot_w64(!idle) | __builtin_amdgcn_ballot_w64(!idle2)) == 0ull;

@@ -3,7 +3,7 @@
 // for the call; tsem_generate: the synthetic matrix on the device, bit-exact twin of telescope_amd/synthetic.py), the score table
 // (Q = expm1((r / max) * 100), model.py:653), instrumentation and debug entry points.
 //
-// Data layout in HBM (see DESIGN.md):
+// Data layout in HBM (see DESIGN.md 3):
 //   * canonical CSR of uint16 raw scores (indptr int64, indices int32, raw u16)
 //     + the Q lookup table lut[r] = expm1(r/max*100) (model.py:653);
 //   * for the EM hot loop, the AMBIGUOUS rows (Y_i = 1, model.py:679) re-laid

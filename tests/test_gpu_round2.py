@@ -422,7 +422,7 @@ def test_integer_outputs_identical_across_runs(gpu_device):
             assert np.array_equal(a, b)
         assert np.allclose(r[2], runs[0][2], rtol=1e-12, atol=0)
         for a, b in zip(r[3], runs[0][3]):                       # float-valued modes: unordered fp64 atomics, documented
-            assert np.allclose(a, b, rtol=1e-12, atol=1e-9)      # tolerance
+            assert np.allclose(a, b, rtol=1e-12, atol=1e-9)      # tolerance (profiles/HISTORY.md 5)
     big = []
     for _ in range(2):
         tl = _synthetic_tl(5_000_000, 30000, 40, 'zipf', uniq=0.05, opts=Opts(max_iter=10, em_epsilon=0.0))
@@ -439,7 +439,7 @@ def test_integer_outputs_identical_across_runs(gpu_device):
 def test_precision_sweep_legs(gpu_device):
     """Score codes are EXACT (same fp64 numbers as the fp64 layout); fp32-rounded stored values with fp64 sums stay
     five orders inside north_star's 1e-4 bar; fp32 arithmetic and sums (diagnostic kernel) are finite, close, and
-    visibly worse — the measured reason the product accumulates in fp64.  Full-size table: DESIGN.md 9."""
+    visibly worse — the measured reason the product accumulates in fp64.  Full-size table: profiles/HISTORY.md 9."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
     import precision_sweep as ps

@@ -24,15 +24,16 @@ def short(name):
 WARMUP = 2          # launches of the EM kernel before bench.py's timed region (--warmup 2 in tools/profile.sh)
 
 
-def kernel_table(path):
+def kernel_table(path, steps=None):
     agg = defaultdict(list)
     meta = {}
     seen = defaultdict(int)
     for r in sorted(csv.DictReader(open(path)), key=lambda r: int(r['Start_Timestamp'])):
         k = short(r['Kernel_Name'])
         seen[k] += 1
-        if k.startswith('k_em_fused') and seen[k] <= WARMUP:
-            continue                                        # timed launches only: the summary then reproduces bench's kernel_ms
+        if k.startswith('k_em_fused') and (seen[k] <= WARMUP or (steps and seen[k] > WARMUP + steps)):
+            continue                                        # the launches of bench.py's TIMED region only (not its warm-up, not the phase-timing /
+                                                            # whole-call legs behind it): the summary then reproduces the line's roofline.kernel_ms
         agg[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
         meta[k] = (int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])), r['Workgroup_Size_X'], r['LDS_Block_Size'],
                    int(r['VGPR_Count']) + int(r['Accum_VGPR_Count']), r['SGPR_Count'])
@@ -67,11 +68,11 @@ def main():
     one = lambda pat: sorted(glob.glob(os.path.join(src, pat)))[0]
     bench = json.load(open(os.path.join(src, 'bench.json')))
     cmd = 'python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-sweep --no-reproducible-leg'
-    kl, avg = kernel_table(one('trace/*/*_kernel_trace.csv'))
+    kl, avg = kernel_table(one('trace/*/*_kernel_trace.csv'), steps=6)
     with open(os.path.join(ROOT, 'profiles', prefix + '_fused_kernel_stats.txt'), 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats -- %s   (default workload; the run times the headline fp64\n'
                 '# layout k_em_fused<4, 0, 2, 0> and then the 2-byte-code layout k_em_fused<4, 0, 1, 0>;\n# template arguments: team size, mode (0 EM / 1 lnl), entry format, geometry)\n'
-                '# k_em_fused rows: the %d warm-up launches of each engine are left out (timed launches only).  lds_B is the STATIC\n'
+                '# k_em_fused rows: the 6 launches of the TIMED region of each engine (the %d warm-up launches before it and the phase-timing / whole-call legs behind it are left out).  lds_B is the STATIC\n'
                 '# allocation; the fused kernel allocates its LDS dynamically: %s B per workgroup (tsem.hip fz_lds_bytes).\n'
                 % (cmd, WARMUP, bench['config']['layout'].get('lds_bytes', 'n/a')))
         f.write('\n'.join(kl) + '\n')

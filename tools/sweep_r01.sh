@@ -1,5 +1,5 @@
 #!/bin/bash
-# the rows of DESIGN.md section 9: shard sizes, config-5-like shard, uniform columns, two-pass, both entry formats
+# the rows of profiles/HISTORY.md section 9: shard sizes, config-5-like shard, uniform columns, two-pass, both entry formats
 C="--steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout"
 for f in code16 f64; do
   echo "== value format $f"
