@@ -147,6 +147,9 @@ struct tsem_ctx {
   double* d_lctab = nullptr;        // [Kpad] log(pi * theta), permuted like d_ctab; rebuilt before every pass that reads it
   double* d_lqtab = nullptr;        // [lq_n] log Q: per score code (code entries), or indexed by the top bits of Q (fp64 entries)
   int lq_n = 0, lq_shift = 0, lq_base = 0;   // fp64 entries: index = (high word of Q >> lq_shift) - lq_base
+  bool lq_tab_fits = false;         // the log Q table fits the LDS the layout leaves
+  int lq_lin = 0, lq_c0 = 0;        // code entries with the reference's own score table: log Q = (code * lq_a) * lq_b from lq_c0 on (no table at all)
+  double lq_a = 0, lq_b = 0;
   bool lq_tried = false;            // the tables were attempted for this layout (lq_n == 0 afterwards: they do not fit / do not apply)
   bool lag_agreed = false;          // row-sharded runs: EVERY rank can run MODE 4 (decided once per run, dropped for good after a time-out anywhere)
   bool lag_valid = false;           // the iteration committed last still owes its lnl, and d_rinv / d_ctab_prev are what the next MODE 4 pass needs for it

@@ -533,10 +533,29 @@ static int ensure_log_tables(tsem_ctx* h) {
   if (fmt == 0 || !h->use_fused || h->split || h->lut_len <= 1 || (int)h->lut_host.size() != h->lut_len) return TSEM_OK;
   const size_t room = (size_t)(TS_LDS_MAX - 1024) - fz_lds_bytes(h, true);
   std::vector<double> tab;
+  h->lq_lin = 0;
   if (fmt == 1) {
-    if ((size_t)h->lut_len * 8 > room) return TSEM_OK;
+    // The reference's table (model.py:653: Q = expm1((code * (1 / max)) * 100.)) has log Q = t to the last bits once t = (code / max) * 100
+    // >= 38: then the kernel needs no log Q table at all — which is what lets the layouts whose row slots fill the LDS (short rows
+    // at K = 30k) use the log form too.  Checked code by code against log(lut[code]); any other table takes the look-up.
+    {
+      const int mx = h->lut_len - 1;
+      const double a = 1.0 / (double)mx, b = std::nearbyint(std::log1p(h->lut_host[mx]));
+      int c0 = -1;
+      bool ok = mx >= 1 && b >= 40.0 && b <= 700.0;
+      for (int r = 1; r <= mx && ok; ++r) {
+        const double t = ((double)r * a) * b;
+        if (t < 38.0) continue;
+        if (c0 < 0) c0 = r;
+        const double lq = std::log(h->lut_host[r]);
+        ok = std::fabs(lq - t) <= 4.0 * (std::nextafter(t, INFINITY) - t);
+      }
+      if (ok && c0 > 0) { h->lq_lin = 1; h->lq_c0 = c0; h->lq_a = a; h->lq_b = b; }
+    }
+    h->lq_tab_fits = (size_t)h->lut_len * 8 <= room;
+    if (!h->lq_lin && !h->lq_tab_fits) return TSEM_OK;
     tab.resize(h->lut_len);
-    for (int i = 0; i < h->lut_len; ++i) tab[i] = std::log(h->lut_host[i]);   // (log 0 = -inf)
+    for (int i = 0; i < h->lut_len; ++i) tab[i] = std::log(h->lut_host[i]);   // (log 0 = -inf; kept for layout_info / when the table is not the reference's)
     h->lq_shift = 0; h->lq_base = 0;
   } else {
     auto hi = [](double q) { int64_t b; std::memcpy(&b, &q, 8); return (int)(b >> 32); };
@@ -607,14 +626,16 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
 
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
   size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
-  A.lctab = nullptr; A.lqtab = nullptr; A.lq_n = 0; A.lq_shift = 0; A.lq_base = 0;
+  A.lctab = nullptr; A.lqtab = nullptr; A.lq_n = 0; A.lq_shift = 0; A.lq_base = 0; A.lq_lin = 0; A.lq_c0 = 0; A.lq_a = 0; A.lq_b = 0;
   if (mode == 1 && !(h->opt_dbg & 8192)) {                  // (fused_dbg bit 13: the per-entry logarithm, for A/B timing and tests)
     if (int rc = ensure_log_tables(h)) return rc;
     if (h->lq_n > 0) {
       k_log_tab<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->d_ctab, h->d_lctab);
       TSEM_HIP(hipGetLastError());
       A.lctab = h->d_lctab; A.lqtab = h->d_lqtab; A.lq_n = h->lq_n; A.lq_shift = h->lq_shift; A.lq_base = h->lq_base;
-      ldsf += (size_t)h->lq_n * 8;
+      A.lq_lin = (fz_fmt(h) == 1 && !((h->opt_dbg & 16384) && h->lq_tab_fits)) ? h->lq_lin : 0;   // (fused_dbg bit 14: the look-up even where the arithmetic form applies — tests)
+      A.lq_c0 = h->lq_c0; A.lq_a = h->lq_a; A.lq_b = h->lq_b;
+      if (!A.lq_lin) ldsf += (size_t)h->lq_n * 8;
       kmode = 9;
     }
   }

@@ -128,7 +128,12 @@ struct FusedArgs {
   // log tables (round 5; MODE 1 and MODE 4 with the score table in LDS): log1p(Q c) = log Q + log c + 1 / (Q c) wherever Q c >= 2^27
   const double* lctab;    // [P*Kp] log(pi * theta) of the parameters whose log1p the pass takes (MODE 1: takes ctab2's place in LDS; MODE 4: a fourth table)
   const double* lqtab;    // [lq_n] log Q — FMT 1: per score code; FMT 2: index = (high word of Q >> lq_shift) - lq_base
-  int lq_n, lq_shift, lq_base;   // lq_n == 0: no log tables, every term goes through fz_log1p_tab
+  int lq_n, lq_shift, lq_base;   // lq_n == 0 (and lq_lin == 0): no log tables, every term goes through fz_log1p_tab
+  // FMT 1 with the reference's score table Q = expm1((code * (1 / max)) * scale) (model.py:653): log Q = t - e^-t + ... IS t = (code * lq_a) * lq_b
+  // to the last bits once t >= 38 — no table, no gather: two multiplications.  The host checks it against log(lut[code]) code by code
+  // (ensure_log_tables); codes below lq_c0 (t < 38: absent from alignment data, whose Q starts at e^46) take the exact branch.
+  int lq_lin, lq_c0;
+  double lq_a, lq_b;
   int dbg;              // bit0: skip partner loads (timing experiments only; wrong results)
                         // bit5 / bit6: behave like a hand-off time-out in the EM / lnl pass (tests of the recovery path)
   unsigned long long* prof;   // optional per-step timestamps of team 0 / member 0
@@ -260,17 +265,20 @@ __device__ __forceinline__ double fz_log1p_tab(double x, const double2* __restri
 //     four times per lane, spilled 116 VGPRs in the fp64-entry kernel.)
 constexpr double FZ_L_FAST = 18.715, FZ_L_ZERO = -40.0;
 template <bool CERR, class F>
-__device__ __forceinline__ double fz_log1p_of_log(double L, F&& exact_x, const double2* __restrict__ tab) {
+__device__ __forceinline__ double fz_log1p_of_log(double L, F&& exact_x, const double2* __restrict__ tab, bool force_exact = false, bool live = true) {
   double v = L + (double)__expf(-(float)L);                // (L = -inf: NaN, replaced below)
-  const bool slow = L < FZ_L_FAST;                         // ONE compare on the fast path; everything else hides behind the wave-uniform branch
+  // ONE compare on the fast path; everything else hides behind the wave-uniform branch.  Lanes whose z is 0 (`live` false: the padding
+  // of a sub-block's last quads, columns whose previous pi*theta is 0) never take it — with the arithmetic log Q the padding's L is an
+  // ordinary number, and one wave per step walking into the exact branch (a global load) cost 1 ms of a 4.4 ms pass.
+  const bool slow = ((L < FZ_L_FAST) | force_exact) & live;
   if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {
-    const bool mid = slow & (L >= FZ_L_ZERO);
+    const bool mid = slow & ((L >= FZ_L_ZERO) | force_exact);
     if (slow) v = 0.0;
     if (__builtin_amdgcn_ballot_w64(mid) != 0ull) {
       if (mid) v = fz_log1p_tab<CERR>(exact_x(), tab);
     }
   }
-  return v;                                                // always finite: callers need no `z != 0` guard (0 * v = 0)
+  return live ? v : 0.0;                                   // always finite: z * v is safe to add
 }
 // FMT 2 (fp64 entries, score table in LDS): log Q from Q's top bits — the host proved the index unique over the score table
 __device__ __forceinline__ double fz_logq_of(double q, const double* __restrict__ lqS, int lq_n, int lq_shift, int lq_base) {
@@ -633,10 +641,10 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   // MODE 1 / 4 with log tables: log Q behind the score table [lq_n]
   constexpr bool LT = MODE == 9;
   double* const lqS = lutS + A.lut_len;
-  if (LT)
+  if (LT && !(FMT == 1 && A.lq_lin))
     for (int t = tid; t < A.lq_n; t += FZ_NT) lqS[t] = A.lqtab[t];
   // MODE 1: [FZ_LOGTAB] (1 / c_i, log c_i) for fz_log1p_tab, in the same place as MODE 2's table (the two modes never share a launch)
-  double2* const logtab = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(lutS + A.lut_len + (LT ? A.lq_n : 0)) + 15) & ~(uintptr_t)15);
+  double2* const logtab = reinterpret_cast<double2*>((reinterpret_cast<uintptr_t>(lutS + A.lut_len + ((LT && !(FMT == 1 && A.lq_lin)) ? A.lq_n : 0)) + 15) & ~(uintptr_t)15);
   if ((LNL1 || LAG || SPL) && tid < FZ_LOGTAB) {
     const double ci = 1.0 + (double)tid * (1.0 / FZ_LOGTAB);
     logtab[tid] = make_double2(1.0 / ci, ts_log1p_pos((double)tid * (1.0 / FZ_LOGTAB)));
@@ -823,8 +831,8 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
             const double za = (qa * c[ja]) * sb[rca >> 16], zb = (qb * c[jb]) * sb[rcb >> 16];
             const double La = la + acc[ja], Lb = lb + acc[jb];
             __builtin_amdgcn_sched_barrier(0);
-            lsum = fma(za, fz_log1p_of_log<true>(La, [&]() { return qa * cg[ja]; }, logtab), lsum);   // (always finite; padding has z = 0)
-            lsum = fma(zb, fz_log1p_of_log<true>(Lb, [&]() { return qb * cg[jb]; }, logtab), lsum);
+            lsum = fma(za, fz_log1p_of_log<true>(La, [&]() { return qa * cg[ja]; }, logtab, false, za != 0.0), lsum);   // (always finite; padding has z = 0)
+            lsum = fma(zb, fz_log1p_of_log<true>(Lb, [&]() { return qb * cg[jb]; }, logtab, false, zb != 0.0), lsum);
           };
           if (FMT == 1) {
             const uint32_t k0 = rr.cd.x & 0xFFFFu, k1 = rr.cd.x >> 16, k2 = rr.cd.y & 0xFFFFu, k3 = rr.cd.y >> 16;
@@ -832,12 +840,20 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
             const double q0 = lutS[k0], q1 = lutS[k1], q2 = lutS[k2], q3 = lutS[k3];
             const double z0 = (q0 * c[j0]) * sb[rr.rc.x >> 16], z1 = (q1 * c[j1]) * sb[rr.rc.y >> 16];
             const double z2 = (q2 * c[j2]) * sb[rr.rc.z >> 16], z3 = (q3 * c[j3]) * sb[rr.rc.w >> 16];
-            const double L0 = lqS[k0] + acc[j0], L1 = lqS[k1] + acc[j1], L2 = lqS[k2] + acc[j2], L3 = lqS[k3] + acc[j3];
+            const bool lin = A.lq_lin != 0;                // (a kernel argument: wave-uniform)
+            double l0, l1, l2, l3;
+            bool f0 = false, f1 = false, f2 = false, f3 = false;
+            if (lin) {                                     // log Q = (code * (1 / max)) * scale: no gather
+              l0 = ((double)k0 * A.lq_a) * A.lq_b; l1 = ((double)k1 * A.lq_a) * A.lq_b;
+              l2 = ((double)k2 * A.lq_a) * A.lq_b; l3 = ((double)k3 * A.lq_a) * A.lq_b;
+              f0 = (int)k0 < A.lq_c0; f1 = (int)k1 < A.lq_c0; f2 = (int)k2 < A.lq_c0; f3 = (int)k3 < A.lq_c0;   // (the padding's code 0 has z = 0: not live)
+            } else { l0 = lqS[k0]; l1 = lqS[k1]; l2 = lqS[k2]; l3 = lqS[k3]; }
+            const double L0 = l0 + acc[j0], L1 = l1 + acc[j1], L2 = l2 + acc[j2], L3 = l3 + acc[j3];
             __builtin_amdgcn_sched_barrier(0);
-            lsum = fma(z0, fz_log1p_of_log<true>(L0, [&]() { return q0 * cg[j0]; }, logtab), lsum);
-            lsum = fma(z1, fz_log1p_of_log<true>(L1, [&]() { return q1 * cg[j1]; }, logtab), lsum);
-            lsum = fma(z2, fz_log1p_of_log<true>(L2, [&]() { return q2 * cg[j2]; }, logtab), lsum);
-            lsum = fma(z3, fz_log1p_of_log<true>(L3, [&]() { return q3 * cg[j3]; }, logtab), lsum);
+            lsum = fma(z0, fz_log1p_of_log<true>(L0, [&]() { return q0 * cg[j0]; }, logtab, f0, z0 != 0.0), lsum);
+            lsum = fma(z1, fz_log1p_of_log<true>(L1, [&]() { return q1 * cg[j1]; }, logtab, f1, z1 != 0.0), lsum);
+            lsum = fma(z2, fz_log1p_of_log<true>(L2, [&]() { return q2 * cg[j2]; }, logtab, f2, z2 != 0.0), lsum);
+            lsum = fma(z3, fz_log1p_of_log<true>(L3, [&]() { return q3 * cg[j3]; }, logtab, f3, z3 != 0.0), lsum);
           } else {
             pair(rr.v0.x, rr.v0.y, fz_logq_of(rr.v0.x, lqS, A.lq_n, A.lq_shift, A.lq_base), fz_logq_of(rr.v0.y, lqS, A.lq_n, A.lq_shift, A.lq_base),
                  rr.rc.x, rr.rc.y);

@@ -615,6 +615,7 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[26] = h->em_rows ? 1 : 0;                           // K beyond 64 column parts: plain CSR row passes (no blocked layout)
   info[25] = h->n_single_part;                             // ambiguous rows whose entries all lie in ONE column part (they would need no exchange)
   info[24] = h->split ? 1 : 0;                             // split layout: two light passes per iteration (K > 61 440)
+  info[28] = h->lq_lin;                                    // ... and log Q is (code / max) * scale itself: no table (code entries, the reference's score table)
   info[27] = h->lq_n;                                      // entries of the log Q table of the lnl passes (0: not built yet / does not fit / does not apply)
   info[23] = h->lnl3 ? 1 : 0;                              // the layout lets the EM pass carry the previous iteration's log-likelihood (option "use_likelihood")
   return TSEM_OK;

@@ -127,6 +127,49 @@ def test_lnl_pass_with_log_tables_equals_the_per_entry_logarithm(gpu_device, fmt
     assert abs(vals[0][0] - vals[8192][0]) <= 1e-13 * abs(vals[8192][0]), vals
     if (rows, cols, d) == (400_000, 30_000, 40):
         assert vals[0][1] > 0, 'the bench geometry (40 per row, K = 30k) leaves room for the log tables'
+    if fmt == 2:
+        # score codes with the reference's own table: log Q = (code / max) * 100 needs no table (layout_info 'lnl_linear'), so even the
+        # layouts whose row slots fill the LDS take the log form; fused_dbg bit 14 forces the table look-up where it fits: same value
+        tl = _synthetic_tl(rows, cols, d, 'zipf', uniq=0.05, options=(('value_format', fmt), ('fused_dbg', 16384)), opts=Opts(max_iter=6, em_epsilon=0.0))
+        tl.em()
+        info = tl._eng.layout_info()
+        assert info['lnl_linear'] == 1
+        assert abs(tl.lnl - vals[0][0]) <= 1e-13 * abs(vals[0][0])
+
+
+def test_lnl_log_form_on_a_layout_whose_row_slots_fill_the_lds(gpu_device):
+    """K = 30k with 12 entries per row: 1152 row slots take the LDS, no room for a log Q table — with score codes and the reference's
+    table the pass needs none (log Q = (code / max) * 100).  Against the per-entry logarithm and the C oracle; and a score table that
+    is NOT the reference's (rounded to 11 bits) falls back to the table / the per-entry form with the same results."""
+    from oracle import em_fused as oc
+    rows, cols, d = 600_000, 30_000, 12
+    out = {}
+    for dbg in (0, 8192):
+        tl = _synthetic_tl(rows, cols, d, 'zipf', uniq=0.05, options=(('fused_dbg', dbg),), opts=Opts(max_iter=5, em_epsilon=0.0))
+        tl.em()
+        info = tl._eng.layout_info()
+        assert info['fused'] == 1 and info['value_bytes'] == 2 and info['geometry'] >= 2, info
+        out[dbg] = (tl.lnl, info)
+        if dbg == 0:
+            ip, ix, rw = tl._eng.export_csr()
+            ref = oc.em_fused_arrays(ip, ix, rw, cols, 0, 200000, 0.0, 5)
+    assert out[0][1]['lnl_linear'] == 1 and out[0][1]['lnl_tables'] > 0
+    assert abs(out[0][0] - ref['lnl']) <= RTOL * abs(ref['lnl']) and abs(out[0][0] - out[8192][0]) <= 1e-13 * abs(out[0][0])
+    # a rounded score table: the arithmetic form is refused by the host's check
+    from telescope_amd import _lib, synthetic
+    from telescope_amd.likelihood import TelescopeLikelihood
+    eng = _lib.Engine(0)
+    eng.generate(0, 200_000, 5_000, synthetic.poisson_cdf_u32(20), 42, synthetic.DIST_CODE['zipf'], 0.05)
+    t2 = TelescopeLikelihood.from_engine(eng, Opts(max_iter=4, em_epsilon=0.0), lut_mantissa_bits=11)
+    t2.em()
+    i2 = eng.layout_info()
+    assert i2['lnl_linear'] == 0 and i2['lnl_tables'] > 0
+    eng3 = _lib.Engine(0)
+    eng3.set_option('fused_dbg', 8192)
+    eng3.generate(0, 200_000, 5_000, synthetic.poisson_cdf_u32(20), 42, synthetic.DIST_CODE['zipf'], 0.05)
+    t3 = TelescopeLikelihood.from_engine(eng3, Opts(max_iter=4, em_epsilon=0.0), lut_mantissa_bits=11)
+    t3.em()
+    assert abs(t2.lnl - t3.lnl) <= 1e-13 * abs(t3.lnl)
 
 
 def test_lnl_log_tables_with_dying_and_dead_columns(gpu_device):
