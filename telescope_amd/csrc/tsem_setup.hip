@@ -302,6 +302,21 @@ __global__ __launch_bounds__(64) void k_sb_count_pc(int64_t nb, int P, const int
     if (threadIdx.x == 0 && q < P) sb_cnt[b * P + q] = t;
   }
 }
+// sub-block counts -> padded sizes (in place), with the largest count and the sum of the counts on the way
+__global__ __launch_bounds__(256) void k_sb_pad(int64_t n, int64_t* __restrict__ cnt, unsigned long long* __restrict__ st /* [0] max, [1] sum */) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long c = i < n ? cnt[i] : 0;
+  if (i < n) cnt[i] = (c + (TS_STRANDS * 4 - 1)) / (TS_STRANDS * 4) * (TS_STRANDS * 4);
+  long long m = c, sm = c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { m = max(m, __shfl_xor(m, o, 64)); sm += __shfl_xor(sm, o, 64); }
+  if ((threadIdx.x & 63) == 0 && sm) { atomicMax(&st[0], (unsigned long long)m); atomicAdd(&st[1], (unsigned long long)sm); }
+}
+// entry offsets -> quad offsets of the fused kernel (n offsets + one trailing zero)
+__global__ void k_sb_q32(int64_t n, const int64_t* __restrict__ off, uint32_t* __restrict__ q32) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) q32[i] = i < n ? (uint32_t)(off[i] >> 2) : 0u;
+}
 // layout statistic: ambiguous rows whose entries all fall into ONE column part (such a row's normaliser needs no exchange)
 __global__ __launch_bounds__(256) void k_single_part_rows(int64_t na, const unsigned long long* __restrict__ pc, unsigned long long* __restrict__ out) {
   unsigned n = 0;
@@ -1124,39 +1139,46 @@ int tsem_build_layout(tsem_ctx* h) {
     TSEM_HIP(hipGetLastError());
   }
   pt.lap("layout: part counts, blocks, slots");
-  // 4. sub-block sizes -> offsets
-  std::vector<int64_t> sb(nb * P + 1, 0);
+  // 4. sub-block sizes -> offsets, on the device (round 5: the counts used to travel to the host and the offsets back, 12 MB of
+  //    pageable copies and a host loop: 2.3 ms at 146k blocks): pad every count to TS_STRANDS*4 entries, exclusive scan, 32-bit quad
+  //    offsets for the fused kernel; three scalars come back (largest sub-block, stored entries, padded total)
+  int64_t off = 0;
+  TSEM_ALLOC(h->d_sb_off, nb * P + 1);
   if (nb) {
     int64_t* d_cnt = nullptr;
-    TSEM_SCOPED(d_cnt);
-    TSEM_ALLOC(d_cnt, nb * P);
+    unsigned long long* d_st = nullptr;
+    TSEM_SCOPED(d_cnt); TSEM_SCOPED(d_st);
+    TSEM_ALLOC(d_cnt, nb * P + 1); TSEM_ALLOC(d_st, 2);
+    TSEM_HIP(hipMemsetAsync(d_st, 0, 16, h->stream));
+    TSEM_HIP(hipMemsetAsync(d_cnt + nb * P, 0, 8, h->stream));
     if (d_pc) k_sb_count_pc<<<(unsigned)nb, 64, 0, h->stream>>>(nb, P, d_bs, d_pc, d_cnt);
     else k_sb_count<<<(unsigned)nb, 256, 0, h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_colmap, d_cnt);
+    k_sb_pad<<<cdiv64(nb * P, 256), 256, 0, h->stream>>>(nb * P, d_cnt, d_st);
     TSEM_HIP(hipGetLastError());
-    TSEM_HIP(hipMemcpyAsync(sb.data(), d_cnt, sizeof(int64_t) * nb * P, hipMemcpyDeviceToHost, h->stream));
+    size_t tb = 0;
+    TSEM_HIP(rocprim::exclusive_scan(nullptr, tb, d_cnt, h->d_sb_off, (int64_t)0, (size_t)(nb * P + 1), rocprim::plus<int64_t>(), h->stream));
+    void* tmp = nullptr;
+    TSEM_SCOPED(tmp);
+    TSEM_HIP(hipMalloc(&tmp, tb ? tb : 1));
+    TSEM_HIP(rocprim::exclusive_scan(tmp, tb, d_cnt, h->d_sb_off, (int64_t)0, (size_t)(nb * P + 1), rocprim::plus<int64_t>(), h->stream));
+    unsigned long long st[2] = {0, 0};
+    TSEM_HIP(hipMemcpyAsync(st, d_st, 16, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(&off, h->d_sb_off + nb * P, 8, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
+    h->nnz_amb += (int64_t)st[1];
+    if (h->use_fused) {
+      h->max_subblock = (int64_t)st[0];
+      if ((int64_t)st[0] > fz_cap(h->geo)) h->use_fused = false;
+    }
+  } else {
+    TSEM_HIP(hipMemsetAsync(h->d_sb_off, 0, 8, h->stream));
+    if (h->use_fused) h->max_subblock = 0;
   }
-  if (h->use_fused) {
-    int64_t mx = 0;
-    for (int64_t i = 0; i < nb * P; ++i) mx = std::max(mx, sb[i]);
-    h->max_subblock = mx;
-    if (mx > fz_cap(h->geo)) h->use_fused = false;
-  }
-  int64_t off = 0;
-  for (int64_t i = 0; i < nb * P; ++i) {   // sub-blocks padded to TS_STRANDS*4 entries (strand-transposed order)
-    h->nnz_amb += sb[i];
-    int64_t c = (sb[i] + (TS_STRANDS * 4 - 1)) / (TS_STRANDS * 4) * (TS_STRANDS * 4);
-    sb[i] = off; off += c;
-  }
-  sb[nb * P] = off;
   h->nnz_pad = off;
-  TSEM_ALLOC(h->d_sb_off, nb * P + 1);
-  TSEM_HIP(hipMemcpy(h->d_sb_off, sb.data(), sizeof(int64_t) * (nb * P + 1), hipMemcpyHostToDevice));
   if (h->use_fused && (off >> 2) < 0xFFFFFFFFll) {
-    std::vector<uint32_t> q32(nb * P + 2, 0);
-    for (int64_t i = 0; i <= nb * P; ++i) q32[i] = (uint32_t)(sb[i] >> 2);
     TSEM_ALLOC(h->d_sb_q32, nb * P + 2);
-    TSEM_HIP(hipMemcpy(h->d_sb_q32, q32.data(), sizeof(uint32_t) * (nb * P + 2), hipMemcpyHostToDevice));
+    k_sb_q32<<<cdiv64(nb * P + 2, 256), 256, 0, h->stream>>>(nb * P + 1, h->d_sb_off, h->d_sb_q32);
+    TSEM_HIP(hipGetLastError());
   } else if (h->use_fused) {
     h->use_fused = false;
   }

@@ -181,11 +181,11 @@ def test_load_shard_reads_exactly_the_ranks_fragments(tmp_path):
 def test_load_shard_keeps_a_ranks_memory_below_the_file_size(tmp_path):
     """A rank of a 2-way run must not read the whole checkpoint: the peak memory `load_shard` allocates in a fresh process stays below 0.6 x
     the file size (it reads the row pointers, its half of the entries, and no fragment names), where `Telescope.load` needs more than
-    the file.  A 1.5M-fragment checkpoint written with the reference's schema (~250 MB)."""
+    the file.  An 800k-fragment checkpoint written with the reference's schema (~150 MB)."""
     import scipy.sparse as sp
     from telescope_amd import synthetic
     from telescope_amd.run_container import Telescope
-    n, k = 1_500_000, 3000
+    n, k = 800_000, 3000
     ip, ix, rw = synthetic.generate(n, k, 20.0, seed=3, dist='zipf', uniq_frac=0.05)
     ts = Telescope()
     ts.raw_scores = sp.csr_matrix((rw, ix, ip), shape=(n, k))
