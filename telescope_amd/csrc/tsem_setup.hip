@@ -552,8 +552,10 @@ constexpr int DC_NT = 256;
 // place with selects — every position is a compile-time constant of the unrolled walk.  The round-2 version built a
 // permutation and applied it with 128 scattered loads per window afterwards: 8192 vector-cache address cycles per
 // wave against 1536 for reading the window, which was most of its 14 ms at 2e9 entries.
-__global__ __launch_bounds__(DC_NT) void k_sb_deconflict(int64_t n_win, const uint32_t* __restrict__ prc_in, const uint16_t* __restrict__ code_in,
-                                                          uint32_t* __restrict__ prc_out, uint16_t* __restrict__ code_out) {
+// Round 5: IN PLACE (a thread reads its whole window into registers before it writes it back, and windows are disjoint): no second
+// copy of the layout — 6 B per entry less at the peak of a build, two GB-sized hipMalloc / hipFree pairs less.
+__global__ __launch_bounds__(DC_NT) void k_sb_deconflict(int64_t n_win, const uint32_t* prc_in, const uint16_t* code_in,
+                                                          uint32_t* prc_out, uint16_t* code_out) {
   for (int64_t w = (int64_t)blockIdx.x * DC_NT + threadIdx.x; w < n_win; w += (int64_t)gridDim.x * DC_NT) {
     const int64_t base = w * 64;
     const uint4* pin = reinterpret_cast<const uint4*>(prc_in + base);
@@ -1213,12 +1215,10 @@ int tsem_build_layout(tsem_ctx* h) {
   // row 2.70 -> 2.48 (profiles/r02_sweep.txt, r02_sweep_short.txt).
   h->sorted_layout = h->use_fused && R * P <= FILL_MAX_RP &&   // (the fill kernel keeps R x P counters in LDS)
                      (h->opt_sorted >= 0 ? h->opt_sorted != 0 : true);
-  // temporaries of the fill / conflict-aware order: allocated BEFORE the kernels go out (a hipMalloc of gigabytes next to a running
-  // kernel took 60-300 ms in round 5's first attempt at overlapping this section), freed after the one synchronisation behind them
+  // (the small table of the fill lives until the one synchronisation behind the kernels; nothing GB-sized is allocated next to a
+  //  running kernel: that took 60-300 ms in round 5's first attempt at overlapping this section)
   uint8_t* d_lgtab = nullptr;
-  uint32_t* prc2 = nullptr; uint16_t* code2 = nullptr;
-  TSEM_SCOPED(d_lgtab); TSEM_SCOPED(prc2); TSEM_SCOPED(code2);
-  bool swap_deconflicted = false;
+  TSEM_SCOPED(d_lgtab);
   if (nb && h->sorted_layout) {
     // the popularity ids stand in for the column-map gather when every row's ids are written (they are: k_row_partcounts +
     // k_rid16_rows above) and the split columns' ids fit the small table
@@ -1241,7 +1241,6 @@ int tsem_build_layout(tsem_ctx* h) {
     // (reproducible mode keeps the row order: a row's entries in a sub-block then form ONE run, which ends in at most two LDS
     // atomics on its row sum — two additions commute, three need not)
     const bool deconflict = h->fmt_code && h->opt_deconflict != 0 && !h->opt_reproducible && off >= 64;
-    if (deconflict) { TSEM_ALLOC(prc2, off); TSEM_ALLOC(code2, off); }
     const uint32_t magicP = (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P);
     k_sb_fill_sorted<<<(unsigned)nb, 256, fill_lds_bytes(R, P), h->stream>>>(na, R, P, h->d_slot_row, h->d_indptr, h->d_indices, h->d_raw, h->d_lut,
                                                          h->d_colmap, h->d_sb_off, h->d_pval, h->d_pcode, h->d_prc,
@@ -1250,9 +1249,8 @@ int tsem_build_layout(tsem_ctx* h) {
     if (deconflict) {
       const int64_t n_win = off / 64;
       k_sb_deconflict<<<(unsigned)std::min<int64_t>(n_win / DC_NT + 1, (int64_t)h->n_cu * 32), DC_NT, 0, h->stream>>>(
-          n_win, h->d_prc, h->d_pcode, prc2, code2);
+          n_win, h->d_prc, h->d_pcode, h->d_prc, h->d_pcode);
       TSEM_HIP(hipGetLastError());
-      swap_deconflicted = true;
     }
     // While the device fills the layout (15 ms at 2e9 entries) the host loads the code object of the fused kernel's unit — 3 ms in a
     // fresh process, at the first hipFuncSetAttribute / launch of one of its kernels — instead of doing so afterwards.
@@ -1261,11 +1259,6 @@ int tsem_build_layout(tsem_ctx* h) {
       if (f0) (void)hipFuncSetAttribute((const void*)f0, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024);
     }
     TSEM_HIP(hipStreamSynchronize(h->stream));
-    if (swap_deconflicted) {
-      (void)hipFree(h->d_prc); (void)hipFree(h->d_pcode);
-      h->d_prc = prc2; h->d_pcode = code2;
-      prc2 = nullptr; code2 = nullptr;                     // (ownership moved to the context)
-    }
     // option "drop_csr_indices": the fill was the last reader of the CSR column ids (the report pass and this layout carry 2-byte
     // popularity ids; col = col_of_id[id]): 10 instead of 14 B per stored entry stay resident.
     if (rid_fill && h->d_col_of_id && (h->opt_drop_indices == 1 || (h->opt_drop_indices < 0 && h->nnz >= 4000000000ll))) dfree(h->d_indices);
