@@ -384,6 +384,16 @@ class TelescopeLikelihood(object):
             lg.debug("time: {}".format(perf_counter() - xtime))
         if timing_was is not None:
             eng.set_option('kernel_timing', timing_was)
+        # A fall-back to the two-pass kernels (the persistent kernel could not keep its workgroups co-resident: a GPU shared with another
+        # process, a CU mask) costs 3-6 x per iteration from then on: say so where the caller's log goes, not only on the library's stderr
+        try:
+            fb = int(eng.layout_info().get('fallbacks', 0))
+        except Exception:                                   # noqa: BLE001 — (a tests-only engine without layout_info)
+            fb = 0
+        if fb > getattr(self, '_fallbacks_seen', 0):
+            lg.warning('telescope_amd: the fused EM kernel fell back to the two-pass kernels (%d time(s)): this GPU is shared or masked; '
+                       'iterations run 3-6x slower from here on' % fb)
+            self._fallbacks_seen = fb
         if chunked:
             self.pi_init, self.theta_init = eng.get_params(Z_FIRST)
         self.pi, self.theta = eng.get_params(Z_CUR)
