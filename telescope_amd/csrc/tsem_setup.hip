@@ -140,7 +140,10 @@ __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, 
   for (int64_t i = (int64_t)blockIdx.x * ngrp + grp; i < N; i += (int64_t)gridDim.x * ngrp) {
     const int64_t s = indptr[i];
     const int len = (int)(indptr[i + 1] - s);
-    const uint64_t hrow = ts_mix64(0x7715ull ^ ((uint64_t)(row_offset + i) * TS_GOLDEN));   // the row half of ts_hash3
+    // the row half of the hash: a full 64-bit mix once per lane and row; the entry half (round 5) is a 32-bit multiply-xorshift of the
+    // score — ~6 instead of ~20 instructions per entry: the kernel is bound by its arithmetic, and all the signature has to do is tell
+    // columns with EQUAL counts apart (a filter: k_update still ties two columns only while their sums agree to 1e-12)
+    const uint32_t hrow = (uint32_t)(ts_mix64(0x7715ull ^ ((uint64_t)(row_offset + i) * TS_GOLDEN)) >> 32);
     for (int k0 = E * gl; k0 < len; k0 += E * G) {         // (the arrays carry TS_ENTRY_PAD entries of padding)
       cs_u32x4_a4 ix[4]; cs_u32x4_a2 cd[2];
 #pragma unroll
@@ -152,8 +155,10 @@ __global__ __launch_bounds__(1024) void k_colsig(int64_t N, int64_t row_offset, 
         const int c = (int)ix[j / 4][j & 3] - col_base;
         if (k0 + j < len && c >= 0 && c < SIG_WIN) {
           const uint32_t w = cd[j / 8][(j / 2) & 3];
-          const uint64_t r = (j & 1) ? w >> 16 : w & 0xFFFFu;
-          atomicAdd(&hh[c], (ts_mix64(hrow ^ (r * TS_M1)) & 0xFFFFFFFF00000000ull) | 1ull);
+          const uint32_t r = (j & 1) ? w >> 16 : w & 0xFFFFu;
+          uint32_t hv = hrow ^ (r * 0x9E3779B1u);
+          hv ^= hv >> 15; hv *= 0x85EBCA77u; hv ^= hv >> 13;
+          atomicAdd(&hh[c], ((unsigned long long)hv << 32) | 1ull);
         }
       }
     }
@@ -177,11 +182,13 @@ __global__ __launch_bounds__(LM ? 1024 : 256) void k_row_partcounts(int64_t N_am
     unsigned long long* __restrict__ out /* [N_amb][2] */, uint16_t* __restrict__ rid /* popularity ids (k_report_rows) or null */, int P) {
   constexpr int E = 16;
   extern __shared__ uint32_t pc_cm[];                      // LM: [K]
+  // (round 5) the table holds what the loop needs of a column — part << 24 | popularity id — instead of the column-map word: no
+  // multiply per entry; and a step counts its (at most 16) entries per part in 8-bit fields of ONE word, widened once per step
+  auto pack = [&](uint32_t cmw) -> uint32_t { const uint32_t p = cmw >> CM_PS; return (p << 24) | ((cmw & CM_SM) * (uint32_t)P + p); };
   if (LM) {
-    for (int t = threadIdx.x; t < K; t += blockDim.x) pc_cm[t] = colmap_g[t];
+    for (int t = threadIdx.x; t < K; t += blockDim.x) pc_cm[t] = pack(colmap_g[t]);
     __syncthreads();
   }
-  const uint32_t* const colmap = LM ? pc_cm : colmap_g;
   const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
   for (int64_t a = (int64_t)blockIdx.x * ngrp + grp; a < N_amb; a += (int64_t)gridDim.x * ngrp) {
     const int64_t i = amb_row[a];
@@ -194,16 +201,18 @@ __global__ __launch_bounds__(LM ? 1024 : 256) void k_row_partcounts(int64_t N_am
       for (int q = 0; q < 4; ++q) ix[q] = *reinterpret_cast<const cs_u32x4_a4*>(indices + s + k0 + 4 * q);
       uint32_t cm[E];
 #pragma unroll
-      for (int j = 0; j < E; ++j) cm[j] = colmap[k0 + j < len ? ix[j / 4][j & 3] : 0u];
+      for (int j = 0; j < E; ++j) { const uint32_t c = k0 + j < len ? ix[j / 4][j & 3] : 0u; cm[j] = LM ? pc_cm[c] : pack(colmap_g[c]); }
       uint32_t idv[E];
+      unsigned long long c8 = 0;                           // 8 x 8-bit counters of this step
 #pragma unroll
       for (int j = 0; j < E; ++j) {
-        const uint32_t p = cm[j] >> CM_PS;
-        idv[j] = (cm[j] & CM_SM) * P + p;
-        if (k0 + j < len) {
-          const unsigned long long one = 1ull << (16 * (p & 3));
-          if (p < 4) lo += one; else hi += one;
-        }
+        idv[j] = cm[j] & 0xFFFFFFu;
+        if (k0 + j < len) c8 += 1ull << (8 * (cm[j] >> 24));
+      }
+      {
+        const uint32_t a4 = (uint32_t)c8, b4 = (uint32_t)(c8 >> 32);
+        lo += (unsigned long long)(a4 & 0xFFu) | ((unsigned long long)((a4 >> 8) & 0xFFu) << 16) | ((unsigned long long)((a4 >> 16) & 0xFFu) << 32) | ((unsigned long long)(a4 >> 24) << 48);
+        hi += (unsigned long long)(b4 & 0xFFu) | ((unsigned long long)((b4 >> 8) & 0xFFu) << 16) | ((unsigned long long)((b4 >> 16) & 0xFFu) << 32) | ((unsigned long long)(b4 >> 24) << 48);
       }
       if (rid) {
         if (k0 + E <= len) {                               // a full lane: two 16-byte stores instead of sixteen 2-byte ones
