@@ -290,6 +290,7 @@ int tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols, const int64_t*
   TSEM_ALLOC(d_bad, 4);
   TSEM_HIP(hipMemsetAsync(d_bad, 0, 4 * sizeof(uint32_t), h->stream));
   k_check_csr<<<2048, 256, 0, h->stream>>>(n_rows, n_cols, lut_len, h->d_indptr, h->d_indices, h->d_raw, d_bad);
+  tsem_setup_preload();                                      // (the set-up unit's code object loads while the check runs)
   uint32_t badw[4] = {0, 0, 0, 0};
   TSEM_HIP(hipMemcpyAsync(badw, d_bad, sizeof(badw), hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
@@ -344,6 +345,15 @@ int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_col
   if (n) {
     k_gen_rows<<<cdiv64(n, 128), 128, 0, h->stream>>>(row_begin, n, n_cols, seed, dist, h->d_indptr, h->d_indices, h->d_raw);
     TSEM_HIP(hipGetLastError());
+    tsem_setup_preload();                                    // (the set-up unit's code object loads while the generator runs)
+    // ... and so does the runtime's path for sizeable copies to pageable host memory: a matrix that comes from the host pays that
+    // one-off (7 ms, once per process) inside its upload (tools/time_setup_host.py: the row statistics' read-backs then take 0.09 ms);
+    // the generated matrix has no upload, and the one-off used to land in tsem_rowstats' read-backs instead
+    {
+      std::vector<unsigned char> warm((size_t)1 << 18);
+      (void)hipMemcpyAsync(warm.data(), h->d_indptr, std::min<size_t>(warm.size(), sizeof(int64_t) * (size_t)(n + 1)), hipMemcpyDeviceToHost, h->stream);
+      (void)hipStreamSynchronize(h->stream);
+    }
     TSEM_HIP(hipStreamSynchronize(h->stream));
   }
   (void)hipFree(d_cdf);

@@ -676,6 +676,14 @@ __global__ __launch_bounds__(256) void k_indices_from_rid(int64_t nnz, const uin
 
 extern "C" {
 
+// HIP loads a translation unit's code object at the first launch (or attribute query) of one of its kernels: 5.8 ms for this unit in
+// the first engine of a process, which used to sit at the head of tsem_rowstats.  The matrix loaders call this right after their last
+// kernel goes out (k_check_csr / k_gen_rows), so the load happens while the device is busy with work that has to be done anyway.
+void tsem_setup_preload(void) {
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, (const void*)k_class_flags);
+}
+
 int tsem_ensure_indices(tsem_ctx* h) {
   if (h->d_indices || !h->d_indptr || h->nnz == 0) return TSEM_OK;
   if (!h->d_rid16 || !h->d_col_of_id) TSEM_FAIL(TSEM_ERR_ARG, "the CSR column ids were dropped and there are no popularity ids to rebuild them from");
