@@ -134,6 +134,26 @@ def configure_logging(opts):
     lg.basicConfig(level=level, format=fmt, datefmt='%Y-%m-%d %H:%M:%S', stream=stream, force=True)
 
 
+def warm_device(opts):
+    """Single-process runs: bring the HIP runtime up (library load, device context: ~0.9 s on a fresh MI355X box) in a helper thread
+    WHILE the main thread imports pandas / scipy and reads the input — ctypes releases the GIL for the call.  Returns the thread (join it
+    before the engine is needed) or None for a rank of a distributed launch (torch initialises the device there, in its own order)."""
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('TSEM_NO_WARM', '0') == '1':
+        return None
+    os.environ.setdefault('TSEM_NO_TORCH', '1')              # (a single-process run needs no torch: its import is most of a small run)
+    import threading
+
+    def _up():
+        try:
+            from ._lib import Engine
+            Engine(opts.device).close()
+        except Exception:                                    # noqa: BLE001 — the real constructor reports the problem, loudly
+            pass
+    t = threading.Thread(target=_up, name='tsem-warm', daemon=True)
+    t.start()
+    return t
+
+
 def build_model(raw_scores, opts, row_range=None, comm=None):
     """The likelihood model — on one GPU, or, when the process is one rank of a `torch.distributed.run` launch (WORLD_SIZE > 1:
     `python -m torch.distributed.run --nproc-per-node N -m telescope_amd resume ...`), on this rank's contiguous share of the
@@ -175,10 +195,11 @@ def finish(comm):
 
 def run_resume(args):
     """telescope_resume.py:183-232."""
-    from .likelihood import TelescopeLikelihood
-    from .run_container import Telescope
     opts = ResumeOptions(args)
     configure_logging(opts)
+    warm = None if opts.skip_em else warm_device(opts)       # (before the heavy imports below: they run while the device comes up)
+    from .likelihood import TelescopeLikelihood
+    from .run_container import Telescope
     lg.info('\n{}\n'.format(opts))
     total_time = time()
     lg.info('Loading Telescope object from file...')
@@ -193,6 +214,8 @@ def run_resume(args):
     seed = ts.get_random_seed()
     lg.debug('Random seed: {}'.format(seed))
     np.random.seed(seed)
+    if warm is not None:
+        warm.join()
     ts_model, comm = build_model(ts.raw_scores, opts, ts.row_range)
     lg.info('Running Expectation-Maximization...')
     stime = time()
@@ -211,13 +234,14 @@ def run_assign(args):
     """telescope_assign.py:372-451.  Row-sharded (`torch.distributed.run ... -m telescope_amd assign`): rank 0 alone parses the
     annotation and the alignments and writes the checkpoint; the other ranks wait for it and read THEIR fragments from the file
     (Telescope.load_shard) — one BAM parse and one whole matrix in host memory per job, not per rank."""
-    from .likelihood import TelescopeLikelihood
-    from .loader import Annotation
-    from .run_container import Telescope
     opts = ResumeOptions(args)
     configure_logging(opts)
     if opts.updated_sam or opts.ncpu != 1:
         raise SystemExit('--updated_sam and --ncpu > 1 are not available in this engine')
+    warm = None if opts.skip_em else warm_device(opts)       # (the device comes up while the BAM is parsed)
+    from .likelihood import TelescopeLikelihood
+    from .loader import Annotation
+    from .run_container import Telescope
     lg.info('\n{}\n'.format(opts))
     total_time = time()
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
@@ -250,6 +274,8 @@ def run_assign(args):
     if status or opts.skip_em:
         if not status:
             lg.info('Skipping EM...')
+        if warm is not None:
+            warm.join()
         finish(comm)
         lg.info('telescope assign complete (%s)' % format_minutes(time() - total_time))
         return 0
@@ -259,6 +285,8 @@ def run_assign(args):
     seed = ts.get_random_seed()
     lg.debug('Random seed: {}'.format(seed))
     np.random.seed(seed)
+    if warm is not None:
+        warm.join()
     ts_model, comm = build_model(ts.raw_scores, opts, ts.row_range, comm)
     lg.info('Running Expectation-Maximization...')
     stime = time()
