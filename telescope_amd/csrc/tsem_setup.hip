@@ -454,15 +454,23 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
     }
   }
   __syncthreads();
-  if (threadIdx.x < P) {                                   // exclusive scan down the rows, one thread per part
-    uint32_t run = 0, last = 0;
-    for (int lr = 0; lr < R; ++lr) {
-      const uint32_t c = cnt[lr * P + threadIdx.x];
-      cnt[lr * P + threadIdx.x] = run;
-      if (c) last = (uint32_t)lr;
-      run += c;
+  {                                                        // exclusive scan down the rows: one WAVE per part, 64 rows per step (round 5: one
+    const int wave = threadIdx.x >> 6, ln = threadIdx.x & 63, nw = blockDim.x >> 6;   // thread per part walked the R rows serially)
+    for (int q = wave; q < P; q += nw) {
+      uint32_t run = 0, last = 0;
+      for (int base = 0; base < R; base += 64) {
+        const int lr = base + ln;
+        const uint32_t c = lr < R ? cnt[lr * P + q] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (ln >= d) incl += t; }
+        if (lr < R) cnt[lr * P + q] = run + incl - c;
+        const unsigned long long m = __ballot(c != 0u);
+        if (m) last = (uint32_t)(base + 63 - __clzll((long long)m));
+        run += __shfl(incl, 63, 64);
+      }
+      if (ln == 0) { total[q] = run; lastrow[q] = last; }
     }
-    total[threadIdx.x] = run; lastrow[threadIdx.x] = last;
   }
   __syncthreads();
   // A row's entries keep their CSR order inside each part: the position of an entry = the row's cursor for its part
