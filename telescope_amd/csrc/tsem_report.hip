@@ -709,6 +709,47 @@ __global__ __launch_bounds__(1024) void k_report_init_codes(ReportArgs A) {
   }
 }
 
+// `choose` over the INITIAL z for a LIST of (tied) rows, on the score codes alone (same premises as k_report_init_codes): the best hits of
+// a row are its entries with the largest code, in CSR order; picks[i] is the ordinal of the chosen one (sparse_plus.py:140-154).  One
+// 16-lane group per listed row, two sweeps over its 2-byte codes; the winner's column (col_of_id[rid]) gets +1.  The generic row pass
+// (16 lanes per row over column ids + scores + the score table, fp64) took 3.5 ms for the 5.6M tied rows of the 50M-row matrix.
+// The winners are counted per popularity id in LDS (32-bit counters for the Hs most popular ids, i.e. all of them up to 38k slots) and
+// flushed once per workgroup: 5.6M global fp64 atomics straight onto the columns ran at the hot-column rate (2 G/s: 2.8 ms).
+__global__ __launch_bounds__(1024) void k_choose_init_codes(int64_t n, const int32_t* __restrict__ rowlist, const int32_t* __restrict__ picks,
+    const int64_t* __restrict__ indptr, const uint16_t* __restrict__ raw, const uint16_t* __restrict__ rid,
+    const int32_t* __restrict__ col_of_id, double* __restrict__ colsums, int Hs) {
+  constexpr int G = 16;
+  extern __shared__ uint32_t ch_hot[];                     // [Hs]
+  for (int t = threadIdx.x; t < Hs; t += blockDim.x) ch_hot[t] = 0u;
+  __syncthreads();
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+  const int sh = (threadIdx.x & 63) / G * G;               // the group's first lane inside its wave
+  for (int64_t i = (int64_t)blockIdx.x * ngrp + grp; i < n; i += (int64_t)gridDim.x * ngrp) {
+    const int64_t row = rowlist[i];
+    const int64_t s = indptr[row];
+    const int len = (int)(indptr[row + 1] - s);
+    int m = 0;
+    for (int k = gl; k < len; k += G) m = max(m, (int)raw[s + k]);
+    m = sg_max_i<G>(m);
+    int want = picks ? picks[i] : 0, seen = 0;
+    for (int k0 = 0; k0 < len; k0 += G) {                  // (all 16 lanes stay in the loop: the ballots need them)
+      const bool hit = k0 + gl < len && (int)raw[s + k0 + gl] == m;
+      const uint32_t mask = (uint32_t)(__ballot(hit) >> sh) & 0xFFFFu;
+      const int before = seen + __popc(mask & ((1u << gl) - 1u));
+      if (hit && before == want) {
+        const uint32_t id = rid[s + k0 + gl];
+        if ((int)id < Hs) atomicAdd(&ch_hot[id], 1u); else unsafeAtomicAdd(&colsums[col_of_id[id]], 1.0);
+      }
+      seen += __popc(mask);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < Hs; t += blockDim.x) {
+    const uint32_t c = ch_hot[t];
+    if (c) unsafeAtomicAdd(&colsums[col_of_id[t]], (double)c);
+  }
+}
+
 // the rows k_report_rows left: any length, sweeps of 16 entries, one 16-lane group per row
 template <bool INIT, int GM = 0>
 __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
@@ -1253,8 +1294,6 @@ int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const 
   if (int rc = ensure_device(h)) return rc;
   for (int j = 0; j < h->K; ++j) colsums[j] = 0.0;
   if (n == 0) return TSEM_OK;
-  RowPassArgs A;
-  if (int rc = rowpass_args(h, which, A)) return rc;
   if (rows)
     for (int64_t i = 0; i < n; ++i)
       if (rows[i] < 0 || rows[i] >= h->N) TSEM_FAIL(TSEM_ERR_ARG, "tsem_reassign_rows: row out of range");
@@ -1271,6 +1310,27 @@ int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const 
     TSEM_ALLOC(d_picks, n);
     TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
   }
+  // `choose` over the initial z: the picked best hit is the picks[i]-th entry with the row's largest score code — no score table,
+  // no column ids (the popularity ids do), no floating point — under the premises of k_report_init_codes
+  if (method == TSEM_RA_CHOOSE && which == TSEM_Z_INITIAL && h->lut_increasing && !h->opt_reproducible && h->opt_report_kernel == 1 &&
+      h->d_rid16 && h->d_col_of_id && h->d_ucount) {
+    uint32_t has_zero = 1;
+    TSEM_HIP(hipMemcpyAsync(&has_zero, h->d_ucount + h->K, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (!has_zero) {
+      const int Hs = std::min(h->Kpad, (TS_LDS_MAX - 2048) / 4);
+      const int grid = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, (n + 63) / 64));
+      TSEM_HIP(hipFuncSetAttribute((const void*)k_choose_init_codes, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+      k_choose_init_codes<<<grid, 1024, (size_t)Hs * 4, h->stream>>>(n, rows ? d_rows : h->d_tie_rows, d_picks, h->d_indptr, h->d_raw, h->d_rid16,
+                                                                     h->d_col_of_id, d_cs, Hs);
+      TSEM_HIP(hipGetLastError());
+      TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+      TSEM_HIP(hipStreamSynchronize(h->stream));
+      return TSEM_OK;
+    }
+  }
+  RowPassArgs A;
+  if (int rc = rowpass_args(h, which, A)) return rc;
   A.method = method; A.thresh = thresh; A.colsums = d_cs; A.picks = d_picks;
   A.rowlist = rows ? d_rows : h->d_tie_rows; A.nlist = n;
   const int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + 15) / 16));

@@ -296,6 +296,15 @@ def test_initial_report_pass_from_the_score_codes(gpu_device, rows, cols, d, dis
     assert next(iter(tl._report_cache))[1] < 0                  # one pass, asked without a conf column
     conf = tl.reassign_colsums('conf', 0.9, initial=True)
     assert np.allclose(conf, full['conf'], rtol=1e-12, atol=1e-9) and np.array_equal(a[0], full['exclude'].astype(np.int64))
+    # `choose`: the picked best hits of the tied rows come from the codes-only kernel (k_choose_init_codes); the generic row pass
+    # (report_kernel = 0) must give the same column sums for the same picks — with the device's tie list and with a caller's rows
+    picks = np.random.RandomState(9).randint(0, c1).astype(np.int32)
+    fast_rows = eng.reassign_rows('choose', 0.9, Z_INITIAL, r1, picks)
+    fast_list = eng.reassign_rows('choose', 0.9, Z_INITIAL, None, picks, n=len(r1))
+    eng.set_option('report_kernel', 0)
+    slow_rows = eng.reassign_rows('choose', 0.9, Z_INITIAL, r1, picks)
+    eng.set_option('report_kernel', 1)
+    assert np.array_equal(fast_rows, slow_rows) and np.array_equal(fast_list, slow_rows) and int(slow_rows.sum()) == len(r1)
 
 
 def test_initial_report_pass_with_a_stored_zero_score_takes_the_full_kernel(gpu_device):
