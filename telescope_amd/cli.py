@@ -249,28 +249,38 @@ def run_assign(args):
     if world > 1:
         from .distributed import init_from_env
         comm = init_from_env()
-    ts, status = None, 0                                     # status 1: nothing overlaps the annotation (every rank must learn it)
+    ts, status, failure = None, 0, None                      # status 1: nothing overlaps the annotation; 2: rank 0 failed (every rank must learn it)
     if rank == 0:
-        ts = Telescope(opts)
-        ts.run_info['version'] = opts.version
-        lg.info('Loading annotation...')
-        stime = time()
-        annot = Annotation(opts.gtffile, opts.attribute, opts.stranded_mode)
-        lg.info('Loaded annotation in {}'.format(format_minutes(time() - stime)))
-        lg.info('Loaded {} features.'.format(len(annot.loci)))
-        lg.info('Loading alignments...')
-        stime = time()
-        ts.load_alignment(annot)
-        lg.info('Loaded alignment in {}'.format(format_minutes(time() - stime)))
-        ts.print_summary(lg.INFO)
-        if ts.run_info['overlap_unique'] + ts.run_info['overlap_ambig'] == 0:
-            lg.info('No alignments overlapping annotation')
-            status = 1
-        else:
-            os.makedirs(opts.outdir, exist_ok=True)
-            ts.save(opts.outfile_path('checkpoint'))
+        try:
+            ts = Telescope(opts)
+            ts.run_info['version'] = opts.version
+            lg.info('Loading annotation...')
+            stime = time()
+            annot = Annotation(opts.gtffile, opts.attribute, opts.stranded_mode)
+            lg.info('Loaded annotation in {}'.format(format_minutes(time() - stime)))
+            lg.info('Loaded {} features.'.format(len(annot.loci)))
+            lg.info('Loading alignments...')
+            stime = time()
+            ts.load_alignment(annot)
+            lg.info('Loaded alignment in {}'.format(format_minutes(time() - stime)))
+            ts.print_summary(lg.INFO)
+            if ts.run_info['overlap_unique'] + ts.run_info['overlap_ambig'] == 0:
+                lg.info('No alignments overlapping annotation')
+                status = 1
+            else:
+                os.makedirs(opts.outdir, exist_ok=True)
+                ts.save(opts.outfile_path('checkpoint'))
+        except BaseException as e:                           # noqa: BLE001 — re-raised below, once the other ranks know
+            if comm is None:
+                raise
+            failure, status = e, 2
     if comm is not None:
         status = comm.max_scalar(status)                     # (also the barrier behind which the checkpoint exists)
+    if status == 2:                                          # the ranks that wait for the checkpoint must not wait for ever
+        finish(comm)
+        if failure is not None:
+            raise failure
+        raise SystemExit('telescope assign: rank 0 failed while loading the annotation / alignments (see its message)')
     if status or opts.skip_em:
         if not status:
             lg.info('Skipping EM...')

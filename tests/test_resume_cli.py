@@ -236,3 +236,20 @@ def test_assign_skip_em_over_two_rank_processes(tmp_path):
     for k in a.files:
         if k != '_run_info':
             assert np.array_equal(a[k], b[k]), k
+
+
+def test_assign_two_ranks_rank0_failure_reaches_the_other_rank(tmp_path):
+    """Rank 0 alone parses the input; if that fails (here: no such BAM) rank 1 must not wait for the checkpoint for ever: the status
+    all-reduce carries the failure, both ranks leave with an error, promptly."""
+    import socket
+    import time
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, TSEM_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), '--max-restarts', '0', '-m', 'telescope_amd', 'assign', os.path.join(str(tmp_path), 'missing.bam'),
+           os.path.join(GOLD, 'bundled_annotation.gtf'), '--outdir', str(tmp_path), '--exp_tag', 'run', '--skip_em']
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert time.time() - t0 < 300, 'the ranks waited for each other'
+    assert 'rank 0 failed while loading' in r.stderr or 'missing.bam' in r.stderr, r.stderr[-2000:]
