@@ -986,6 +986,26 @@ int tsem_export_rowinfo(tsem_ctx* h, uint8_t* Y, double* weights) {
   return TSEM_OK;
 }
 
+// stable LSD radix sort of (key, idx) pairs by 64-bit key (11-bit digits; passes whose digit is constant are skipped): the two K-sized
+// host sorts of a set-up (columns by popularity, column signatures for the twin search) took 1.3 ms each with std::stable_sort /
+// std::sort at K = 30k — a fixed cost that is a quarter of the set-up of a 2M-row matrix
+static void radix_sort_pairs(std::vector<uint64_t>& key, std::vector<int>& idx) {
+  const size_t n = key.size();
+  std::vector<uint64_t> k2(n);
+  std::vector<int> i2(n);
+  uint32_t hist[2048];
+  for (int pass = 0; pass < 6; ++pass) {
+    const int sh = 11 * pass;
+    for (uint32_t& x : hist) x = 0u;
+    for (size_t i = 0; i < n; ++i) hist[(key[i] >> sh) & 0x7FFu] += 1u;
+    if (n && hist[(key[0] >> sh) & 0x7FFu] == n) continue;
+    uint32_t run = 0;
+    for (uint32_t& x : hist) { const uint32_t c = x; x = run; run += c; }
+    for (size_t i = 0; i < n; ++i) { const uint32_t q = hist[(key[i] >> sh) & 0x7FFu]++; k2[q] = key[i]; i2[q] = idx[i]; }
+    key.swap(k2); idx.swap(i2);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // layout: column partition by popularity, blocked COO of ambiguous rows
 // ---------------------------------------------------------------------------
@@ -1019,7 +1039,11 @@ int tsem_build_layout(tsem_ctx* h) {
   const int P = h->P, Kp = h->Kp;
   std::vector<int> order(K);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return counts[a] > counts[b]; });
+  {                                                        // most popular first, equal counts by column index (a stable sort by count, descending)
+    std::vector<uint64_t> key((size_t)K);
+    for (int j = 0; j < K; ++j) key[j] = ~counts[j];
+    radix_sort_pairs(key, order);
+  }
   // colmap[j] = part << CM_PS | log2(copies) << CM_LS | first slot (tsem_device.h).  A column that holds a large share of its
   // part's entries would serialise the LDS scatter (64 f lanes of every ds_add_f64 on ONE address:
   // the hottest column of a Zipf-like matrix, or Telescope's `__no_feature`, reaches 8-way), so it
@@ -1361,16 +1385,21 @@ int tsem_set_model(tsem_ctx* h, const double* stats3, const double* pisum0, cons
   const int K = h->K;
   h->col_count.assign(col_count, col_count + K);
   {  // exact twin columns -> representative = smallest column index of the class
-    struct Sig { uint64_t count, hash; int col; };            // (sorted in place)
-    std::vector<Sig> sg((size_t)K);
-    for (int j = 0; j < K; ++j) sg[j] = Sig{col_count[j], col_hash[j], j};
-    std::sort(sg.begin(), sg.end(), [](const Sig& a, const Sig& b) {
-      if (a.count != b.count) return a.count < b.count;
-      if (a.hash != b.hash) return a.hash < b.hash;
-      return a.col < b.col;
-    });
+    // order by (count, hash, column): a stable radix sort of the column indices by count, then the (short) runs of equal counts by
+    // (hash, column)
     std::vector<int> ord(K);
-    for (int j = 0; j < K; ++j) ord[j] = sg[j].col;
+    std::iota(ord.begin(), ord.end(), 0);
+    {
+      std::vector<uint64_t> key(col_count, col_count + K);
+      radix_sort_pairs(key, ord);
+      for (int i = 0; i < K;) {
+        int j = i;
+        while (j + 1 < K && key[j + 1] == key[i]) ++j;
+        if (j > i)
+          std::sort(ord.begin() + i, ord.begin() + j + 1, [&](int a, int b) { return col_hash[a] != col_hash[b] ? col_hash[a] < col_hash[b] : a < b; });
+        i = j + 1;
+      }
+    }
     std::vector<int32_t> rep(K);
     h->n_twin_cols = 0;
     for (int i = 0; i < K;) {
