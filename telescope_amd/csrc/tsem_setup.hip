@@ -571,19 +571,77 @@ constexpr int DC_NT = 256;
 // wave against 1536 for reading the window, which was most of its 14 ms at 2e9 entries.
 // Round 5: IN PLACE (a thread reads its whole window into registers before it writes it back, and windows are disjoint): no second
 // copy of the layout — 6 B per entry less at the peak of a build, two GB-sized hipMalloc / hipFree pairs less.
+// ... and (later in round 5) with COOPERATIVE loads and stores: a thread used to read and write its own window with 16-byte accesses 256 B
+// (128 B) apart from its neighbour's — 64 cache lines per wave instruction, and the texture-address unit takes a line per clock: ~30 of
+// the 52 us a window took per thread went there (TCP_TOTAL_CACHE_ACCESSES / TCP_TCC_WRITE_REQ 1.0e9, profiles/r05_setup_pmc.txt).  Now
+// a WAVE owns 64 consecutive windows; it loads them with contiguous 16-byte pieces (8 lines per instruction), passes them through an LDS
+// tile (windows x 32 words, row stride 36 words: both the piece-wise and the row-wise b128 accesses are conflict-free per 16 lanes) so
+// that lane l ends up with window l in registers, and stores them back the same way.  The walk itself is unchanged: same layout bit for bit.
+constexpr int DC_S = 36;                                   // LDS row stride in words (32 + 4)
 __global__ __launch_bounds__(DC_NT) void k_sb_deconflict(int64_t n_win, const uint32_t* prc_in, const uint16_t* code_in,
                                                           uint32_t* prc_out, uint16_t* code_out) {
-  for (int64_t w = (int64_t)blockIdx.x * DC_NT + threadIdx.x; w < n_win; w += (int64_t)gridDim.x * DC_NT) {
-    const int64_t base = w * 64;
-    const uint4* pin = reinterpret_cast<const uint4*>(prc_in + base);
-    const uint2* cin = reinterpret_cast<const uint2*>(code_in + base);
-    uint32_t P[64], Cd[64];
+  __shared__ __attribute__((aligned(16))) uint32_t dc_tile[DC_NT / 64][64 * DC_S];
+  uint32_t* const tile = dc_tile[threadIdx.x >> 6];
+  const int ln = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * DC_NT + threadIdx.x) >> 6, nwave = ((int64_t)gridDim.x * DC_NT) >> 6;
+  // a chunk = 32 words of each of the wave's 64 windows: 128 B per window, `wstride` words from one window's chunk to the next;
+  // piece t = q * 64 + lane of a chunk is the 16 bytes at word 4 * (t % 8) of window t / 8
+  // (addresses: a wave-uniform base + one 32-bit lane offset + a constant per piece — 64-bit addresses per piece, hoisted out of the
+  //  window loop, were 96 registers)
+  const uint32_t lo64 = (uint32_t)(ln >> 3) * 64u + 4u * (uint32_t)(ln & 7), lo32 = (uint32_t)(ln >> 3) * 32u + 4u * (uint32_t)(ln & 7);
+  auto chunk_in = [&](const uint32_t* src, uint32_t wstride, int64_t wb, uint32_t (&out)[32]) {
+    const uint32_t* const bp = src + wb * (int64_t)wstride;  // wave-uniform
+    const uint32_t lo = wstride == 64u ? lo64 : lo32;
+    const int64_t left = n_win - wb;                          // windows of this wave that exist (>= 1)
+    uint4 v[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const uint4 a = pin[q];
-      const uint2 cd = cin[q];
-      P[4 * q] = a.x; P[4 * q + 1] = a.y; P[4 * q + 2] = a.z; P[4 * q + 3] = a.w;
-      Cd[4 * q] = cd.x & 0xFFFFu; Cd[4 * q + 1] = cd.x >> 16; Cd[4 * q + 2] = cd.y & 0xFFFFu; Cd[4 * q + 3] = cd.y >> 16;
+    for (int q = 0; q < 8; ++q)
+      v[q] = q * 8 + (ln >> 3) < left ? *reinterpret_cast<const uint4*>(bp + (lo + (uint32_t)q * 8u * wstride)) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t = q * 64 + ln;
+      *reinterpret_cast<uint4*>(tile + (t >> 3) * DC_S + 4 * (t & 7)) = v[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint4 r = *reinterpret_cast<const uint4*>(tile + ln * DC_S + 4 * j);
+      out[4 * j] = r.x; out[4 * j + 1] = r.y; out[4 * j + 2] = r.z; out[4 * j + 3] = r.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto chunk_out = [&](uint32_t* dst, uint32_t wstride, int64_t wb, const uint32_t (&in)[32]) {
+    uint32_t* const bp = dst + wb * (int64_t)wstride;
+    const uint32_t lo = wstride == 64u ? lo64 : lo32;
+    const int64_t left = n_win - wb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      *reinterpret_cast<uint4*>(tile + ln * DC_S + 4 * j) = make_uint4(in[4 * j], in[4 * j + 1], in[4 * j + 2], in[4 * j + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t = q * 64 + ln;
+      const uint4 r = *reinterpret_cast<const uint4*>(tile + (t >> 3) * DC_S + 4 * (t & 7));
+      if (q * 8 + (ln >> 3) < left) *reinterpret_cast<uint4*>(bp + (lo + (uint32_t)q * 8u * wstride)) = r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int64_t wb = wave * 64; wb < n_win; wb += nwave * 64) {
+    uint32_t P[64], Cd[64];
+    {
+      uint32_t h0[32], h1[32], cw[32];
+      chunk_in(prc_in, 64, wb, h0);                        // (one chunk after the other: all 24 loads in flight at once would cost 96 registers)
+      __builtin_amdgcn_sched_barrier(0);
+      chunk_in(prc_in + 32, 64, wb, h1);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk_in(reinterpret_cast<const uint32_t*>(code_in), 32, wb, cw);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) { P[i] = h0[i]; P[32 + i] = h1[i]; Cd[2 * i] = cw[i] & 0xFFFFu; Cd[2 * i + 1] = cw[i] >> 16; }
     }
     unsigned long long cont = 0ull;                        // bit i: entry i continues the row of entry i-1 (and neither is padding)
 #pragma unroll
@@ -622,12 +680,15 @@ __global__ __launch_bounds__(DC_NT) void k_sb_deconflict(int64_t n_win, const ui
       }
       h[j] += (unsigned long long)(lb < 15u ? 1u : 0u) << (cb * 4u);
     }
-    uint4* pout = reinterpret_cast<uint4*>(prc_out + base);
-    uint2* cout = reinterpret_cast<uint2*>(code_out + base);
+    {
+      uint32_t h0[32], h1[32], cw[32];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      pout[q] = make_uint4(P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]);
-      cout[q] = make_uint2(Cd[4 * q] | (Cd[4 * q + 1] << 16), Cd[4 * q + 2] | (Cd[4 * q + 3] << 16));
+      for (int i = 0; i < 32; ++i) { h0[i] = P[i]; h1[i] = P[32 + i]; cw[i] = Cd[2 * i] | (Cd[2 * i + 1] << 16); }
+      chunk_out(prc_out, 64, wb, h0);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk_out(prc_out + 32, 64, wb, h1);
+      __builtin_amdgcn_sched_barrier(0);
+      chunk_out(reinterpret_cast<uint32_t*>(code_out), 32, wb, cw);
     }
   }
 }
