@@ -477,21 +477,37 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
   // (read-only after the scan) + the number of earlier entries of the row in that part, counted with wave ballots over
   // the 16 lanes that walk the row — no LDS atomic per entry (2e9 of them with a return value were half of this
   // kernel's time), and the layout is the same from run to run.
-  const int sgbase = (threadIdx.x & 63) / RS_SUB * RS_SUB;
-  const uint32_t below = (1u << lane) - 1u;
-  // one step of 16 entries: column-map word cm of this lane's entry (0xFFFF.... part for lanes past the row's end), its score
-  auto place = [&](int lr, uint32_t (&run)[8], bool valid, uint32_t cm, uint32_t code) {
-    const uint32_t p = valid ? cm >> CM_PS : 0xFFFFu;
-    uint32_t t = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (q < P) {
-        const uint32_t m = (uint32_t)(__ballot(p == (uint32_t)q) >> sgbase) & 0xFFFFu;
-        if (p == (uint32_t)q) t = run[q] + __popc(m & below);
-        run[q] += __popc(m);
-      }
+  // (later in round 5) ... counted with a prefix sum over the row's 16 lanes instead of one ballot per part: every lane contributes a
+  // one in the 8-bit field of its part (parts 0-3 in one word, 4-7 in a second), four DPP row shifts give the inclusive scan, lane 15's
+  // value is the step's total per part; the row's running counts sit in 16-bit fields of two 64-bit words (a row has fewer than
+  // 65 536 entries).  ~20 VALU instructions per step where the P ballots took ~10 each (the kernel's static code shrank by a
+  // quarter); measured 8.1 -> 7.9 ms at 2e9 entries: the 3.4e9 VALU wave-instructions of profiles/r05_setup_pmc.txt were not
+  // what it waits for either — its 2- and 4-byte scattered stores (7.5e8 L2 write requests) are.  Same positions as before.
+  auto scan16 = [](uint32_t x) -> uint32_t {               // inclusive scan over a DPP row (= the 16 lanes of a row group)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+    return x;
+  };
+  auto widen = [](uint32_t x) -> unsigned long long {      // 4 x 8-bit fields -> 4 x 16-bit fields
+    const uint32_t lo = (x & 0xFFu) | ((x & 0xFF00u) << 8), hi = ((x >> 16) & 0xFFu) | ((x >> 8) & 0xFF0000u);
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  // one step of 16 entries: column-map word cm of this lane's entry (anything for lanes past the row's end), its score
+  auto place = [&](int lr, unsigned long long (&run)[2], bool valid, uint32_t cm, uint32_t code) {
+    const uint32_t p = cm >> CM_PS, sh8 = (p & 3u) * 8u;
+    const bool upper = p >= 4u;
+    const uint32_t w0 = scan16(valid && !upper ? 1u << sh8 : 0u);
+    uint32_t inc = w0, t = (uint32_t)(run[0] >> ((p & 3u) * 16u)) & 0xFFFFu;
+    run[0] += widen((uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x15F, 0xF, 0xF, false));   // (row_newbcast:15: the row's total)
+    if (P > 4) {
+      const uint32_t w1 = scan16(valid && upper ? 1u << sh8 : 0u);
+      if (upper) { inc = w1; t = (uint32_t)(run[1] >> ((p & 3u) * 16u)) & 0xFFFFu; }
+      run[1] += widen((uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x15F, 0xF, 0xF, false));
     }
     if (valid) {
+      t += ((inc >> sh8) & 0xFFu) - 1u;                    // earlier entries of this step in the same part (inclusive count - itself)
       t += cnt[lr * P + p];
       const int64_t pos = sbase[p] + t;
       if (pcode) pcode[pos] = (uint16_t)code;
@@ -520,7 +536,7 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
       load_row(lr + subs);                                 // (past the block's last row: the last row again, unused)
       const int len = rlen[lr];
       const int64_t s0 = rstart[lr];
-      uint32_t run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned long long run[2] = {0ull, 0ull};
 #pragma unroll
       for (int j = 0; j < PF; ++j)
         if (16 * j < len) place(lr, run, 16 * j + lane < len, cm_of_id(cid[j]), crw[j]);   // (uniform over the 16 lanes)
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(256) void k_sb_fill_sorted(int64_t N_amb, int R, in
     for (int lr = sub; lr < R; lr += subs) {
       const int len = rlen[lr];
       const int64_t s0 = rstart[lr];
-      uint32_t run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned long long run[2] = {0ull, 0ull};
       for (int k0 = 0; k0 < len; k0 += RS_SUB) {           // (all 16 lanes stay in the loop: the ballots need them)
         const bool valid = k0 + lane < len;
         place(lr, run, valid, valid ? colmap[indices[s0 + k0 + lane]] : 0u, valid ? (uint32_t)raw[s0 + k0 + lane] : 0u);
