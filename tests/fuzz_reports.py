@@ -1,0 +1,102 @@
+"""Random small matrices through em() and EVERY reassign column sum (6 methods x initial / final z, in random order, so that the
+report cache, the codes-only pass of the initial z, the tie list on the device and `choose`'s picks meet in every combination)
+against the oracle: integer columns bit for bit, conf / average to 1e-9.  A soak (the oracle is the checker, hence its place under tests/); tests/test_gpu_round5.py runs a slice of it:
+
+    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+import numpy as np
+import scipy.sparse as sp
+from oracle.telescope_oracle import OracleModel
+from telescope_amd import _lib
+from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+
+
+class Opts(object):
+    def __init__(self, **kw):
+        self.em_epsilon, self.max_iter, self.pi_prior, self.theta_prior = 1e-7, 100, 0, 200000
+        self.__dict__.update(kw)
+
+
+def one(seed):
+    rng = np.random.RandomState(77000 + seed)
+    k = int(rng.choice([3, 17, 200, 5000, 9000, 24000, 33000]))
+    n = int(rng.choice([1, 7, 300, 2500, 12000, 30000]))
+    max_len = int(min(k, rng.choice([2, 5, 30, 120])))
+    uniq = float(rng.choice([0.0, 0.1, 0.6]))
+    lens = np.where(rng.rand(n) < uniq, 1, rng.randint(1, max_len + 1, n))
+    if rng.rand() < 0.2:
+        lens[rng.randint(0, n, max(1, n // 50))] = 0                          # empty rows
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    indices = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    lo, hi = [(139, 212), (1, 5), (1, 2), (100, 1500), (60000, 65535), (0, 6)][int(rng.randint(6))]   # (few distinct scores: many ties; (0, 6): stored zeros)
+    data = rng.randint(lo, hi + 1, indptr[-1]).astype(np.uint16)
+    if indptr[-1] == 0 or data.max() == 0:
+        return 'skipped (empty)'
+    raw = sp.csr_matrix((data, indices, indptr), shape=(n, k))
+    options = [('value_format', int(rng.randint(0, 3)) if hi <= 1500 else int(rng.randint(0, 2)))]   # (2 = codes forced: needs a table of at most 2048 entries)
+    if rng.rand() < 0.3:
+        options.append(('block_rows', int(rng.choice([64, 128, 256]))))
+    if rng.rand() < 0.3:
+        options.append(('drop_csr_indices', 1))
+    if rng.rand() < 0.15:
+        options.append(('em_kernel', 1))
+    o = Opts(max_iter=int(rng.randint(1, 5)), em_epsilon=0.0)
+    o.pi_prior, o.theta_prior = [(0, 200000), (0, 0), (5, 1000)][int(rng.randint(3))]
+    eng = _lib.Engine(0)
+    for key, v in options:
+        eng.set_option(key, v)
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), k, score_lut(int(raw.data.max())))
+    try:
+        tl = TelescopeLikelihood.from_engine(eng, o)
+    except _lib.EngineError as e:
+        if 'value_format=codes needs' in str(e):              # (codes forced where the layout cannot have them: a designed, loud refusal)
+            return 'skipped (%s)' % e
+        raise
+    tl._raw = raw
+    tl.em()
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    om.em(0.0, o.max_iter)
+    ctx = (seed, n, k, max_len, uniq, (lo, hi), options)
+    if not np.isfinite(om.lnl):
+        # no ambiguous row and theta_prior = 0: the reference divides 0 by 0 and spreads the NaN over the unique rows through 0 * NaN
+        # (model.py:706-714 multiplies Q * Y by pi * theta); the engine keeps unique rows out of theta and stays finite there
+        return 'skipped (the reference yields NaN: %s)' % (ctx,)
+    assert abs(tl.lnl - om.lnl) <= 1e-9 * max(abs(om.lnl), 1e-300), ('lnl', tl.lnl, om.lnl, ctx)
+    assert np.allclose(tl.pi, om.pi, rtol=1e-9, atol=1e-300) and np.allclose(tl.theta, om.theta, rtol=1e-9, atol=1e-300), ('pi / theta', ctx)
+    # The masks of the FINAL z hang on exact ties between products of rounded sums: the engine's column sums (atomics) and the
+    # reference's (row order) differ in the last bit of ~5 % of the columns, which flips near-ties on matrices made of two scores
+    # (seeds 10, 85, 145 of the first run).  What is checked here is the report pass: the oracle's z is therefore formed from the
+    # ENGINE's parameters of the last E-step, bit for bit the same inputs on both sides.
+    p_prev, t_prev = eng.get_params(_lib.Z_PREV)
+    om.z = om.estep(p_prev, t_prev)
+    asks = [(m, ini) for m in ('exclude', 'choose', 'average', 'conf', 'unique', 'all') for ini in (False, True)]
+    for i in rng.permutation(len(asks)):
+        m, ini = asks[i]
+        thresh = float(rng.choice([0.9, 0.6, 0.99]))
+        np.random.seed(1234 + seed)
+        got = tl.reassign_colsums(m, thresh, initial=ini)
+        np.random.seed(1234 + seed)
+        want = np.asarray(om.reassign(m, thresh, initial=ini, rng=np.random).sum(0)).ravel()
+        if m in ('conf', 'average'):
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-9), (m, ini, thresh, np.abs(got - want).max(), ctx)
+        else:
+            assert np.array_equal(np.asarray(got, np.int64), np.rint(want).astype(np.int64)), (m, ini, thresh, int(np.abs(got - want).sum()), ctx)
+    eng.close()
+    return 'ok %s' % (ctx,)
+
+
+if __name__ == '__main__':
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    bad = 0
+    for s in range(first, first + count):
+        try:
+            r = one(s)
+        except AssertionError as e:
+            bad += 1
+            r = 'FAILED %s' % (e,)
+        print(s, r, flush=True)
+    print('failures: %d of %d' % (bad, count))
+    sys.exit(1 if bad else 0)

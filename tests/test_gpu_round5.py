@@ -327,3 +327,16 @@ def test_initial_report_pass_with_a_stored_zero_score_takes_the_full_kernel(gpu_
     gen, r3, c3 = eng.report_colsums(Z_INITIAL, 0.9)
     assert np.array_equal(fast['exclude'], gen['exclude']) and np.array_equal(r2, r3) and np.array_equal(c2, c3)
     assert np.allclose(fast['average'], gen['average'], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [3, 10, 41, 85, 145, 146, 212, 301])
+def test_reassign_column_sums_of_random_matrices_against_the_oracle(gpu_device, seed):
+    """A slice of tests/fuzz_reports.py (the soak ran 400 seeds: profiles/r05_fuzz_reports.txt): a random small matrix through em()
+    and all twelve reassign column sums — six methods x initial / final z, in random order with random thresholds, so that the report
+    cache, the codes-only pass of the initial z, the device's tie list and `choose`'s picks meet in every combination — against the
+    oracle, integer columns bit for bit.  Seeds 10, 85 and 145 are the two-score matrices whose final masks sit on near-ties:
+    the oracle's final z is formed from the engine's parameters, which is what makes them comparable."""
+    import fuzz_reports as fuzz
+    res = fuzz.one(seed)
+    assert res.startswith('ok') or res.startswith('skipped'), res
