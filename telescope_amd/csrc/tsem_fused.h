@@ -947,8 +947,13 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
       constexpr uint32_t xm_l = 0xFFFFu, xm_c = 0xFFFFu;
 #endif
       if (FMT == 1) {                                     // Q from the score table: the same fp64 the fp64 layout stores
+#ifdef FZ_X_NOLUT   // upper bound (WRONG RESULTS): the step without its four score-table gathers (a conversion on the VALU instead)
+        q0 = make_double2((double)(rp.cd.x & 0xFFFFu), (double)(rp.cd.x >> 16));
+        q1 = make_double2((double)(rp.cd.y & 0xFFFFu), (double)(rp.cd.y >> 16));
+#else
         q0 = make_double2(lutS[rp.cd.x & xm_l], lutS[(rp.cd.x >> 16) & xm_l]);
         q1 = make_double2(lutS[rp.cd.y & xm_l], lutS[(rp.cd.y >> 16) & xm_l]);
+#endif
       }
       double c0 = 1.0, c1 = 1.0, c2 = 1.0, c3 = 1.0;           // (MODE 7 scatters Q * s: the column's pi*theta is applied by k_colreduce)
       if (!SPB) { c0 = c[rp.rc.x & xm_c]; c1 = c[rp.rc.y & xm_c]; c2 = c[rp.rc.z & xm_c]; c3 = c[rp.rc.w & xm_c]; }
