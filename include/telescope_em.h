@@ -355,7 +355,7 @@ int  tsem_phase_times(tsem_ctx* h, int reset, double* ms6, int64_t* n_iter);
  * ids | blocked layout | per-row arrays }.  What a capacity plan needs: 14 B per stored entry by default (score codes), 10 after
  * the drop, + ~20 B per row. */
 int  tsem_device_memory(tsem_ctx* h, int device, int64_t* free_bytes, int64_t* total_bytes, int64_t* resident5);
-int  tsem_layout_info(tsem_ctx* h, int64_t* info32 /* 29 values written */);
+int  tsem_layout_info(tsem_ctx* h, int64_t* info32 /* 31 values written; [29] / [30] synchronise the stream to read the lnl pass's last choice of form */);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
 /* the same option's start-up timeline: per workgroup b (up to 512), out[8 b ..] = 100 MHz wall clock at entry / tickets counted /

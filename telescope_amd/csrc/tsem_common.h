@@ -151,6 +151,9 @@ struct tsem_ctx {
   int lq_lin = 0, lq_c0 = 0;        // code entries with the reference's own score table: log Q = (code * lq_a) * lq_b from lq_c0 on (no table at all)
   double lq_a = 0, lq_b = 0;
   bool lq_tried = false;            // the tables were attempted for this layout (lq_n == 0 afterwards: they do not fit / do not apply)
+  double lq_lo = 0, lq_hi = 0;      // log Q of the smallest / largest stored score (> 0): which columns may reach the exact branch of the log form
+  unsigned long long* d_lq_mid = nullptr;   // [1] stored entries of such columns, counted by k_log_tab before every lnl pass (the device picks the form)
+  int64_t lq_choice[2] = {0, 0};    // lnl passes enqueued with the selection armed | (diagnostic) reserved
   bool lag_agreed = false;          // row-sharded runs: EVERY rank can run MODE 4 (decided once per run, dropped for good after a time-out anywhere)
   bool lag_valid = false;           // the iteration committed last still owes its lnl, and d_rinv / d_ctab_prev are what the next MODE 4 pass needs for it
   bool exact_single = false;        // reproducible: both pieces in ONE pass (three tables per part fit the LDS with <= 8 parts)

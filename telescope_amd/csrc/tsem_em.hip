@@ -518,9 +518,46 @@ static void phase_harvest(tsem_ctx* h, int n) {
 }
 
 // ---- log tables of the log-likelihood passes (tsem_fused.h, fz_log1p_of_log) ----
-__global__ void k_log_tab(int n, const double* __restrict__ c, double* __restrict__ lc) {
+// ... and, on the way, how many stored entries sit in columns whose log(pi*theta) may take an entry into the exact branch of the log
+// form (FZ_L_ZERO <= log Q + log c < FZ_L_FAST for SOME stored score: lq_lo / lq_hi bound log Q): in that branch a wave fetches pi*theta
+// from global memory and waits for it behind its whole prefetch queue.  Columns on their way to pi = 0 pass through that range: at
+// K = 50k, ~100 per row, a third of the columns is there after 20 iterations and the pass takes 5.0 ms where the per-entry logarithm
+// takes 3.2 (profiles/r05_lnl_evolution.txt).  The two forms of the pass read the count and one of them returns at once.
+__global__ void k_log_tab(int n, const double* __restrict__ c, double* __restrict__ lc, const int32_t* __restrict__ col_of_pc,
+                          const unsigned long long* __restrict__ colcount, double lq_lo, double lq_hi, unsigned long long* __restrict__ mid) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) lc[t] = log(c[t]);                            // log 0 = -inf: the kernel's "zero" range
+  unsigned long long m = 0;
+  if (t < n) {
+    const double l = log(c[t]);                            // log 0 = -inf: the kernel's "zero" range
+    lc[t] = l;
+    if (mid && colcount) {
+      // the share of the column's entries whose log Q puts them between the two limits, for scores spread evenly over [lq_lo, lq_hi]
+      // (real scores crowd near the top: an over-estimate, i.e. the per-entry logarithm takes over a little early)
+      const int j = col_of_pc[t];                          // (-1: padding, the further slots of a split column)
+      if (j >= 0 && l + lq_hi >= FZ_L_ZERO && l + lq_lo < FZ_L_FAST) {
+        const double w = lq_hi - lq_lo;
+        const double below_fast = w > 0.0 ? fmin(1.0, fmax(0.0, (FZ_L_FAST - l - lq_lo) / w)) : 1.0;
+        const double below_zero = w > 0.0 ? fmin(1.0, fmax(0.0, (FZ_L_ZERO - l - lq_lo) / w)) : 0.0;
+        m = (unsigned long long)((double)colcount[j] * (below_fast - below_zero) + 0.5);
+      }
+    }
+  }
+  if (mid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(mid, m);
+  }
+}
+// smallest stored score > 0 (the lower end of log Q for k_log_tab's test)
+__global__ void k_min_u16_nz(const uint16_t* __restrict__ raw, int64_t n, uint32_t* __restrict__ out) {
+  uint32_t m = 0xFFFFu;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t r = raw[i];
+    m = r != 0u && r < m ? r : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMin(out, m);
 }
 // log Q, built once per layout and score table.  Code entries: one value per code.  fp64 entries: a direct-index table on the top bits
 // of Q — the fewest mantissa bits that keep the codes 1 .. max apart — provided it fits the LDS the layout leaves.  lq_n stays 0 when
@@ -592,6 +629,27 @@ static int ensure_log_tables(tsem_ctx* h) {
   if (!f9) return TSEM_OK;
   TSEM_HIP(hipFuncSetAttribute((const void*)f9, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
   TSEM_ALLOC(h->d_lctab, h->Kpad);
+  // the range of log Q over the stored scores, for the choice between the two forms of the pass (k_log_tab)
+  h->lq_lo = 0.0; h->lq_hi = 0.0;
+  if (h->d_colcount && h->d_col_of_pc && h->nnz > 0 && h->max_code > 0 && h->max_code < h->lut_len) {
+    TSEM_ALLOC(h->d_lq_mid, 1);
+    uint32_t mn = 0xFFFFu;
+    uint32_t* const d_mn = reinterpret_cast<uint32_t*>(h->d_lq_mid);
+    TSEM_HIP(hipMemcpyAsync(d_mn, &mn, 4, hipMemcpyHostToDevice, h->stream));
+    k_min_u16_nz<<<1024, 256, 0, h->stream>>>(h->d_raw, h->nnz, d_mn);
+    TSEM_HIP(hipMemcpyAsync(&mn, d_mn, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (mn >= 1u && (int)mn <= h->max_code && h->lut_host[mn] > 0.0 && std::isfinite(h->lut_host[h->max_code])) {
+      h->lq_lo = std::log(h->lut_host[mn]); h->lq_hi = std::log(h->lut_host[h->max_code]);
+      // the arithmetic log Q sends every code below lq_c0 into the exact branch: with such scores stored, take the look-up where its
+      // table fits, else let every live column count (-> the per-entry logarithm runs)
+      if (h->lq_lin && (int)mn < h->lq_c0) {
+        if (h->lq_tab_fits) h->lq_lin = 0; else h->lq_lo = -INFINITY;
+      }
+    } else {
+      dfree(h->d_lq_mid);                                  // (no usable range: the log form runs unconditionally, as before)
+    }
+  }
   h->lq_n = (int)tab.size();
   return TSEM_OK;
 }
@@ -627,11 +685,22 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
   A.pcode = h->d_pcode; A.lut = h->d_lut; A.lut_len = fz_fmt(h) ? h->lut_len : 0; A.wcode = h->d_amb_wcode;
   size_t ldsf = fz_lds_bytes(h, fz_fmt(h) != 0);
   A.lctab = nullptr; A.lqtab = nullptr; A.lq_n = 0; A.lq_shift = 0; A.lq_base = 0; A.lq_lin = 0; A.lq_c0 = 0; A.lq_a = 0; A.lq_b = 0;
+  A.sel = nullptr; A.sel_thr = 0; A.sel_want = 0;
   if (mode == 1 && !(h->opt_dbg & 8192)) {                  // (fused_dbg bit 13: the per-entry logarithm, for A/B timing and tests)
     if (int rc = ensure_log_tables(h)) return rc;
     if (h->lq_n > 0) {
-      k_log_tab<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->d_ctab, h->d_lctab);
+      // fused_dbg bit 15: the log form whatever the parameters look like (tests of its exact branch, A/B timing)
+      const bool choose = h->d_lq_mid && !(h->opt_dbg & 32768);
+      if (choose) TSEM_HIP(hipMemsetAsync(h->d_lq_mid, 0, sizeof(unsigned long long), h->stream));
+      k_log_tab<<<cdiv64(h->Kpad, 256), 256, 0, h->stream>>>(h->Kpad, h->d_ctab, h->d_lctab, h->d_col_of_pc, h->d_colcount, h->lq_lo, h->lq_hi,
+                                                              choose ? h->d_lq_mid : nullptr);
       TSEM_HIP(hipGetLastError());
+      if (choose) {
+        // a wave takes the exact branch when ANY of its 256 entries of a step is in the range: with a share f of the entries there,
+        // 1 - (1 - f)^256 of the steps stall — 22 % at f = 1e-3, about where the two forms cost the same
+        A.sel = h->d_lq_mid; A.sel_thr = (unsigned long long)(1e-3 * (double)h->nnz); A.sel_want = 0;
+        h->lq_choice[0] += 1;
+      }
       A.lctab = h->d_lctab; A.lqtab = h->d_lqtab; A.lq_n = h->lq_n; A.lq_shift = h->lq_shift; A.lq_base = h->lq_base;
       A.lq_lin = (fz_fmt(h) == 1 && !((h->opt_dbg & 16384) && h->lq_tab_fits)) ? h->lq_lin : 0;   // (fused_dbg bit 14: the look-up even where the arithmetic form applies — tests)
       A.lq_c0 = h->lq_c0; A.lq_a = h->lq_a; A.lq_b = h->lq_b;
@@ -646,6 +715,14 @@ static int launch_fused(tsem_ctx* h, int mode, hipEvent_t* pair, int bin = 0) {
   if (pair) TSEM_HIP(hipEventRecord(pair[0], h->stream));   // time the kernel, not the memsets
   fn<<<h->fz_grid, FZ_NT, ldsf, h->stream>>>(A);
   TSEM_HIP(hipGetLastError());
+  if (kmode == 9 && A.sel) {                                // ... and the per-entry-logarithm form behind it: exactly one of the two runs
+    fz_fn f1 = fz_kernel(h->P, 1, fz_fmt(h), h->geo);
+    if (!f1) TSEM_FAIL(TSEM_ERR_ARG, "fused lnl: no kernel for this team size / geometry");
+    FusedArgs B = A;
+    B.lctab = nullptr; B.lqtab = nullptr; B.lq_n = 0; B.lq_lin = 0; B.sel_want = 1;
+    f1<<<h->fz_grid, FZ_NT, fz_lds_bytes(h, fz_fmt(h) != 0), h->stream>>>(B);
+    TSEM_HIP(hipGetLastError());
+  }
   h->fused_launched = true;
   return TSEM_OK;
 }

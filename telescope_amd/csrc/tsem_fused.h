@@ -100,6 +100,12 @@ struct FusedArgs {
   double* xchg;         // [team][FZ_XS][P][R] tagged granules, zero-filled before launch
   uint32_t* sync;       // zero-filled before launch
   const uint32_t* ctl;  // device-side loop control (tsem_em_chunk): ctl[0] != 0 -> the run has stopped, return at once
+  // lnl pass, two forms enqueued back to back (tsem_em.hip launch_fused): `sel` counts the stored entries of columns whose log(pi*theta)
+  // may put them into the exact branch of the log-table form; the launch with sel_want = 0 (log tables) runs while that count is
+  // <= sel_thr, the one with sel_want = 1 (a logarithm per entry) when it is above — the other returns at once.  null: no selection
+  const unsigned long long* sel;
+  unsigned long long sel_thr;
+  int sel_want;
   // MODE 2 (option "reproducible"): the column scatter adds pre-rounded pieces of w*z, so that every LDS accumulator sums EXACTLY
   // and the order in which the hardware serves the atomics stops mattering (profiles/HISTORY.md 5.1)
   const uint16_t* ebias;  // [P*Kp] biased exponent eb of the slot's bound 2^E (every contribution of the slot is < 2^E)
@@ -607,6 +613,7 @@ __global__ __launch_bounds__(FZ_NT) void k_em_fused(FusedArgs A) {
   uint32_t* const sync = A.sync;
   uint32_t* const err = sync + 9;
   if (A.ctl && fz_ld_u32(A.ctl) != 0u) return;            // stopped by an earlier update kernel of this chunk
+  if (LNL1 && A.sel && ((*A.sel > A.sel_thr) != (A.sel_want != 0))) return;   // the other form of the lnl pass runs (see FusedArgs)
   // start-up timeline (tools/startup_prof.py): 100 MHz wall clock of every workgroup's thread 0 at entry / tickets counted / LDS
   // zeroed / tables loaded / loop start / loop end / exit, behind the per-step slots of team 0
   unsigned long long* const sprof = (A.prof && tid == 0) ? A.prof + 64 * FZ_PROF_SLOTS + (size_t)blockIdx.x * 8 : nullptr;

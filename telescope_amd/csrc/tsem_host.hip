@@ -97,7 +97,7 @@ void tsem_free_layout(tsem_ctx* h) {
   dfree(h->d_ebias); dfree(h->d_ovf); dfree(h->d_red_hi); dfree(h->d_binflag); dfree(h->d_ehist);
   dfree(h->d_colmap); dfree(h->d_col_of_pc); dfree(h->d_rid16); dfree(h->d_col_of_id); dfree(h->d_sb_off); dfree(h->d_pval); dfree(h->d_pcode); dfree(h->d_prc);
   dfree(h->d_ypart); dfree(h->d_partial); dfree(h->d_xchg); dfree(h->d_xflags); dfree(h->d_fz_aux); h->fz_clean = false; dfree(h->d_fpartial); dfree(h->d_fpartial2); dfree(h->d_amb_w); dfree(h->d_sb_q32); dfree(h->d_rinv); h->lag_valid = false;
-  dfree(h->d_lctab); dfree(h->d_lqtab); h->lq_n = 0; h->lq_tried = false;
+  dfree(h->d_lctab); dfree(h->d_lqtab); dfree(h->d_lq_mid); h->lq_n = 0; h->lq_tried = false;
   h->fused_launched = false;
 }
 void tsem_free_matrix(tsem_ctx* h) {
@@ -625,6 +625,13 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[26] = h->em_rows ? 1 : 0;                           // K beyond 64 column parts: plain CSR row passes (no blocked layout)
   info[25] = h->n_single_part;                             // ambiguous rows whose entries all lie in ONE column part (they would need no exchange)
   info[24] = h->split ? 1 : 0;                             // split layout: two light passes per iteration (K > 61 440)
+  // the lnl pass's choice of form (tsem_em.hip k_log_tab): stored entries in columns that may reach the exact branch of the log form,
+  // as counted before the LAST lnl pass (-1: no choice armed), and the count above which the per-entry logarithm ran instead
+  info[29] = -1; info[30] = (int64_t)(1e-3 * (double)h->nnz);
+  if (h->d_lq_mid && h->lq_choice[0] > 0 && hipSetDevice(h->device) == hipSuccess) {
+    unsigned long long m = 0;
+    if (hipMemcpyAsync(&m, h->d_lq_mid, 8, hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess) info[29] = (int64_t)m;
+  }
   info[28] = h->lq_lin;                                    // ... and log Q is (code / max) * scale itself: no table (code entries, the reference's score table)
   info[27] = h->lq_n;                                      // entries of the log Q table of the lnl passes (0: not built yet / does not fit / does not apply)
   info[23] = h->lnl3 ? 1 : 0;                              // the layout lets the EM pass carry the previous iteration's log-likelihood (option "use_likelihood")

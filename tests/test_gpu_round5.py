@@ -178,7 +178,9 @@ def test_lnl_log_tables_with_dying_and_dead_columns(gpu_device):
     `use_likelihood` runs the dedicated pass when the carrying layout is not asked for)."""
     from oracle import em_fused as oc
     rows, cols = 60_000, 3_000
-    tl = _synthetic_tl(rows, cols, 8, 'zipf', uniq=0.3, options=(('value_format', 1),), opts=Opts(max_iter=400, em_epsilon=0.0, theta_prior=0))
+    # (fused_dbg bit 15: the log form whatever the parameters look like — left alone, the device switches to the per-entry logarithm
+    #  once many entries sit in dying columns, test_lnl_pass_picks_its_form_on_the_device)
+    tl = _synthetic_tl(rows, cols, 8, 'zipf', uniq=0.3, options=(('value_format', 1), ('fused_dbg', 32768)), opts=Opts(max_iter=400, em_epsilon=0.0, theta_prior=0))
     ip, ix, rw = tl._eng.export_csr()
     for it in (5, 60, 400):
         tl.max_iter = it
@@ -187,6 +189,34 @@ def test_lnl_log_tables_with_dying_and_dead_columns(gpu_device):
         ref = oc.em_fused_arrays(ip, ix, rw, cols, 0, 0, 0.0, it)
         assert abs(tl.lnl - ref['lnl']) <= RTOL * abs(ref['lnl']), (it, tl.lnl, ref['lnl'])
     assert tl.pi.min() < 1e-30                                       # columns did die
+
+
+def test_lnl_pass_picks_its_form_on_the_device(gpu_device):
+    """The log form of the lnl pass stalls on its exact branch (pi * theta fetched from global memory) when columns are on their way to
+    pi = 0; k_log_tab counts the stored entries of such columns before every pass and the two forms of the pass read the count: one of
+    them returns at once.  Fresh parameters: nothing counted, the log form runs.  After a long run with pi_prior = theta_prior = 0:
+    more than the limit, the per-entry logarithm runs.  Same lnl either way (both forced forms against each other and the C oracle)."""
+    from oracle import em_fused as oc
+    rows, cols = 120_000, 6_000
+    fresh = _synthetic_tl(rows, cols, 10, 'zipf', uniq=0.3, opts=Opts(max_iter=3, em_epsilon=0.0))      # the reference's default priors
+    fresh.em()
+    i0 = fresh._eng.layout_info()
+    assert i0['lnl_tables'] > 0 and 0 <= i0['lnl_mid_entries'] <= i0['lnl_mid_limit'], i0   # the log form ran
+    vals = {}
+    for dbg in (0, 8192, 32768):
+        tl = _synthetic_tl(rows, cols, 10, 'zipf', uniq=0.3, options=(('fused_dbg', dbg),), opts=Opts(max_iter=300, em_epsilon=0.0, theta_prior=0))
+        tl.em()
+        vals[dbg] = (tl.lnl, tl._eng.layout_info())
+        if dbg == 0:
+            ip, ix, rw = tl._eng.export_csr()
+    l0, j0 = vals[0]
+    assert j0['lnl_mid_entries'] > j0['lnl_mid_limit'] > 0, j0                     # dying columns: the per-entry logarithm took over
+    assert vals[8192][1]['lnl_mid_entries'] == -1 and vals[32768][1]['lnl_mid_entries'] == -1   # forced forms: no choice armed
+    a, b, c = vals[0][0], vals[8192][0], vals[32768][0]
+    assert abs(a - b) <= 1e-13 * abs(b) and abs(c - b) <= 1e-13 * abs(b), (a, b, c)
+    ref = oc.em_fused_arrays(ip, ix, rw, cols, 0, 0, 0.0, 300)
+    assert abs(l0 - ref['lnl']) <= RTOL * abs(ref['lnl'])
+    assert tl.pi.min() < 1e-30
 
 
 # ---- option drop_csr_indices (VERDICT r4 #7) -----------------------------------------------------------------------------------------

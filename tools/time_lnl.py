@@ -1,4 +1,4 @@
-"""Time tsem_lnl_pass (and the EM pass beside it) on the bench workload: python tools/time_lnl.py [rows] [nnz_row=40] [k=v ...]"""
+"""Time tsem_lnl_pass (and the EM pass beside it) on the bench workload: python tools/time_lnl.py [rows] [nnz_row=40] [cols=30000] [k=v ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
@@ -8,8 +8,10 @@ from test_gpu_parity import _synthetic_tl
 rows = int(sys.argv[1]) if len(sys.argv) > 1 and '=' not in sys.argv[1] else 50_000_000
 kv = dict(a.split('=') for a in sys.argv[1:] if '=' in a)
 nnz_row = int(kv.pop('nnz_row', 40))                 # (not an engine option: entries per row of the synthetic matrix)
+cols = int(kv.pop('cols', 30000))
 opts = tuple((k, int(v)) for k, v in kv.items())
-tl = _synthetic_tl(rows, 30000, nnz_row, 'zipf', options=opts)
+tl = _synthetic_tl(rows, cols, nnz_row, 'zipf', options=opts)
+print({k: tl._eng.layout_info()[k] for k in ('P', 'geometry', 'R', 'lnl_tables', 'lnl_linear', 'value_bytes')})
 e = tl._eng
 for _ in range(3):
     e.em_pass(); e.em_update()
