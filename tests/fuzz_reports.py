@@ -2,7 +2,7 @@
 report cache, the codes-only pass of the initial z, the tie list on the device and `choose`'s picks meet in every combination)
 against the oracle: integer columns bit for bit, conf / average to 1e-9.  A soak (the oracle is the checker, hence its place under tests/); tests/test_gpu_round5.py runs a slice of it:
 
-    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200]"""
+    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200] [public]      (`public`: estep / mstep / calculate_lnl with caller-supplied parameters)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
@@ -19,7 +19,8 @@ class Opts(object):
         self.__dict__.update(kw)
 
 
-def one(seed):
+def make_case(seed):
+    """(rng, raw matrix or None when empty, engine options, shape description) of a seed."""
     rng = np.random.RandomState(77000 + seed)
     k = int(rng.choice([3, 17, 200, 5000, 9000, 24000, 33000]))
     n = int(rng.choice([1, 7, 300, 2500, 12000, 30000]))
@@ -33,7 +34,7 @@ def one(seed):
     lo, hi = [(139, 212), (1, 5), (1, 2), (100, 1500), (60000, 65535), (0, 6)][int(rng.randint(6))]   # (few distinct scores: many ties; (0, 6): stored zeros)
     data = rng.randint(lo, hi + 1, indptr[-1]).astype(np.uint16)
     if indptr[-1] == 0 or data.max() == 0:
-        return 'skipped (empty)'
+        return rng, None, [], None
     raw = sp.csr_matrix((data, indices, indptr), shape=(n, k))
     options = [('value_format', int(rng.randint(0, 3)) if hi <= 1500 else int(rng.randint(0, 2)))]   # (2 = codes forced: needs a table of at most 2048 entries)
     if rng.rand() < 0.3:
@@ -42,6 +43,14 @@ def one(seed):
         options.append(('drop_csr_indices', 1))
     if rng.rand() < 0.15:
         options.append(('em_kernel', 1))
+    return rng, raw, options, (n, k, max_len, uniq, (lo, hi))
+
+
+def one(seed):
+    rng, raw, options, shape = make_case(seed)
+    if raw is None:
+        return 'skipped (empty)'
+    n, k, max_len, uniq, (lo, hi) = shape
     o = Opts(max_iter=int(rng.randint(1, 5)), em_epsilon=0.0)
     o.pi_prior, o.theta_prior = [(0, 200000), (0, 0), (5, 1000)][int(rng.randint(3))]
     eng = _lib.Engine(0)
@@ -87,13 +96,59 @@ def one(seed):
     return 'ok %s' % (ctx,)
 
 
+def public(seed):
+    """estep / mstep / calculate_lnl (model.py:702-760) with caller-supplied parameters — a share of them exactly 0, which drops
+    entries from z's pattern like scipy's CSR arithmetic does — against the oracle: pattern equal, values to 1e-9."""
+    rng, raw, options, shape = make_case(seed)
+    if raw is None:
+        return 'skipped (empty)'
+    n, k = raw.shape
+    o = Opts(max_iter=1, em_epsilon=0.0)
+    o.pi_prior, o.theta_prior = [(0, 200000), (0, 0), (5, 1000)][int(rng.randint(3))]
+    eng = _lib.Engine(0)
+    for key, v in options:
+        eng.set_option(key, v)
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), k, score_lut(int(raw.data.max())))
+    try:
+        tl = TelescopeLikelihood.from_engine(eng, o)
+    except _lib.EngineError as e:
+        if 'value_format=codes needs' in str(e):
+            return 'skipped (%s)' % e
+        raise
+    tl._raw = raw
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    pi, theta = rng.dirichlet(np.full(k, 0.3)), rng.dirichlet(np.full(k, 0.3))
+    zf = float(rng.choice([0.0, 0.05, 0.3]))
+    pi[rng.rand(k) < zf] = 0.0
+    theta[rng.rand(k) < zf] = 0.0
+    ctx = (seed, shape, options, zf)
+    with np.errstate(all='ignore'):
+        zo = sp.csr_matrix(om.estep(pi, theta))
+        zg = sp.csr_matrix(tl.estep(pi, theta))
+        zo.sort_indices(); zg.sort_indices()
+        if not (np.all(np.isfinite(zo.data))):
+            return 'skipped (the reference yields NaN / inf: %s)' % (ctx,)
+        assert np.array_equal(zo.indptr, zg.indptr) and np.array_equal(zo.indices, zg.indices), ('estep pattern', zo.nnz, zg.nnz, ctx)
+        assert np.allclose(zg.data, zo.data, rtol=1e-9, atol=1e-300), ('estep values', ctx)
+        po, to = om.mstep(zo)
+        pg, tg = tl.mstep(zg)
+        if np.all(np.isfinite(po)) and np.all(np.isfinite(to)):
+            assert np.allclose(pg, po, rtol=1e-9, atol=1e-300) and np.allclose(tg, to, rtol=1e-9, atol=1e-300), ('mstep', ctx)
+            lo_, lg_ = om.calculate_lnl(zo, po, to), tl.calculate_lnl(zg, pg, tg)
+            if np.isfinite(lo_):
+                assert abs(lg_ - lo_) <= 1e-9 * max(abs(lo_), 1e-300), ('calculate_lnl', lg_, lo_, ctx)
+    eng.close()
+    return 'ok %s' % (ctx,)
+
+
 if __name__ == '__main__':
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    fn = public if len(sys.argv) > 3 and sys.argv[3] == 'public' else one
     bad = 0
     for s in range(first, first + count):
         try:
-            r = one(s)
+            r = fn(s)
         except AssertionError as e:
             bad += 1
             r = 'FAILED %s' % (e,)

@@ -370,3 +370,13 @@ def test_reassign_column_sums_of_random_matrices_against_the_oracle(gpu_device, 
     import fuzz_reports as fuzz
     res = fuzz.one(seed)
     assert res.startswith('ok') or res.startswith('skipped'), res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [1, 22, 57, 140, 263])
+def test_public_methods_on_random_matrices_against_the_oracle(gpu_device, seed):
+    """A slice of `python tests/fuzz_reports.py 0 300 public` (0 failures of 271 cases): estep / mstep / calculate_lnl with caller-supplied
+    parameters, a share of them exactly 0 (entries leave z's pattern as in scipy's CSR arithmetic), against the oracle."""
+    import fuzz_reports as fuzz
+    res = fuzz.public(seed)
+    assert res.startswith('ok') or res.startswith('skipped'), res
