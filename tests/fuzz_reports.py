@@ -2,7 +2,7 @@
 report cache, the codes-only pass of the initial z, the tie list on the device and `choose`'s picks meet in every combination)
 against the oracle: integer columns bit for bit, conf / average to 1e-9.  A soak (the oracle is the checker, hence its place under tests/); tests/test_gpu_round5.py runs a slice of it:
 
-    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200] [public]      (`public`: estep / mstep / calculate_lnl with caller-supplied parameters)"""
+    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200] [public | sharded]      (`sharded`: 2-3 in-process ranks; `public`: estep / mstep / calculate_lnl with caller-supplied parameters)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
@@ -141,10 +141,84 @@ def public(seed):
     return 'ok %s' % (ctx,)
 
 
+def sharded(seed):
+    """The same random matrices ROW-SHARDED over 2 or 3 ranks (host threads on one GPU, the library's in-process transport: the shipped
+    tsem_em_chunk protocol, one all-reduce per iteration) — ranks without rows, with unique rows only, with a single row included —
+    against the oracle on the whole matrix: pi / theta / lnl to 1e-9 on every rank and bit-identical between the ranks, the integer
+    report columns bit for bit (the final z's from the engine's own parameters, as in `one`)."""
+    import threading
+    from telescope_amd.distributed import ThreadGroup, shard_bounds
+    rng, raw, options, shape = make_case(seed)
+    if raw is None:
+        return 'skipped (empty)'
+    n, k = raw.shape
+    o = Opts(max_iter=int(rng.randint(1, 5)), em_epsilon=0.0)
+    o.pi_prior, o.theta_prior = [(0, 200000), (0, 0), (5, 1000)][int(rng.randint(3))]
+    world = int(rng.choice([2, 3]))
+    options = [kv for kv in options if kv[0] != 'em_kernel']        # (every rank on the fused kernel: what a row-sharded run uses)
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    om.em(0.0, o.max_iter)
+    ctx = (seed, shape, options, world)
+    if not np.isfinite(om.lnl):
+        return 'skipped (the reference yields NaN: %s)' % (ctx,)
+    cuts = shard_bounds(n, world, indptr=raw.indptr)
+    group = ThreadGroup(0, world)
+    out, errs = [None] * world, []
+    asks = [(m, ini) for m in ('exclude', 'choose', 'average', 'conf', 'unique', 'all') for ini in (False, True)]
+    order = rng.permutation(len(asks))
+
+    def rank_main(rank):
+        comm = group.comm(rank)
+        r0, r1 = cuts[rank], cuts[rank + 1]
+        eo = dict(options); eo['row_offset'] = r0
+        tl = TelescopeLikelihood(raw[r0:r1], o, device=0, comm=comm, engine_options=eo)
+        tl.em()
+        res = dict(lnl=tl.lnl, pi=tl.pi.copy(), theta=tl.theta.copy(), prev=tl._eng.get_params(_lib.Z_PREV), cols={})
+        for i in order:
+            m, ini = asks[i]
+            if rank == 0:
+                np.random.seed(1234 + seed)
+            res['cols'][(m, ini)] = tl.reassign_colsums(m, 0.9, initial=ini)
+        comm.close()
+        return res
+
+    def work(r):
+        try:
+            out[r] = rank_main(r)
+        except BaseException as e:   # noqa: BLE001
+            errs.append((r, e))
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    hung = any(t.is_alive() for t in ts)
+    try:
+        group.close()
+    except Exception:    # noqa: BLE001
+        pass
+    assert not hung, ('a rank hangs', ctx)
+    if errs:
+        if 'value_format=codes needs' in str(errs[0][1]):
+            return 'skipped (%s)' % errs[0][1]
+        raise AssertionError(('rank %d: %r' % errs[0], ctx))
+    for r in out:
+        assert abs(r['lnl'] - om.lnl) <= 1e-9 * max(abs(om.lnl), 1e-300), ('lnl', r['lnl'], om.lnl, ctx)
+        assert np.allclose(r['pi'], om.pi, rtol=1e-9, atol=1e-300) and np.allclose(r['theta'], om.theta, rtol=1e-9, atol=1e-300), ('pi / theta', ctx)
+        assert np.array_equal(r['pi'], out[0]['pi']) and np.array_equal(r['theta'], out[0]['theta']) and r['lnl'] == out[0]['lnl'], ('ranks differ', ctx)
+    om.z = om.estep(*out[0]['prev'])
+    for (m, ini), got in out[0]['cols'].items():
+        np.random.seed(1234 + seed)
+        want = np.asarray(om.reassign(m, 0.9, initial=ini, rng=np.random).sum(0)).ravel()
+        if m in ('conf', 'average'):
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-9), (m, ini, ctx)
+        else:
+            assert np.array_equal(np.asarray(got, np.int64), np.rint(want).astype(np.int64)), (m, ini, int(np.abs(got - want).sum()), ctx)
+    return 'ok %s' % (ctx,)
+
+
 if __name__ == '__main__':
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    fn = public if len(sys.argv) > 3 and sys.argv[3] == 'public' else one
+    fn = {'public': public, 'sharded': sharded}.get(sys.argv[3] if len(sys.argv) > 3 else '', one)
     bad = 0
     for s in range(first, first + count):
         try:

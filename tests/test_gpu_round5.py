@@ -380,3 +380,16 @@ def test_public_methods_on_random_matrices_against_the_oracle(gpu_device, seed):
     import fuzz_reports as fuzz
     res = fuzz.public(seed)
     assert res.startswith('ok') or res.startswith('skipped'), res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [10, 3, 77, 118])
+def test_row_sharded_random_matrices_against_the_oracle(gpu_device, seed):
+    """A slice of `python tests/fuzz_reports.py 0 150 sharded` (139 cases, 0 failures): the random matrices row-sharded over 2 or 3
+    in-process ranks (the shipped tsem_em_chunk protocol), ranks without rows included; pi / theta / lnl on every rank, bit-identical
+    between ranks, all twelve report columns against the oracle.  Seed 10 is the case that exposed FMA-contracted row sums in the
+    streaming report kernel (one ulp in 1 / rowsum broke an exact tie of two z values): the report, mask and z kernels are compiled
+    with -ffp-contract=off since (telescope_amd/_lib.py build_library)."""
+    import fuzz_reports as fuzz
+    res = fuzz.sharded(seed)
+    assert res.startswith('ok') or res.startswith('skipped'), res

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ''
 csrc = os.path.join(ROOT, 'telescope_amd', 'csrc')
-cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-I' + os.path.join(ROOT, 'include'),
+cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics'] + ([] if os.path.basename(src).startswith('tsem_fz_p') else ['-ffp-contract=off']) + ['-I' + os.path.join(ROOT, 'include'),
        '-I' + csrc, '-c', src, '-o', '/dev/null', '-Rpass-analysis=kernel-resource-usage'] + sys.argv[3:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
