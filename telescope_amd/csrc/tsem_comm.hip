@@ -240,7 +240,7 @@ int tsem_comm_local_group(tsem_local_group** out, int device, int world) {
   *out = nullptr;
   if (hipSetDevice(device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return TSEM_ERR_HIP; }
   tsem_local_group* g = new tsem_local_group();
-  g->world = world; g->device = device;
+  g->world = world; g->device = device; g->refs = 1;       // the creator's handle
   for (int q = 0; q < world; ++q)
     for (int par = 0; par < 2; ++par)
       if (hipEventCreateWithFlags(&g->ready[q][par], hipEventDisableTiming) != hipSuccess ||
@@ -251,8 +251,15 @@ int tsem_comm_local_group(tsem_local_group** out, int device, int world) {
   return TSEM_OK;
 }
 
-void tsem_comm_local_group_destroy(tsem_local_group* g) {
-  if (!g) return;
+// The group lives until its creator's handle AND every communicator made from it are gone (`refs`): a caller that destroys the group
+// while a rank's communicator still exists — an error path that skipped a rank's close, a garbage-collected Python object — used to
+// leave that communicator with a dangling pointer, and its destructor locked a destroyed mutex (std::system_error, found by the
+// row-sharded soak).  A destroyed group is `broken` for the ranks that still hold it: their collectives fail instead of waiting.
+static void local_group_release(tsem_local_group* g) {
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (--g->refs > 0) return;
+  }
   (void)hipSetDevice(g->device);
   (void)hipDeviceSynchronize();
   for (int q = 0; q < g->world; ++q)
@@ -264,6 +271,16 @@ void tsem_comm_local_group_destroy(tsem_local_group* g) {
   delete g;
 }
 
+void tsem_comm_local_group_destroy(tsem_local_group* g) {
+  if (!g) return;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->broken = true;                                      // (ranks still inside a collective, or entering one later, fail at once)
+    g->cv.notify_all();
+  }
+  local_group_release(g);
+}
+
 int tsem_comm_create_local(tsem_comm** out, tsem_local_group* g, int rank) {
   if (!out || !g || rank < 0 || rank >= g->world) return TSEM_ERR_ARG;
   *out = nullptr;
@@ -271,6 +288,7 @@ int tsem_comm_create_local(tsem_comm** out, tsem_local_group* g, int rank) {
     std::lock_guard<std::mutex> lk(g->mu);
     if (g->taken[rank]) { g_comm_err = "tsem_comm_create_local: this rank of the group is taken"; return TSEM_ERR_ARG; }
     g->taken[rank] = true;
+    g->refs += 1;
   }
   tsem_comm* c = new tsem_comm();
   c->device = g->device; c->rank = rank; c->world = g->world; c->local = g;
@@ -283,7 +301,10 @@ void tsem_comm_destroy(tsem_comm* c) {
   (void)hipSetDevice(c->device);
   if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->nccl) (void)nccl_api()->CommDestroy(c->nccl);
-  if (c->local) { std::lock_guard<std::mutex> lk(c->local->mu); c->local->taken[c->rank] = false; }
+  if (c->local) {
+    { std::lock_guard<std::mutex> lk(c->local->mu); c->local->taken[c->rank] = false; }
+    local_group_release(c->local);
+  }
   delete c;
 }
 

@@ -46,6 +46,15 @@ def shard_bounds(n_rows, world, rank=None, indptr=None):
     return cuts[rank], cuts[rank + 1]
 
 
+def _detach(engine, attached):
+    """Take a communicator that is about to be destroyed off the engine it was attached to (tsem_comm_attach(h, NULL))."""
+    if engine is not None and attached:
+        try:
+            engine.comm_attach(None)
+        except Exception:                                     # noqa: BLE001 — (the engine may be closed already)
+            pass
+
+
 class Comm(object):
     """An initialised torch.distributed process group + (on GPUs) the library's RCCL communicator."""
 
@@ -132,6 +141,8 @@ class Comm(object):
 
     def close(self):
         if self.lib is not None:
+            _detach(getattr(self, '_eng', None), self.in_library)   # (the engine must not keep a pointer to a destroyed communicator)
+            self.in_library = False
             self.lib.close()
             self.lib = None
 
@@ -329,6 +340,8 @@ class ThreadComm(object):
 
     def close(self):
         if self.lib is not None:
+            _detach(getattr(self, '_eng', None), self.in_library)
+            self.in_library = False
             self.lib.close()
             self.lib = None
 
@@ -365,6 +378,7 @@ class ThreadComm(object):
         self.lib.allreduce([0.0], 'f64', 'sum')
 
     def attach(self, engine, n_cols):
+        self._eng = engine
         engine.comm_attach(self.lib.handle)
         self.in_library = True
 
