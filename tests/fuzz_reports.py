@@ -2,7 +2,7 @@
 report cache, the codes-only pass of the initial z, the tie list on the device and `choose`'s picks meet in every combination)
 against the oracle: integer columns bit for bit, conf / average to 1e-9.  A soak (the oracle is the checker, hence its place under tests/); tests/test_gpu_round5.py runs a slice of it:
 
-    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200] [public | sharded | lookups]      (`sharded`: 2-3 in-process ranks; `public`: estep / mstep / calculate_lnl with caller-supplied parameters)"""
+    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200] [public | sharded | lookups | groups]      (`sharded`: 2-3 in-process ranks; `public`: estep / mstep / calculate_lnl with caller-supplied parameters)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
@@ -263,10 +263,61 @@ def lookups(seed):
     return 'ok %s' % (ctx,)
 
 
+def groups(seed):
+    """`tl.reassign_group_sums(method, group_rows)` — per-barcode column sums (model.py:523-555 sums the mask's rows per cell) — for
+    random groupings (rows in no group, in several, listed twice; empty groups; a small group tile) against the oracle's masks."""
+    rng, raw, options, shape = make_case(seed)
+    if raw is None:
+        return 'skipped (empty)'
+    n, k = raw.shape
+    o = Opts(max_iter=int(rng.randint(1, 4)), em_epsilon=0.0)
+    o.pi_prior, o.theta_prior = [(0, 200000), (0, 0), (5, 1000)][int(rng.randint(3))]
+    eng = _lib.Engine(0)
+    for key, v in options:
+        eng.set_option(key, v)
+    if rng.rand() < 0.4:
+        eng.set_option('group_tile_bytes', int(rng.choice([1 << 16, 1 << 20])))       # (bytes: forces several tiles)
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), k, score_lut(int(raw.data.max())))
+    try:
+        tl = TelescopeLikelihood.from_engine(eng, o)
+    except _lib.EngineError as e:
+        if 'value_format=codes needs' in str(e):
+            return 'skipped (%s)' % e
+        raise
+    tl._raw = raw
+    tl.em()
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    om.em(0.0, o.max_iter)
+    ctx = (seed, shape, options)
+    if not np.isfinite(om.lnl):
+        return 'skipped (the reference yields NaN: %s)' % (ctx,)
+    om.z = om.estep(*eng.get_params(_lib.Z_PREV))
+    ng = int(rng.choice([1, 3, 40]))
+    style = int(rng.randint(3))
+    if style == 0:                                              # a partition (what barcodes are)
+        lab = rng.randint(0, ng, n)
+        grp = [np.nonzero(lab == g)[0] for g in range(ng)]
+    elif style == 1:                                            # some rows nowhere, some in two groups, some listed twice
+        grp = [rng.randint(0, n, rng.randint(0, max(1, n // 2) + 1)) for _ in range(ng)]
+    else:                                                       # python lists, an empty group
+        grp = [list(map(int, rng.randint(0, n, rng.randint(0, 20)))) for _ in range(ng)] + [[]]
+    for method in ('exclude', 'average', 'conf', 'unique', 'all'):
+        ini = bool(rng.randint(2))
+        thresh = float(rng.choice([0.9, 0.6]))
+        got = tl.reassign_group_sums(method, grp, thresh, initial=ini)
+        mo = sp.csr_matrix(om.reassign(method, thresh, initial=ini)).astype(np.float64)
+        for gi, g in enumerate(grp):
+            g = np.asarray(g, np.int64)
+            want = np.asarray(mo[g].sum(0)).ravel() if len(g) else np.zeros(k)
+            assert np.allclose(got[gi], want, rtol=1e-9, atol=1e-9), (method, ini, thresh, gi, float(np.abs(got[gi] - want).max()), ctx)
+    eng.close()
+    return 'ok %s' % (ctx,)
+
+
 if __name__ == '__main__':
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    fn = {'public': public, 'sharded': sharded, 'lookups': lookups}.get(sys.argv[3] if len(sys.argv) > 3 else '', one)
+    fn = {'public': public, 'sharded': sharded, 'lookups': lookups, 'groups': groups}.get(sys.argv[3] if len(sys.argv) > 3 else '', one)
     bad = 0
     for s in range(first, first + count):
         try:
