@@ -2,7 +2,7 @@
 report cache, the codes-only pass of the initial z, the tie list on the device and `choose`'s picks meet in every combination)
 against the oracle: integer columns bit for bit, conf / average to 1e-9.  A soak (the oracle is the checker, hence its place under tests/); tests/test_gpu_round5.py runs a slice of it:
 
-    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200] [public | sharded | lookups | groups]      (`sharded`: 2-3 in-process ranks; `public`: estep / mstep / calculate_lnl with caller-supplied parameters)"""
+    python tests/fuzz_reports.py [first_seed=0] [n_seeds=200] [public | sharded | lookups | groups | converge]      (`sharded`: 2-3 in-process ranks; `public`: estep / mstep / calculate_lnl with caller-supplied parameters)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
@@ -314,10 +314,60 @@ def groups(seed):
     return 'ok %s' % (ctx,)
 
 
+def converge(seed):
+    """em() run to CONVERGENCE on the random matrices — both tests of the reference (model.py:771-797: sum |pi - pi_prev| < epsilon, or
+    under use_likelihood |lnl - lnl_prev| < epsilon), epsilons that stop the loop early, late or never — against the oracle: the same
+    iteration count (unless the oracle's own deciding quantity sits within 1e-6 of epsilon: then either side may stop one later),
+    pi / theta / lnl to 1e-9.  Covers the device-side stop flag, the lagged test of the carried lnl (MODE 4) and the per-iteration lnl pass."""
+    rng, raw, options, shape = make_case(seed)
+    if raw is None:
+        return 'skipped (empty)'
+    n, k = raw.shape
+    use_lnl = bool(rng.randint(2))
+    o = Opts(max_iter=int(rng.choice([3, 40, 120])), em_epsilon=float(rng.choice([1e-7, 1e-4, 1e-2, 1.0])))
+    o.pi_prior, o.theta_prior = [(0, 200000), (5, 1000)][int(rng.randint(2))]
+    eng = _lib.Engine(0)
+    for key, v in options:
+        eng.set_option(key, v)
+    if use_lnl and rng.rand() < 0.7:
+        eng.set_option('use_likelihood', 1)                  # lay the matrix out for the carried lnl where the geometry allows
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), k, score_lut(int(raw.data.max())))
+    try:
+        tl = TelescopeLikelihood.from_engine(eng, o)
+    except _lib.EngineError as e:
+        if 'value_format=codes needs' in str(e):
+            return 'skipped (%s)' % e
+        raise
+    tl._raw = raw
+    tl.em(use_likelihood=use_lnl)
+    om = OracleModel(raw, o.pi_prior, o.theta_prior)
+    trace = om.em(o.em_epsilon, o.max_iter, use_likelihood=use_lnl)
+    ctx = (seed, shape, options, use_lnl, o.em_epsilon, o.max_iter, eng.layout_info()['lnl_fused'])
+    if not np.isfinite(om.lnl):
+        return 'skipped (the reference yields NaN: %s)' % (ctx,)
+    n_ref = len(trace)
+    if tl.n_iter != n_ref:
+        # the deciding quantity of the oracle's last (or the engine's last) iteration within 1e-6 of epsilon?
+        def decider(i):
+            if i < 1 or i > len(trace):
+                return None
+            if use_lnl:
+                return abs(trace[i - 1][1] - trace[i - 2][1]) if i >= 2 else None
+            return trace[i - 1][0]
+        near = [d for d in (decider(min(tl.n_iter, n_ref)), decider(max(tl.n_iter, n_ref))) if d is not None]
+        close = any(abs(d - o.em_epsilon) <= 1e-6 * max(o.em_epsilon, d) for d in near)
+        assert close and abs(tl.n_iter - n_ref) == 1, ('iterations', tl.n_iter, n_ref, near, ctx)
+        return 'ok (stopped one apart on a threshold tie) %s' % (ctx,)
+    assert abs(tl.lnl - om.lnl) <= 1e-9 * max(abs(om.lnl), 1e-300), ('lnl', tl.lnl, om.lnl, ctx)
+    assert np.allclose(tl.pi, om.pi, rtol=1e-9, atol=1e-300) and np.allclose(tl.theta, om.theta, rtol=1e-9, atol=1e-300), ('pi / theta', ctx)
+    eng.close()
+    return 'ok %s' % (ctx,)
+
+
 if __name__ == '__main__':
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    fn = {'public': public, 'sharded': sharded, 'lookups': lookups, 'groups': groups}.get(sys.argv[3] if len(sys.argv) > 3 else '', one)
+    fn = {'public': public, 'sharded': sharded, 'lookups': lookups, 'groups': groups, 'converge': converge}.get(sys.argv[3] if len(sys.argv) > 3 else '', one)
     bad = 0
     for s in range(first, first + count):
         try:

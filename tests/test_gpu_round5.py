@@ -413,3 +413,13 @@ def test_group_sums_on_random_matrices_against_the_oracle(gpu_device, seed):
     import fuzz_reports as fuzz
     res = fuzz.groups(seed)
     assert res.startswith('ok') or res.startswith('skipped'), res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [2, 37, 120, 201, 288])
+def test_convergence_on_random_matrices_against_the_oracle(gpu_device, seed):
+    """A slice of `python tests/fuzz_reports.py 0 300 converge` (271 cases, 0 failures, none stopped apart): em() to convergence under
+    both of the reference's tests with epsilons that stop early, late or never — iteration count, pi, theta, lnl against the oracle."""
+    import fuzz_reports as fuzz
+    res = fuzz.converge(seed)
+    assert res.startswith('ok') or res.startswith('skipped'), res
