@@ -88,6 +88,7 @@ struct tsem_ctx {
   uint16_t* d_row_code = nullptr;   // [N] per CSR row: its largest raw score (w_i = lut[code], model.py:690); tsem_rowstats, kept for tsem_export_rowinfo
   uint8_t* d_row_cls = nullptr;     // [N] 0 empty row, 1 unique (Y_i = 0), 2 ambiguous (Y_i = 1, model.py:679)
   int32_t max_code = -1;            // largest raw score of the resident matrix (-1: not taken yet); tsem_max_score
+  int32_t min_code = -1;            // smallest stored score above 0 (taken by the same pass; -1: none / not taken yet)
   bool have_rowstats = false;
   bool bin_inexact = false;         // option "reproducible": a pass gave up moving a column's grid after 40 repeats (its sums are not exact)
 

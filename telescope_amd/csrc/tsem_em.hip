@@ -548,17 +548,6 @@ __global__ void k_log_tab(int n, const double* __restrict__ c, double* __restric
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(mid, m);
   }
 }
-// smallest stored score > 0 (the lower end of log Q for k_log_tab's test)
-__global__ void k_min_u16_nz(const uint16_t* __restrict__ raw, int64_t n, uint32_t* __restrict__ out) {
-  uint32_t m = 0xFFFFu;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t r = raw[i];
-    m = r != 0u && r < m ? r : m;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMin(out, m);
-}
 // log Q, built once per layout and score table.  Code entries: one value per code.  fp64 entries: a direct-index table on the top bits
 // of Q — the fewest mantissa bits that keep the codes 1 .. max apart — provided it fits the LDS the layout leaves.  lq_n stays 0 when
 // the tables do not apply (no score table in LDS) or do not fit: the passes then evaluate the logarithm per entry as before.
@@ -631,23 +620,16 @@ static int ensure_log_tables(tsem_ctx* h) {
   TSEM_ALLOC(h->d_lctab, h->Kpad);
   // the range of log Q over the stored scores, for the choice between the two forms of the pass (k_log_tab)
   h->lq_lo = 0.0; h->lq_hi = 0.0;
-  if (h->d_colcount && h->d_col_of_pc && h->nnz > 0 && h->max_code > 0 && h->max_code < h->lut_len) {
-    TSEM_ALLOC(h->d_lq_mid, 1);
-    uint32_t mn = 0xFFFFu;
-    uint32_t* const d_mn = reinterpret_cast<uint32_t*>(h->d_lq_mid);
-    TSEM_HIP(hipMemcpyAsync(d_mn, &mn, 4, hipMemcpyHostToDevice, h->stream));
-    k_min_u16_nz<<<1024, 256, 0, h->stream>>>(h->d_raw, h->nnz, d_mn);
-    TSEM_HIP(hipMemcpyAsync(&mn, d_mn, 4, hipMemcpyDeviceToHost, h->stream));
-    TSEM_HIP(hipStreamSynchronize(h->stream));
-    if (mn >= 1u && (int)mn <= h->max_code && h->lut_host[mn] > 0.0 && std::isfinite(h->lut_host[h->max_code])) {
+  if (h->d_colcount && h->d_col_of_pc && h->nnz > 0 && h->max_code > 0 && h->max_code < h->lut_len && h->min_code >= 1 && h->min_code <= h->max_code) {
+    const int mn = h->min_code;                            // (tsem_max_score found both ends in its one pass over the scores)
+    if (h->lut_host[mn] > 0.0 && std::isfinite(h->lut_host[h->max_code])) {
+      TSEM_ALLOC(h->d_lq_mid, 1);
       h->lq_lo = std::log(h->lut_host[mn]); h->lq_hi = std::log(h->lut_host[h->max_code]);
       // the arithmetic log Q sends every code below lq_c0 into the exact branch: with such scores stored, take the look-up where its
       // table fits, else let every live column count (-> the per-entry logarithm runs)
-      if (h->lq_lin && (int)mn < h->lq_c0) {
+      if (h->lq_lin && mn < h->lq_c0) {
         if (h->lq_tab_fits) h->lq_lin = 0; else h->lq_lo = -INFINITY;
       }
-    } else {
-      dfree(h->d_lq_mid);                                  // (no usable range: the log form runs unconditionally, as before)
     }
   }
   h->lq_n = (int)tab.size();

@@ -118,7 +118,7 @@ void tsem_free_matrix(tsem_ctx* h) {
   h->d_red = nullptr;
   h->have_rowstats = h->have_model = false;
   h->N = h->nnz = 0; h->K = 0;
-  h->max_code = -1;
+  h->max_code = -1; h->min_code = -1;
   h->lnl3_declined = false;
 }
 
@@ -360,8 +360,11 @@ int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_col
   return TSEM_OK;
 }
 
+// out[0]: the largest score; out[1] (preset to 0xFFFF): the smallest one above 0 — the range of log Q for the lnl pass's choice of
+// form (tsem_em.hip k_log_tab), found on the way
 __global__ void k_max_u16(const uint16_t* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
-  uint32_t m = 0;
+  uint32_t m = 0, lo = 0xFFFFu;
+  auto low = [](uint32_t a, uint32_t x) -> uint32_t { return x != 0u && x < a ? x : a; };
   // eight scores per 16-byte load (hipMalloc alignment); the tail one by one
   const uint4* v4 = reinterpret_cast<const uint4*>(v);
   const int64_t n8 = n / 8;
@@ -370,23 +373,29 @@ __global__ void k_max_u16(const uint16_t* __restrict__ v, int64_t n, uint32_t* _
     const uint32_t a = max(max(w.x & 0xFFFFu, w.x >> 16), max(w.y & 0xFFFFu, w.y >> 16));
     const uint32_t b = max(max(w.z & 0xFFFFu, w.z >> 16), max(w.w & 0xFFFFu, w.w >> 16));
     m = max(m, max(a, b));
+    lo = low(low(low(low(lo, w.x & 0xFFFFu), w.x >> 16), w.y & 0xFFFFu), w.y >> 16);
+    lo = low(low(low(low(lo, w.z & 0xFFFFu), w.z >> 16), w.w & 0xFFFFu), w.w >> 16);
   }
-  for (int64_t i = n8 * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+  for (int64_t i = n8 * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     m = max(m, (uint32_t)v[i]);
+    lo = low(lo, (uint32_t)v[i]);
+  }
   m = (uint32_t)sg_max_i<64>((int)m);
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  lo = 0xFFFFu - (uint32_t)sg_max_i<64>((int)(0xFFFFu - lo));
+  if ((threadIdx.x & 63) == 0 && m) { atomicMax(out, m); atomicMin(out + 1, lo); }
 }
 
 int tsem_max_score(tsem_ctx* h, int32_t* max_score) {
   if (!h || !h->d_indptr || !max_score) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
   if (h->max_code < 0) {                                     // (the matrix does not change between load / generate calls)
-    TSEM_HIP(hipMemsetAsync(h->d_maxcode, 0, 4, h->stream));
+    uint32_t mm[2] = {0u, 0xFFFFu};
+    TSEM_HIP(hipMemcpyAsync(h->d_maxcode, mm, 8, hipMemcpyHostToDevice, h->stream));
     if (h->nnz) k_max_u16<<<1024, 256, 0, h->stream>>>(h->d_raw, h->nnz, h->d_maxcode);
-    uint32_t m = 0;
-    TSEM_HIP(hipMemcpyAsync(&m, h->d_maxcode, 4, hipMemcpyDeviceToHost, h->stream));
+    TSEM_HIP(hipMemcpyAsync(mm, h->d_maxcode, 8, hipMemcpyDeviceToHost, h->stream));
     TSEM_HIP(hipStreamSynchronize(h->stream));
-    h->max_code = (int32_t)m;
+    h->max_code = (int32_t)mm[0];
+    h->min_code = mm[0] ? (int32_t)mm[1] : -1;             // (smallest stored score above 0; -1: none)
   }
   *max_score = h->max_code;
   return TSEM_OK;
