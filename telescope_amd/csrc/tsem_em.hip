@@ -535,9 +535,10 @@ __global__ void k_log_tab(int n, const double* __restrict__ c, double* __restric
       // (real scores crowd near the top: an over-estimate, i.e. the per-entry logarithm takes over a little early)
       const int j = col_of_pc[t];                          // (-1: padding, the further slots of a split column)
       if (j >= 0 && l + lq_hi >= FZ_L_ZERO && l + lq_lo < FZ_L_FAST) {
-        const double w = lq_hi - lq_lo;
-        const double below_fast = w > 0.0 ? fmin(1.0, fmax(0.0, (FZ_L_FAST - l - lq_lo) / w)) : 1.0;
-        const double below_zero = w > 0.0 ? fmin(1.0, fmax(0.0, (FZ_L_ZERO - l - lq_lo) / w)) : 0.0;
+        const double w = lq_hi - lq_lo;                    // (lq_lo = -inf: codes the arithmetic log Q forces into the branch — every entry counts)
+        const bool spread = w > 0.0 && w < INFINITY;
+        const double below_fast = spread ? fmin(1.0, fmax(0.0, (FZ_L_FAST - l - lq_lo) / w)) : 1.0;
+        const double below_zero = spread ? fmin(1.0, fmax(0.0, (FZ_L_ZERO - l - lq_lo) / w)) : 0.0;
         m = (unsigned long long)((double)colcount[j] * (below_fast - below_zero) + 0.5);
       }
     }

@@ -191,6 +191,34 @@ def test_lnl_log_tables_with_dying_and_dead_columns(gpu_device):
     assert tl.pi.min() < 1e-30                                       # columns did die
 
 
+def test_lnl_choice_when_the_arithmetic_log_q_would_force_the_exact_branch(gpu_device):
+    """Score codes below 0.38 x max (t < 38) are outside the range where log Q = (code / max) * 100 holds: the log form would send every
+    such entry through its exact branch.  Where a log Q table fits the LDS the library takes the look-up instead; on a layout whose row
+    slots fill the LDS (K = 30k, 12 per row) every live column counts towards the choice and the per-entry logarithm runs.  Same lnl as
+    the forced forms and the C oracle either way."""
+    import scipy.sparse as sp
+    from oracle import em_fused as oc
+    from telescope_amd import synthetic
+    from telescope_amd.likelihood import TelescopeLikelihood
+    for rows, cols, d, want_linear in ((600_000, 30_000, 12, 1), (200_000, 5_000, 20, 0)):
+        ip, ix, rw = synthetic.generate(rows, cols, float(d), seed=42, dist='zipf', uniq_frac=0.05)
+        rw = rw.copy()
+        rw[::97] = 40                                             # t = 40 / 300 * 100 = 13: far below 38
+        raw = sp.csr_matrix((rw, ix, ip), shape=(rows, cols))
+        vals = {}
+        for dbg in (0, 8192, 32768):
+            tl = TelescopeLikelihood(raw, Opts(max_iter=4, em_epsilon=0.0), device=0, engine_options={'fused_dbg': dbg})
+            tl.em()
+            vals[dbg] = (tl.lnl, tl._eng.layout_info())
+        info = vals[0][1]
+        assert info['fused'] == 1 and info['lnl_tables'] > 0 and info['lnl_linear'] == want_linear, info
+        if want_linear:                                           # no room for the table: every live column counts, MODE 1 runs
+            assert info['lnl_mid_entries'] > info['lnl_mid_limit'] > 0, info
+        ref = oc.em_fused_arrays(ip, ix, rw, cols, 0, 200000, 0.0, 4)
+        assert abs(vals[0][0] - ref['lnl']) <= RTOL * abs(ref['lnl'])
+        assert abs(vals[0][0] - vals[8192][0]) <= 1e-13 * abs(vals[0][0]) and abs(vals[32768][0] - vals[8192][0]) <= 1e-13 * abs(vals[0][0]), vals
+
+
 def test_lnl_pass_picks_its_form_on_the_device(gpu_device):
     """The log form of the lnl pass stalls on its exact branch (pi * theta fetched from global memory) when columns are on their way to
     pi = 0; k_log_tab counts the stored entries of such columns before every pass and the two forms of the pass read the count: one of
