@@ -355,7 +355,12 @@ int  tsem_phase_times(tsem_ctx* h, int reset, double* ms6, int64_t* n_iter);
  * ids | blocked layout | per-row arrays }.  What a capacity plan needs: 14 B per stored entry by default (score codes), 10 after
  * the drop, + ~20 B per row. */
 int  tsem_device_memory(tsem_ctx* h, int device, int64_t* free_bytes, int64_t* total_bytes, int64_t* resident5);
-int  tsem_layout_info(tsem_ctx* h, int64_t* info32 /* 31 values written; [29] / [30] synchronise the stream to read the lnl pass's last choice of form */);
+/* Facts about the resident layout, 31 values (the Python binding names them: _lib.Engine.layout_info).  Of the later ones: [23] the
+ * EM pass carries the previous iteration's lnl; [24] split layout; [26] plain CSR row passes; [27] entries of the lnl pass's log Q
+ * table (0: none), [28] log Q is arithmetic (no table); [29] stored entries that k_log_tab counted for the exact branch of the log
+ * form before the LAST lnl pass (-1: no choice armed) and [30] the count above which the per-entry logarithm runs instead — reading
+ * [29] synchronises the handle's stream. */
+int  tsem_layout_info(tsem_ctx* h, int64_t* info32);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);
 /* the same option's start-up timeline: per workgroup b (up to 512), out[8 b ..] = 100 MHz wall clock at entry / tickets counted /
