@@ -355,11 +355,13 @@ int  tsem_phase_times(tsem_ctx* h, int reset, double* ms6, int64_t* n_iter);
  * ids | blocked layout | per-row arrays }.  What a capacity plan needs: 14 B per stored entry by default (score codes), 10 after
  * the drop, + ~20 B per row. */
 int  tsem_device_memory(tsem_ctx* h, int device, int64_t* free_bytes, int64_t* total_bytes, int64_t* resident5);
-/* Facts about the resident layout, 31 values (the Python binding names them: _lib.Engine.layout_info).  Of the later ones: [23] the
+/* Facts about the resident layout, 32 values (the Python binding names them: _lib.Engine.layout_info).  Of the later ones: [23] the
  * EM pass carries the previous iteration's lnl; [24] split layout; [26] plain CSR row passes; [27] entries of the lnl pass's log Q
  * table (0: none), [28] log Q is arithmetic (no table); [29] stored entries that k_log_tab counted for the exact branch of the log
  * form before the LAST lnl pass (-1: no choice armed) and [30] the count above which the per-entry logarithm runs instead — reading
- * [29] synchronises the handle's stream. */
+ * [29] synchronises the handle's stream; [31] rows whose row sum the report / row passes recomputed in the reference's own order of
+ * additions (scipy's `sum(axis=1)` = np.add.reduceat: a0 + pairwise(a1 ..)) since the matrix was loaded — the rows where two z values,
+ * or a z value and conf_prob, are closer than the rounding of 1 / rowsum could decide (sparse_plus.py:99-129 compares with `==`). */
 int  tsem_layout_info(tsem_ctx* h, int64_t* info32);
 /* per-block shader-clock stamps of team 0 / member 0 of the fused kernel (option "fused_prof") */
 int  tsem_debug_fused_prof(tsem_ctx* h, uint64_t* out512);

@@ -607,7 +607,7 @@ class Engine(object):
         self._ck(self._L.tsem_layout_info(self._h, ptr(info)))
         return dict(zip(('P', 'Kp', 'R', 'nb', 'N_amb', 'N_uni', 'nnz_amb', 'nnz_pad', 'twin_cols',
                          'G1', 'G2', 'fused', 'slow_path', 'max_subblock', 'value_bytes', 'hot_cols',
-                         'lds_bytes', 'row_order', 'geometry', 'fallbacks', 'bin_repeats', 'reproducible', 'exact_single', 'lnl_fused', 'split', 'single_part_rows', 'row_pass_em', 'lnl_tables', 'lnl_linear', 'lnl_mid_entries', 'lnl_mid_limit'), info.tolist()))
+                         'lds_bytes', 'row_order', 'geometry', 'fallbacks', 'bin_repeats', 'reproducible', 'exact_single', 'lnl_fused', 'split', 'single_part_rows', 'row_pass_em', 'lnl_tables', 'lnl_linear', 'lnl_mid_entries', 'lnl_mid_limit', 'near_tie_rows'), info.tolist()))
 
 
 def legacy_randint(counts):

@@ -110,7 +110,7 @@ void tsem_free_matrix(tsem_ctx* h) {
   dfree(h->d_c32); dfree(h->d_cs32); dfree(h->d_lut32); dfree(h->d_cnat);
   dfree(h->d_ctl); dfree(h->d_ctld); dfree(h->d_lnls); dfree(h->d_pi_first); dfree(h->d_theta_first); dfree(h->d_user_z);
   dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;
-  dfree(h->d_rep_nb); dfree(h->d_rep_rows); dfree(h->d_rep_n);
+  dfree(h->d_rep_nb); dfree(h->d_rep_rows); dfree(h->d_rep_n); dfree(h->d_exact_n); dfree(h->d_flag_bits); h->flag_words = 0;
   dfree(h->d_group); h->n_groups = 0;
   if (h->d_gtile) { (void)hipFree(h->d_gtile); h->d_gtile = nullptr; h->gtile_bytes = 0; }
   if (h->d_rep_tmp) { (void)hipFree(h->d_rep_tmp); h->d_rep_tmp = nullptr; h->rep_tmp_bytes = 0; }
@@ -644,6 +644,13 @@ int tsem_layout_info(tsem_ctx* h, int64_t* info) {
   info[28] = h->lq_lin;                                    // ... and log Q is (code / max) * scale itself: no table (code entries, the reference's score table)
   info[27] = h->lq_n;                                      // entries of the log Q table of the lnl passes (0: not built yet / does not fit / does not apply)
   info[23] = h->lnl3 ? 1 : 0;                              // the layout lets the EM pass carry the previous iteration's log-likelihood (option "use_likelihood")
+  // rows whose sum the report / row passes redid in the reference's order of additions since the matrix was loaded (near-ties of two z
+  // values or of a z value and conf_prob: tsem_report.hip, tsem_npsum.h)
+  info[31] = 0;
+  if (h->d_exact_n && hipSetDevice(h->device) == hipSuccess) {
+    unsigned long long m = 0;
+    if (hipMemcpyAsync(&m, h->d_exact_n, 8, hipMemcpyDeviceToHost, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess) info[31] = (int64_t)m;
+  }
   return TSEM_OK;
 }
 

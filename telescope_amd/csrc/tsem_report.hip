@@ -5,6 +5,41 @@
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
+#include "tsem_npsum.h"
+
+// ---- near-ties: rows whose integer outputs hang on the last bits of 1 / rowsum ---------------------------------------------------
+// The masks compare z_j = fl(n_j r), r = fl(1 / rowsum), with each other (`==`, sparse_plus.py:125) and with conf_prob (`>=`,
+// model.py:851).  The kernels below add a row's numerators in another order than scipy does (np.add.reduceat: tsem_npsum.h), so their
+// r may differ from the reference's in its last bits.  That can change a mask only where two DIFFERENT numerators lie within a few
+// ulp of each other at the row's maximum, or a z value lies that close to the threshold: with every other numerator more than
+// `band` below the largest one, the best hits are the entries EQUAL to it whatever the last bits of r are.  Rows inside the band — a
+// handful per matrix, none on most — get their sum in scipy's order from ONE lane (np_row_sum) and are counted (tsem_layout_info[31]).
+// The band covers the distance between any two orders of adding up to `len` positive terms (2 len 2^-53) with room to spare.
+constexpr double TS_NEAR_BAND = 0x1p-42;
+__device__ __forceinline__ double near_band(int64_t len) { return fmax(TS_NEAR_BAND, (double)len * 0x1p-50); }
+// the m terms of z's pattern in a row — every stored entry (`all`, the initial z) or the non-zero products (model.py:713-714 drops
+// exact zeros before the sum) — added like np.add.reduceat adds them.  Term of the row's k-th stored entry: lut[raw[s + k]], times
+// tab[column] unless tab is null (the initial z); the column is a CSR column id (col32) or a popularity id + toff (col16).
+// NOT inlined: one lane runs it for a handful of rows, and its accumulators and stack must stay out of the row kernels' registers
+// (inlined, k_rowpass went from 49 to 128 VGPRs + 1.5 KB of scratch).
+struct NpRow {
+  const double* lut; const uint16_t* raw; const int32_t* col32; const uint16_t* col16; const double* tab; uint32_t toff; int64_t s;
+};
+__device__ double np_row_sum(const NpRow& a, int64_t m, bool all) {
+  struct Cur {
+    const NpRow& a; int64_t k; bool all;
+    __device__ double operator()() {
+      for (;;) {
+        const int64_t e = a.s + k++;
+        double v = a.lut[a.raw[e]];
+        if (a.tab) v = v * a.tab[a.col32 ? (uint32_t)a.col32[e] : (uint32_t)a.col16[e] + a.toff];
+        if (all || v != 0.0) return v;
+      }
+    }
+  };
+  Cur c{a, 0, all};
+  return m > 0 ? np_reduceat_sum(c, m) : 0.0;
+}
 
 // ============================================================================
 // CSR row passes: z export, best-hit counts, reassign (model.py:808-865)
@@ -55,11 +90,18 @@ struct RowPassArgs {
   // workgroup and flushed once (global fp64 atomics: 22 G/s, 2 G/s on a popular column)
   const uint32_t* colmap; const int32_t* col_of_pc; int P, Kp, Hs;
   double* colsums_lo = nullptr;   // option "reproducible": the low pieces of every value (same shape as colsums; no LDS slots then)
+  unsigned long long* exact_n = nullptr;   // counts the rows redone in the reference's order of additions (near-ties)
+  // near-ties of a pass (see near_band): the pass proper (FIX = false) sets bit `idx` of flag_bits for a visited row it must not
+  // decide with its own row sum and skips it; the same kernel with FIX = true then visits the flagged rows only, with the sum in the
+  // reference's order.  Two kernels because that sum (one lane, eight accumulators, a stack for long rows) would cost the pass
+  // proper its occupancy: 49 -> 128 VGPRs when it is inlined or called.
+  uint32_t* flag_bits = nullptr;           // [ceil(n_visit / 512) * 16] words
+  unsigned long long* flag_n = nullptr;    // [1] rows flagged by this pass
 };
 
 // METH >= 0 fixes the reassign method at compile time (the per-entry switch and the reductions a method does not
 // need disappear: the pass is bound by instruction issue, ~300 per four rows); METH = -1 reads it from the arguments.
-template <int MODE, int METH = -1>
+template <int MODE, int METH = -1, bool FIX = false>
 __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
   const int method = METH >= 0 ? METH : A.method;
   extern __shared__ double rp_lds[];                       // [lut_len] score table | [P][Hs] hot slots (REASSIGN with A.Hs > 0)
@@ -76,7 +118,18 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
   __syncthreads();
   const bool listed = (MODE == RP_REASSIGN || MODE == RP_EXPORT_Z) && A.rowlist;
   const int64_t n_visit = listed ? A.nlist : A.N;
-  for (int64_t idx = (int64_t)blockIdx.x * subs + sub; idx < n_visit; idx += (int64_t)gridDim.x * subs) {
+  // FIX: the outer loop walks the flag words, 16 per group and step (one per lane), the inner loops their set bits
+  const int64_t n_outer = FIX ? ((*A.flag_n != 0ull) ? (n_visit + 511) / 512 : 0) : n_visit;
+  for (int64_t o = (int64_t)blockIdx.x * subs + sub; o < n_outer; o += (int64_t)gridDim.x * subs) {
+   const uint32_t my_word = FIX ? A.flag_bits[o * 16 + lane] : 0u;
+   uint32_t lanes = FIX ? (uint32_t)((__ballot(my_word != 0u) >> ((threadIdx.x & 63) / RP_SUB * RP_SUB)) & 0xFFFFull) : 1u;
+   while (lanes) {
+    const int wl = __ffs((int)lanes) - 1;
+    lanes &= lanes - 1u;
+    uint32_t bits = FIX ? (uint32_t)__shfl((int)my_word, wl, RP_SUB) : 1u;
+   while (bits) {
+    const int64_t idx = FIX ? (o * 16 + wl) * 32 + (__ffs((int)bits) - 1) : o;
+    bits &= bits - 1u;
     const int64_t row = listed ? (int64_t)A.rowlist[idx] : idx;
     const int64_t s = A.indptr[row], e = A.indptr[row + 1];
     const int64_t zo = (listed && A.out_off) ? A.out_off[idx] - s : 0;      // where entry k of this row goes in zout: k + zo
@@ -113,12 +166,39 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       }
       // same summation order as the long-row path below: lane-strided partial sums, then across lanes
       const double rs = recip0(sg_sum<RP_SUB>(((n[0] + n[1]) + n[2]) + n[3]));
-      const double r = A.zin ? 1.0 : rs;                    // the caller's z is used as is (model.py:837)
-      double zmax = -1.0; int cnt = 0;
+      double r = A.zin ? 1.0 : rs;                          // the caller's z is used as is (model.py:837)
+      int cnt = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) if (inp[i]) { zmax = fmax(zmax, n[i] * r); ++cnt; }
-      zmax = sg_max<RP_SUB>(zmax);
+      for (int i = 0; i < 4; ++i) cnt += inp[i] ? 1 : 0;
       cnt = sg_sum_i<RP_SUB>(cnt);
+      if (FIX) {                                            // a near-tie: the row sum in the reference's order (see near_band)
+        double ex = 0.0;
+        if (lane == 0) {
+          const NpRow nr{A.lut, A.raw, A.indices, nullptr, initial ? nullptr : (amb ? A.cnat : A.pi), 0u, s};
+          ex = np_row_sum(nr, cnt, initial);
+          if (A.exact_n) atomicAdd(A.exact_n, 1ull);
+        }
+        r = recip0(__shfl(ex, 0, RP_SUB));
+      } else if (MODE != RP_EXPORT_Z && !A.zin && A.flag_bits) {   // is it one?  Then it is left to the FIX launch
+        double nmx = -1.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (inp[i]) nmx = fmax(nmx, n[i]);
+        nmx = sg_max<RP_SUB>(nmx);
+        const bool uses_thresh = MODE == RP_REPORT || method == TSEM_RA_CONF;
+        const double lo = nmx * (1.0 - TS_NEAR_BAND), tb = A.thresh * TS_NEAR_BAND;
+        int nf = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (inp[i] && ((n[i] >= lo && n[i] != nmx) || (uses_thresh && fabs(n[i] * r - A.thresh) <= tb))) nf = 1;
+        if (sg_max_i<RP_SUB>(nf)) {
+          if (lane == 0) { atomicOr(&A.flag_bits[idx >> 5], 1u << (idx & 31)); atomicAdd(A.flag_n, 1ull); }
+          continue;
+        }
+      }
+      double zmax = -1.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (inp[i]) zmax = fmax(zmax, n[i] * r);
+      zmax = sg_max<RP_SUB>(zmax);
       if (MODE == RP_EXPORT_Z) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (vld[i]) A.zout[s + lane + i * RP_SUB + zo] = inp[i] ? n[i] * r : -1.0;
@@ -186,21 +266,47 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
       }
       continue;
     }
-    // sweep 1: row sum
-    double y = 0.0;
-    for (int64_t k = s + lane; k < e; k += RP_SUB) { const double v = numer(k); y += (A.zin && isnan(v)) ? 0.0 : v; }
+    // sweep 1: row sum (and the largest numerator of z's pattern)
+    double y = 0.0, nmx = -1.0;
+    int cnt = 0;
+    for (int64_t k = s + lane; k < e; k += RP_SUB) {
+      const double v = numer(k);
+      y += (A.zin && isnan(v)) ? 0.0 : v;
+      if (A.zin ? !isnan(v) : (initial || v != 0.0)) { nmx = fmax(nmx, v); ++cnt; }
+    }
     y = sg_sum<RP_SUB>(y);
-    const double r = A.zin ? 1.0 : recip0(y);
+    nmx = sg_max<RP_SUB>(nmx);
+    cnt = sg_sum_i<RP_SUB>(cnt);
+    double r = A.zin ? 1.0 : recip0(y);
+    if (FIX) {                                              // a near-tie: the row sum in the reference's order (see near_band)
+      double ex = 0.0;
+      if (lane == 0) {
+        const NpRow nr{A.lut, A.raw, A.indices, nullptr, initial ? nullptr : (amb ? A.cnat : A.pi), 0u, s};
+        ex = np_row_sum(nr, cnt, initial);
+        if (A.exact_n) atomicAdd(A.exact_n, 1ull);
+      }
+      r = recip0(__shfl(ex, 0, RP_SUB));
+    } else if (MODE != RP_EXPORT_Z && !A.zin && A.flag_bits) {     // is it one?  Then it is left to the FIX launch
+      const bool uses_thresh = MODE == RP_REPORT || method == TSEM_RA_CONF;
+      const double band = near_band(e - s), lo = nmx * (1.0 - band), tb = A.thresh * band;
+      int nf = 0;
+      for (int64_t k = s + lane; k < e; k += RP_SUB) {
+        const double v = numer(k);
+        if ((initial || v != 0.0) && ((v >= lo && v != nmx) || (uses_thresh && fabs(v * r - A.thresh) <= tb))) nf = 1;
+      }
+      if (sg_max_i<RP_SUB>(nf)) {
+        if (lane == 0) { atomicOr(&A.flag_bits[idx >> 5], 1u << (idx & 31)); atomicAdd(A.flag_n, 1ull); }
+        continue;
+      }
+    }
     // sweep 2: row max over z's pattern
     double zmax = -1.0;
-    int cnt = 0;
     for (int64_t k = s + lane; k < e; k += RP_SUB) {
       double n = numer(k);
       bool inpat = A.zin ? !isnan(n) : (initial || (n != 0.0));
-      if (inpat) { zmax = fmax(zmax, n * r); ++cnt; }
+      if (inpat) zmax = fmax(zmax, n * r);
     }
     zmax = sg_max<RP_SUB>(zmax);
-    cnt = sg_sum_i<RP_SUB>(cnt);
     if (MODE == RP_EXPORT_Z) {
       for (int64_t k = s + lane; k < e; k += RP_SUB) {
         double n = numer(k);
@@ -280,6 +386,8 @@ __global__ __launch_bounds__(1024) void k_rowpass(RowPassArgs A) {
         }
       }
     }
+   }
+   }
   }
   if (nhot) {
     __syncthreads();
@@ -330,7 +438,9 @@ struct ReportArgs {
   double *g_conf, *g_n1, *g_n2, *g_avgt;   // [IDN] each, by id
   double *g_conf_lo = nullptr, *g_avgt_lo = nullptr;   // option "reproducible": low pieces (exact_split01); LDS then holds [Hs] more doubles
   int HC, Hs;                          // LDS slots: pi*theta of ids < HC; accumulators of ids < Hs
-  int32_t* defer_rows; unsigned long long* defer_n;   // rows left to k_report_slow
+  int32_t* defer_rows; unsigned long long* defer_n;   // rows left to k_report_slow: too long for the lanes of a row, or (stored as ~row) a near-tie,
+                                                      // whose sum k_report_slow forms in the reference's order of additions (near_band)
+  unsigned long long* exact_n = nullptr;              // counts the latter
   int dbg;                             // timing experiments (wrong results): 1 drop the emits that miss the LDS slots, 2 the row-count stores, 4 the ties
   // per-GROUP sums (GM != 0; the per-barcode count matrix of scTelescope.output_report, model.py:611-625): rows of the groups
   // [g0, g1) add into a tile [g1 - g0][IDN] in HBM, by id — 32-bit counters for `exclude` (GM 1), doubles for `average` (GM 2) and
@@ -495,7 +605,7 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
     }
     return q;
   };
-  auto row_finish = [&](int64_t row, const Ip& p, const Ent& t, const Prep& q) {
+  auto row_finish = [&](int64_t row, const Ip& p, const Ent& t, const Prep& q) -> bool {   // true: a near-tie, left to k_report_slow
     const int k0 = E * gl;
     const double* n = q.n;
     // row sum and the largest numerator of z's pattern (INIT: every stored entry; else the non-zero products, model.py:720)
@@ -513,20 +623,37 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
         const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
         if (in && n[j] * r > 0.0) atomicAdd(&A.t_cnt[p.goff + half(t.id, j)], 1u);
       }
-      return;
+      return false;
     }
     nm = rr_max<G>(nm);
     const bool any = nm >= 0.0;
     const double zmax = any ? nm * r : -1.0;               // = max_j fl(n_j r): rounding is monotone
-    int nbl = 0; uint32_t wid = 0u;
+    // The best hits are the entries EQUAL to the largest numerator — unless another numerator lies within the band below it: then
+    // the last bits of r decide which z values round together, and the row is redone in the reference's order (near_band).  One
+    // butterfly for both counts (a row has at most 256 entries here).
+    const double lo = nm * (1.0 - TS_NEAR_BAND);
+    int nbl = 0, nnl = 0; uint32_t wid = 0u;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
       const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
-      const bool b = in && (n[j] * r == zmax);
+      const bool b = in && n[j] == nm;
       nbl += b ? 1 : 0;
+      nnl += (in && n[j] >= lo) ? 1 : 0;
       wid = b ? half(t.id, j) : wid;
     }
-    const int nb = rr_sum_i<G>(nbl);
+    const int both = rr_sum_i<G>(nbl | (nnl << 16));
+    const int nb = both & 0xFFFF;
+    bool near = (both >> 16) != nb || fabs(zmax - A.thresh) <= A.thresh * TS_NEAR_BAND;
+    if (!one_winner) {                                     // conf_prob <= 0.5: any entry of the row may sit on the threshold
+      int nt = 0;
+#pragma unroll
+      for (int j = 0; j < E; ++j) {
+        const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
+        nt |= (in && fabs(n[j] * r - A.thresh) <= A.thresh * TS_NEAR_BAND) ? 1 : 0;
+      }
+      near = near || rr_max_i<G>(nt) != 0;
+    }
+    if (near) return true;
     const int64_t goff = p.goff;
     if (GM == 0 && gl == 0 && row < A.N && !(A.dbg & 2)) A.nbest[row] = any ? nb : 0;
     if (one_winner) {
@@ -541,7 +668,7 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
 #pragma unroll
           for (int j = 0; j < E; ++j) {
             const bool in = INIT ? (k0 + j < p.len) : (n[j] != 0.0);
-            if (nb > 1 && !(nbl == 1 && nb == 2) && in && n[j] * r == zmax) EM.tie(half(t.id, j), nb, share, goff);
+            if (nb > 1 && !(nbl == 1 && nb == 2) && in && n[j] == nm) EM.tie(half(t.id, j), nb, share, goff);
           }
         }
       }
@@ -564,6 +691,7 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
         if (z == zmax) { if (nb == 1) EM.one(id, goff); else EM.tie(id, nb, share, goff); }
       }
     }
+    return false;
   };
   if (nit > 0) {
     Ip ip0 = load_ip(0), ip1 = load_ip(1);
@@ -580,8 +708,8 @@ __global__ __launch_bounds__(rr_nt(INIT)) void k_report_rows(ReportArgs A) {
       __builtin_amdgcn_sched_barrier(0);
       if (defer) {
         if (gl == 0) A.defer_rows[atomicAdd(A.defer_n, 1ull)] = (int32_t)row;
-      } else {
-        row_finish(row, cur, e0, q);
+      } else if (row_finish(row, cur, e0, q)) {
+        if (gl == 0 && row < A.N) A.defer_rows[atomicAdd(A.defer_n, 1ull)] = ~(int32_t)row;   // a near-tie
       }
       ip0 = ip1; ip1 = ip2; e0 = e1;
     }
@@ -758,29 +886,52 @@ __global__ __launch_bounds__(256) void k_report_slow(ReportArgs A) {
   const int gl = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
   const int64_t nd = (int64_t)*A.defer_n;
   for (int64_t d = (int64_t)blockIdx.x * ngrp + grp; d < nd; d += (int64_t)gridDim.x * ngrp) {
-    const int64_t row = A.defer_rows[d];
+    const int32_t rcode = A.defer_rows[d];                 // ~row: k_report_rows found a near-tie
+    const int64_t row = rcode < 0 ? ~rcode : rcode;
     const int64_t s = A.indptr[row];
     const int len = (int)(A.indptr[row + 1] - s);
     const uint32_t coff = len > 1 ? 0u : (uint32_t)A.IDN;
     const int64_t goff = GM != 0 ? (int64_t)(A.group[row] - A.g0) * A.IDN : 0;   // (only rows of the tile's groups are deferred)
-    auto numer = [&](int k) -> double {
+    auto numer = [&](int64_t k) -> double {
       double x = A.lut[A.raw[s + k]];
       if (!INIT) x = x * A.cnat2[A.rid[s + k] + coff];
       return x;
     };
-    double y = 0.0;
-    for (int k = gl; k < len; k += G) y += numer(k);
-    const double r = recip0(sg_sum<G>(y));
+    double y = 0.0, nmx = -1.0; int cnt = 0;
+    for (int k = gl; k < len; k += G) {
+      const double n = numer(k);
+      y += n;
+      if (INIT || n != 0.0) { nmx = fmax(nmx, n); ++cnt; }
+    }
+    nmx = sg_max<G>(nmx); cnt = sg_sum_i<G>(cnt);
+    double r = recip0(sg_sum<G>(y));
     if (GM == 4) {
       for (int k = gl; k < len; k += G) { const double n = numer(k); if ((INIT || n != 0.0) && n * r > 0.0) atomicAdd(&A.t_cnt[goff + A.rid[s + k]], 1u); }
       continue;
     }
-    double zmax = -1.0, vs = 0.0; int cnt = 0;
+    {                                                       // near-ties (found here or by k_report_rows): the row sum in the reference's order
+      const double band = near_band(len), lo = nmx * (1.0 - band), tb = A.thresh * band;
+      int nf = rcode < 0 ? 1 : 0;
+      for (int k = gl; k < len; k += G) {
+        const double n = numer(k);
+        if ((INIT || n != 0.0) && ((n >= lo && n != nmx) || fabs(n * r - A.thresh) <= tb)) nf = 1;
+      }
+      if (sg_max_i<G>(nf)) {
+        double ex = 0.0;
+        if (gl == 0) {
+          const NpRow nr{A.lut, A.raw, nullptr, A.rid, INIT ? nullptr : A.cnat2, coff, s};
+          ex = np_row_sum(nr, cnt, INIT);
+          if (A.exact_n) atomicAdd(A.exact_n, 1ull);
+        }
+        r = recip0(__shfl(ex, 0, G));
+      }
+    }
+    double zmax = -1.0, vs = 0.0;
     for (int k = gl; k < len; k += G) {
       const double n = numer(k);
-      if (INIT || n != 0.0) { const double z = n * r; zmax = fmax(zmax, z); ++cnt; if (z >= A.thresh) vs += z; }
+      if (INIT || n != 0.0) { const double z = n * r; zmax = fmax(zmax, z); if (z >= A.thresh) vs += z; }
     }
-    zmax = sg_max<G>(zmax); cnt = sg_sum_i<G>(cnt);
+    zmax = sg_max<G>(zmax);
     const double vsum = sg_sum<G>(vs);
     int nb = 0;
     for (int k = gl; k < len; k += G) { const double n = numer(k); if ((INIT || n != 0.0) && n * r == zmax) ++nb; }
@@ -896,6 +1047,25 @@ __global__ void k_hats(int K, const double* __restrict__ ts, const double* __res
   pi_hat[j] = ((pisum0[j] + ts[j]) + pi_pw) / pi_den;
 }
 
+typedef void (*RowKern)(RowPassArgs);
+template <bool FIX> static RowKern rowpass_kern(int mode, int meth) {
+  switch (mode) {
+    case RP_EXPORT_Z: return k_rowpass<RP_EXPORT_Z, -1, false>;
+    case RP_BEST:     return k_rowpass<RP_BEST, -1, FIX>;
+    case RP_REPORT:   return k_rowpass<RP_REPORT, -1, FIX>;
+    default: break;
+  }
+  switch (meth) {
+    case TSEM_RA_EXCLUDE: return k_rowpass<RP_REASSIGN, TSEM_RA_EXCLUDE, FIX>;
+    case TSEM_RA_CHOOSE:  return k_rowpass<RP_REASSIGN, TSEM_RA_CHOOSE, FIX>;
+    case TSEM_RA_AVERAGE: return k_rowpass<RP_REASSIGN, TSEM_RA_AVERAGE, FIX>;
+    case TSEM_RA_CONF:    return k_rowpass<RP_REASSIGN, TSEM_RA_CONF, FIX>;
+    case TSEM_RA_UNIQUE:  return k_rowpass<RP_REASSIGN, TSEM_RA_UNIQUE, FIX>;
+    case TSEM_RA_ALL:     return k_rowpass<RP_REASSIGN, TSEM_RA_ALL, FIX>;
+    default:              return k_rowpass<RP_REASSIGN, -1, FIX>;
+  }
+}
+
 extern "C" {
 
 // ---------------------------------------------------------------------------
@@ -914,8 +1084,73 @@ static int make_cnat(tsem_ctx* h, RowPassArgs& A) {
   return TSEM_OK;
 }
 
+// the counter of rows redone in the reference's order of additions (near-ties), zeroed when it is first needed
+static int exact_counter(tsem_ctx* h, unsigned long long** out) {
+  if (!h->d_exact_n) {
+    TSEM_ALLOC(h->d_exact_n, 1);
+    TSEM_HIP(hipMemsetAsync(h->d_exact_n, 0, sizeof(unsigned long long), h->stream));
+  }
+  *out = h->d_exact_n;
+  return TSEM_OK;
+}
+// The kernels that read the CSR column ids — k_rowpass<*>, k_group_unique, k_mstep_rows, k_lnl_rows — call this right before they are
+// launched; the streaming passes (k_report_rows, k_report_init_codes, k_choose_init_codes, the group tiles) never do, so that a
+// matrix whose ids were dropped (option "drop_csr_indices") stays at 10 B per entry through a report.
+static int with_indices(tsem_ctx* h, RowPassArgs& A) {
+  if (int rc = tsem_ensure_indices(h)) return rc;
+  A.indices = h->d_indices;
+  return TSEM_OK;
+}
+// ... and this afterwards: ids that were rebuilt for one generic pass go again where the option drops them (the passes that need them
+// are the exception on such a matrix: a rebuild is one 6 B-per-entry sweep)
+static void redrop_indices(tsem_ctx* h) {
+  if (h->d_indices && h->d_rid16 && h->d_col_of_id && (h->opt_drop_indices == 1 || (h->opt_drop_indices < 0 && h->nnz >= 4000000000ll))) {
+    (void)hipStreamSynchronize(h->stream);
+    dfree(h->d_indices);
+  }
+}
+
+struct IndicesGuard {                                      // at the top of an entry point: ids this call had to rebuild do not outlive it
+  tsem_ctx* h; bool had;
+  explicit IndicesGuard(tsem_ctx* c) : h(c), had(c && c->d_indices != nullptr) {}
+  ~IndicesGuard() { if (h && !had) redrop_indices(h); }
+};
+
+// One generic row pass = the pass proper + the FIX launch over the rows it flagged as near-ties (RowPassArgs::flag_bits).  `meth`
+// >= 0 picks the instantiation with the reassign method fixed at compile time (-1: read from A.method).  z export and a
+// caller-assigned z decide nothing with a row sum: one launch.
+static int launch_rowpass(tsem_ctx* h, int mode, int meth, int grid, int block, size_t lds, RowPassArgs& A) {
+  const bool listed = (mode == RP_REASSIGN || mode == RP_EXPORT_Z) && A.rowlist;
+  const int64_t n_visit = listed ? A.nlist : A.N;
+  if (n_visit <= 0) return TSEM_OK;
+  const bool fix = mode != RP_EXPORT_Z && !A.zin;
+  A.flag_bits = nullptr; A.flag_n = nullptr;
+  if (fix) {
+    const int64_t words = (n_visit + 511) / 512 * 16;      // (+ 2 words: the counter behind the bits)
+    if (h->flag_words < words || !h->d_flag_bits) {
+      dfree(h->d_flag_bits); h->flag_words = 0;
+      TSEM_ALLOC(h->d_flag_bits, words + 2);
+      h->flag_words = words;
+    }
+    TSEM_HIP(hipMemsetAsync(h->d_flag_bits, 0, sizeof(uint32_t) * (words + 2), h->stream));
+    A.flag_bits = h->d_flag_bits;
+    A.flag_n = reinterpret_cast<unsigned long long*>(h->d_flag_bits + words);
+  }
+  const RowKern k0 = rowpass_kern<false>(mode, meth);
+  if (lds > 48 * 1024) TSEM_HIP(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+  k0<<<grid, block, lds, h->stream>>>(A);
+  TSEM_HIP(hipGetLastError());
+  if (fix) {
+    const RowKern k1 = rowpass_kern<true>(mode, meth);
+    if (lds > 48 * 1024) TSEM_HIP(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+    k1<<<std::min(grid, 128), block, lds, h->stream>>>(A);   // (returns at once when the pass flagged nothing)
+    TSEM_HIP(hipGetLastError());
+  }
+  return TSEM_OK;
+}
+
 static int rowpass_args(tsem_ctx* h, int which, RowPassArgs& A) {
-  if (int rc = tsem_ensure_indices(h)) return rc;          // (the generic row passes read the CSR column ids)
+  if (int rc = exact_counter(h, &A.exact_n)) return rc;
   A.N = h->N; A.K = h->K; A.indptr = h->d_indptr; A.indices = h->d_indices; A.raw = h->d_raw; A.lut = h->d_lut;
   A.method = 0; A.thresh = 0; A.picks = nullptr; A.zout = nullptr; A.nbest = nullptr; A.colsums = nullptr; A.group = nullptr; A.rowlist = nullptr; A.nlist = 0; A.colmap = nullptr; A.col_of_pc = nullptr; A.P = 0; A.Kp = 0; A.Hs = 0;
   A.zin = nullptr; A.cnat = nullptr; A.lut_len = h->lut_len <= 2048 ? h->lut_len : 0;   // (larger tables stay in global memory)
@@ -939,8 +1174,8 @@ static int export_z_with(tsem_ctx* h, RowPassArgs& A, double* z) {
   TSEM_SCOPED(d_z);
   TSEM_ALLOC(d_z, h->nnz);
   A.zout = d_z;
-  if (h->N) k_rowpass<RP_EXPORT_Z><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
-  TSEM_HIP(hipGetLastError());
+  if (int rc = with_indices(h, A)) return rc;
+  if (int rc = launch_rowpass(h, RP_EXPORT_Z, -1, tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, A)) return rc;
   if (h->nnz) TSEM_HIP(hipMemcpyAsync(z, d_z, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
   return TSEM_OK;
@@ -949,6 +1184,7 @@ static int export_z_with(tsem_ctx* h, RowPassArgs& A, double* z) {
 int tsem_export_z(tsem_ctx* h, int which, double* z) {
   if (!h || !h->d_indptr || !z) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
+  IndicesGuard ig(h);
   RowPassArgs A;
   if (int rc = rowpass_args(h, which, A)) return rc;
   return export_z_with(h, A, z);
@@ -968,6 +1204,7 @@ int tsem_estep(tsem_ctx* h, const double* pi, const double* theta, double* z) {
   if (int rc = ensure_device(h)) return rc;
   TSEM_HIP(hipMemcpyAsync(h->d_tmp_pi, pi, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
   TSEM_HIP(hipMemcpyAsync(h->d_tmp_theta, theta, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
+  IndicesGuard ig(h);
   RowPassArgs A;
   if (int rc = rowpass_args(h, TSEM_Z_CUR, A)) return rc;
   A.pi = h->d_tmp_pi; A.theta = h->d_tmp_theta;
@@ -984,8 +1221,9 @@ int tsem_best_counts(tsem_ctx* h, int which, int32_t* nbest) {
   TSEM_SCOPED(d_nb);
   TSEM_ALLOC(d_nb, h->N);
   A.nbest = d_nb;
-  if (h->N) k_rowpass<RP_BEST><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
-  TSEM_HIP(hipGetLastError());
+  IndicesGuard ig(h);
+  if (int rc = with_indices(h, A)) return rc;
+  if (int rc = launch_rowpass(h, RP_BEST, -1, tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, A)) return rc;
   if (h->N) TSEM_HIP(hipMemcpyAsync(nbest, d_nb, sizeof(int32_t) * h->N, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
   return TSEM_OK;
@@ -1013,8 +1251,9 @@ int tsem_best_ties(tsem_ctx* h, int which, int64_t cap, int32_t* rows, int32_t* 
   TSEM_SCOPED(d_nb); TSEM_SCOPED(d_rows); TSEM_SCOPED(d_cnt); TSEM_SCOPED(d_n); TSEM_SCOPED(tmp);
   TSEM_ALLOC(d_nb, h->N); TSEM_ALLOC(d_rows, h->N); TSEM_ALLOC(d_n, 1);
   A.nbest = d_nb;
-  k_rowpass<RP_BEST><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
-  TSEM_HIP(hipGetLastError());
+  IndicesGuard ig(h);
+  if (int rc = with_indices(h, A)) return rc;
+  if (int rc = launch_rowpass(h, RP_BEST, -1, tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, A)) return rc;
   size_t tb = 0;
   TiedRow pred{d_nb};
   rocprim::counting_iterator<int32_t> first(0);
@@ -1089,6 +1328,8 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
     }
   }
   A.method = method; A.thresh = thresh;
+  IndicesGuard ig(h);
+  if (int rc = with_indices(h, A)) return rc;
   double *d_cs = nullptr, *d_mask = nullptr;
   int32_t* d_picks = nullptr;
   TSEM_SCOPED(d_cs); TSEM_SCOPED(d_mask); TSEM_SCOPED(d_picks);
@@ -1111,22 +1352,10 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
     const int wgs = (method == TSEM_RA_ALL || h->opt_rowpass_wgs < 2) ? 1 : 2;
     A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;
     A.Hs = std::max(0, std::min(h->Kp, (int)((TS_LDS_MAX / wgs - 8192 / wgs - 1024 - A.lut_len * 8) / 8 / h->P)));
-    TSEM_HIP(hipFuncSetAttribute((const void*)k_rowpass<RP_REASSIGN>, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
-    void (*kern)(RowPassArgs) = k_rowpass<RP_REASSIGN>;
-    switch (method) {
-      case TSEM_RA_EXCLUDE: kern = k_rowpass<RP_REASSIGN, TSEM_RA_EXCLUDE>; break;
-      case TSEM_RA_CHOOSE:  kern = k_rowpass<RP_REASSIGN, TSEM_RA_CHOOSE>; break;
-      case TSEM_RA_AVERAGE: kern = k_rowpass<RP_REASSIGN, TSEM_RA_AVERAGE>; break;
-      case TSEM_RA_CONF:    kern = k_rowpass<RP_REASSIGN, TSEM_RA_CONF>; break;
-      case TSEM_RA_UNIQUE:  kern = k_rowpass<RP_REASSIGN, TSEM_RA_UNIQUE>; break;
-      case TSEM_RA_ALL:     kern = k_rowpass<RP_REASSIGN, TSEM_RA_ALL>; break;
-    }
-    TSEM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
-    kern<<<h->n_cu * wgs, 1024, (size_t)(A.P * A.Hs + A.lut_len) * 8, h->stream>>>(A);
+    if (int rc = launch_rowpass(h, RP_REASSIGN, method, h->n_cu * wgs, 1024, (size_t)(A.P * A.Hs + A.lut_len) * 8, A)) return rc;
   } else if (h->N) {
-    k_rowpass<RP_REASSIGN><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
+    if (int rc = launch_rowpass(h, RP_REASSIGN, -1, tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, A)) return rc;
   }
-  TSEM_HIP(hipGetLastError());
   if (int rc = rowpass_lo_end(h, d_cs, d_lo, h->K)) return rc;
   TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
   if (mask && h->nnz) TSEM_HIP(hipMemcpyAsync(mask, d_mask, sizeof(double) * h->nnz, hipMemcpyDeviceToHost, h->stream));
@@ -1141,6 +1370,7 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
   if (int rc = ensure_device(h)) return rc;
   const bool want_conf = !(thresh < 0.0);                  // thresh < 0: no `conf` column wanted (its third of out3K stays 0)
   if (!want_conf) thresh = 0.9;                            // (what the paths that compute it anyway use)
+  IndicesGuard ig(h);
   RowPassArgs A;
   if (int rc = rowpass_args(h, which, A)) return rc;
   dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;
@@ -1157,14 +1387,13 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
     int32_t *const d_nb = h->d_rep_nb, *const d_rows = h->d_rep_rows;
     unsigned long long* const d_n = h->d_rep_n;
     A.thresh = thresh; A.colsums = d_cs; A.nbest = d_nb;
-    void (*kern)(RowPassArgs) = k_rowpass<RP_REPORT>;
     if (h->opt_report_kernel != 0 && which != TSEM_Z_USER && h->d_rid16 && h->d_col_of_id && A.lut_len > 0) {
       // the streaming report kernel (k_report_rows): lanes per row x entries per lane = the smallest capacity that
       // fewer than 0.5 % of the rows exceed (row-length histogram of tsem_rowstats); the rest goes to k_report_slow
       const int IDN = h->Kpad;
       ReportArgs R;
       R.N = h->N; R.nnz = h->nnz; R.K = K; R.IDN = IDN; R.indptr = h->d_indptr; R.rid = h->d_rid16; R.raw = h->d_raw;
-      R.lut = h->d_lut; R.lut_len = A.lut_len; R.cnat2 = nullptr; R.thresh = thresh; R.nbest = d_nb;
+      R.lut = h->d_lut; R.lut_len = A.lut_len; R.cnat2 = nullptr; R.thresh = thresh; R.nbest = d_nb; R.exact_n = A.exact_n;
       const bool init = A.pi == nullptr;
       // thresh < 0: the caller wants no `conf` column.  The initial z then needs no arithmetic at all — the best hits of a row are its
       // largest score codes (k_report_init_codes) — provided the score table is strictly increasing and no stored score is 0.
@@ -1223,22 +1452,21 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       TSEM_HIP(hipGetLastError());
       TSEM_HIP(hipStreamSynchronize(h->stream));
     } else if (h->d_colmap && h->d_col_of_pc && h->P > 0) {
+      if (int rc = with_indices(h, A)) return rc;
       const int wgs = h->opt_rowpass_wgs < 2 ? 1 : 2;
       A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;
       A.Hs = std::max(0, std::min(h->Kp, (int)((TS_LDS_MAX / wgs - 8192 / wgs - 1024 - A.lut_len * 8) / 8 / h->P / 3)));
-      TSEM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
       double* d_lo = nullptr;
       TSEM_SCOPED(d_lo);                                    // (the low pieces of the exact sums: freed on every return path)
       if (int rc = rowpass_lo_begin(h, A, 3 * (int64_t)K, &d_lo)) return rc;
-      kern<<<h->n_cu * wgs, 1024, (size_t)(3 * A.P * A.Hs + A.lut_len) * 8, h->stream>>>(A);
-      TSEM_HIP(hipGetLastError());
+      if (int rc = launch_rowpass(h, RP_REPORT, -1, h->n_cu * wgs, 1024, (size_t)(3 * A.P * A.Hs + A.lut_len) * 8, A)) return rc;
       if (int rc = rowpass_lo_end(h, d_cs, d_lo, 3 * (int64_t)K)) return rc;
     } else {
+      if (int rc = with_indices(h, A)) return rc;
       double* d_lo = nullptr;
       TSEM_SCOPED(d_lo);                                    // (the low pieces of the exact sums: freed on every return path)
       if (int rc = rowpass_lo_begin(h, A, 3 * (int64_t)K, &d_lo)) return rc;
-      kern<<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
-      TSEM_HIP(hipGetLastError());
+      if (int rc = launch_rowpass(h, RP_REPORT, -1, tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, A)) return rc;
       if (int rc = rowpass_lo_end(h, d_cs, d_lo, 3 * (int64_t)K)) return rc;
     }
     TSEM_HIP(hipGetLastError());
@@ -1333,12 +1561,13 @@ int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const 
   if (int rc = rowpass_args(h, which, A)) return rc;
   A.method = method; A.thresh = thresh; A.colsums = d_cs; A.picks = d_picks;
   A.rowlist = rows ? d_rows : h->d_tie_rows; A.nlist = n;
+  IndicesGuard ig(h);
+  if (int rc = with_indices(h, A)) return rc;
   const int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + 15) / 16));
   double* d_lo = nullptr;
   TSEM_SCOPED(d_lo);                                    // (the low pieces of the exact sums: freed on every return path)
   if (int rc = rowpass_lo_begin(h, A, h->K, &d_lo)) return rc;
-  k_rowpass<RP_REASSIGN><<<grid, 256, (size_t)A.lut_len * 8, h->stream>>>(A);
-  TSEM_HIP(hipGetLastError());
+  if (int rc = launch_rowpass(h, RP_REASSIGN, -1, grid, 256, (size_t)A.lut_len * 8, A)) return rc;
   if (int rc = rowpass_lo_end(h, d_cs, d_lo, h->K)) return rc;
   TSEM_HIP(hipMemcpyAsync(colsums, d_cs, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
@@ -1380,19 +1609,19 @@ int tsem_rows_lookup(tsem_ctx* h, int which, int method, double thresh, int64_t 
     TSEM_HIP(hipMemcpyAsync(d_picks, picks, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
   }
   A.rowlist = d_rows; A.nlist = n; A.out_off = d_off;
+  IndicesGuard ig(h);
+  if (int rc = with_indices(h, A)) return rc;
   const int grid = (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + 15) / 16));
   if (z_out) {
     TSEM_ALLOC(d_z, total);
     A.zout = d_z;
-    k_rowpass<RP_EXPORT_Z><<<grid, 256, (size_t)A.lut_len * 8, h->stream>>>(A);
-    TSEM_HIP(hipGetLastError());
+    if (int rc = launch_rowpass(h, RP_EXPORT_Z, -1, grid, 256, (size_t)A.lut_len * 8, A)) return rc;
     if (total) TSEM_HIP(hipMemcpyAsync(z_out, d_z, sizeof(double) * total, hipMemcpyDeviceToHost, h->stream));
   }
   if (mask_out) {
     TSEM_ALLOC(d_m, total);
     A.zout = d_m; A.method = method; A.thresh = thresh; A.picks = d_picks; A.colsums = nullptr;
-    k_rowpass<RP_REASSIGN><<<grid, 256, (size_t)A.lut_len * 8, h->stream>>>(A);
-    TSEM_HIP(hipGetLastError());
+    if (int rc = launch_rowpass(h, RP_REASSIGN, -1, grid, 256, (size_t)A.lut_len * 8, A)) return rc;
     if (total) TSEM_HIP(hipMemcpyAsync(mask_out, d_m, sizeof(double) * total, hipMemcpyDeviceToHost, h->stream));
   }
   TSEM_HIP(hipStreamSynchronize(h->stream));
@@ -1436,6 +1665,7 @@ int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, cons
   if (int rc = ensure_device(h)) return rc;
   if (group_of_row) { if (int rc = tsem_set_groups(h, group_of_row, n_groups)) return rc; }
   else if (!h->d_group || h->n_groups != n_groups) TSEM_FAIL(TSEM_ERR_ARG, "tsem_reassign_groups: no group map (tsem_set_groups) for this number of groups");
+  IndicesGuard ig(h);
   RowPassArgs A;
   if (int rc = rowpass_args(h, which, A)) return rc;
   A.method = method; A.thresh = thresh;
@@ -1471,7 +1701,7 @@ int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, cons
   if (stream_ok) {
     R.N = h->N; R.nnz = h->nnz; R.K = K; R.IDN = IDN; R.indptr = h->d_indptr; R.rid = h->d_rid16; R.raw = h->d_raw;
     R.lut = h->d_lut; R.lut_len = A.lut_len; R.cnat2 = nullptr; R.thresh = method == TSEM_RA_CONF ? thresh : 0.9; R.nbest = nullptr;
-    R.g_conf = R.g_n1 = R.g_n2 = R.g_avgt = nullptr; R.dbg = 0;
+    R.g_conf = R.g_n1 = R.g_n2 = R.g_avgt = nullptr; R.dbg = 0; R.exact_n = A.exact_n;
     if (!init) {
       TSEM_TMP(t_c2, sizeof(double) * 2 * IDN);
       k_cnat2_id<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, h->d_col_of_id, A.pi, A.theta, t_c2.as<double>());
@@ -1520,13 +1750,14 @@ int tsem_reassign_groups(tsem_ctx* h, int method, double thresh, int which, cons
       k_group_finish<<<cdiv64(n_id, 256), 256, 0, h->stream>>>(n_id, IDN, K, h->d_col_of_id, R.t_cnt, R.t_val, d_out);
       TSEM_HIP(hipGetLastError());
     } else if (h->N && method == TSEM_RA_UNIQUE && which != TSEM_Z_USER && !h->opt_reproducible) {
+      if (int rc = with_indices(h, A)) return rc;
       k_group_unique<<<cdiv64(h->N, 256), 256, 0, h->stream>>>(h->N, h->d_indptr, h->d_indices, h->d_raw, h->d_lut, A.pi, h->d_group, g0, g1, K, d_out);
       TSEM_HIP(hipGetLastError());
     } else if (h->N) {
+      if (int rc = with_indices(h, A)) return rc;
       A.colsums = d_out; A.picks = t_picks.as<int32_t>(); A.group = h->d_group; A.g0 = g0; A.g1 = g1;
       if (t_lo.p) { TSEM_HIP(hipMemsetAsync(t_lo.p, 0, sizeof(double) * n_out, h->stream)); A.colsums_lo = t_lo.as<double>(); }
-      k_rowpass<RP_REASSIGN><<<tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, h->stream>>>(A);
-      TSEM_HIP(hipGetLastError());
+      if (int rc = launch_rowpass(h, RP_REASSIGN, -1, tsem_rowpass_grid(h), 256, (size_t)A.lut_len * 8, A)) return rc;
       if (t_lo.p) { k_add_lo<<<cdiv64(n_out, 256), 256, 0, h->stream>>>(n_out, d_out, t_lo.as<double>()); TSEM_HIP(hipGetLastError()); }
     }
     TSEM_HIP(hipMemcpyAsync(out + (int64_t)g0 * K, d_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
@@ -1547,6 +1778,8 @@ int tsem_mstep(tsem_ctx* h, const double* z, double* pi_hat, double* theta_hat) 
   if (h->nnz) TSEM_HIP(hipMemcpyAsync(d_z, z, sizeof(double) * h->nnz, hipMemcpyHostToDevice, h->stream));
   TSEM_HIP(hipMemsetAsync(d_cs, 0, sizeof(double) * h->K, h->stream));
   A.colsums = d_cs;
+  IndicesGuard ig(h);
+  if (int rc = with_indices(h, A)) return rc;
   if (h->N) k_mstep_rows<<<tsem_rowpass_grid(h), 256, 0, h->stream>>>(A, d_z);
   if (tsem_comm_on(h)) {                                         // row-sharded: thetasum over all ranks (model.py:731)
     if (int rc = tsem_comm_allreduce_dev(h->comm, d_cs, (size_t)h->K, 0, h->stream, h->err)) return rc;
@@ -1573,6 +1806,8 @@ int tsem_calc_lnl(tsem_ctx* h, const double* z, const double* pi, const double* 
   TSEM_HIP(hipMemcpyAsync(h->d_tmp_pi, pi, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
   TSEM_HIP(hipMemcpyAsync(h->d_tmp_theta, theta, sizeof(double) * h->K, hipMemcpyHostToDevice, h->stream));
   A.pi = h->d_tmp_pi; A.theta = h->d_tmp_theta;
+  IndicesGuard ig(h);
+  if (int rc = with_indices(h, A)) return rc;
   int grid = std::min(4096, tsem_rowpass_grid(h));
   if (h->N) k_lnl_rows<<<grid, 256, 0, h->stream>>>(A, d_z, h->d_lnl_part);
   if (int rc = tsem_sum_parts(h, h->d_lnl_part, h->N ? grid : 0, h->d_lnl_part, 0, h->d_lnl_part + 8000)) return rc;

@@ -702,9 +702,11 @@ def test_report_pass_on_the_layouts_the_row_pass_branches_on(gpu_device):
 
 
 def test_torch_transport_fallback(gpu_device):
-    """If the library's RCCL communicator cannot be created, Comm falls back to torch.distributed collectives on the
-    engine's reduce buffer (one host round trip per iteration).  Forced here with TSEM_TORCH_COLLECTIVES=1 in a
-    1-rank group of its own process: same iteration count, parameters and integer report columns as the goldens."""
+    """If the library's RCCL communicator cannot be created, the run ends with the library's message (EngineError on every rank)
+    unless the caller opted in with TSEM_ALLOW_TORCH_COLLECTIVES=1; then Comm uses torch.distributed collectives on the engine's
+    reduce buffer (one host round trip per iteration).  The failure is made on purpose with TSEM_TORCH_COLLECTIVES=1 in a 1-rank
+    group of its own process: first the default (raises), then the opt-in — same iteration count, parameters and integer report
+    columns as the goldens."""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -716,6 +718,13 @@ def test_torch_transport_fallback(gpu_device):
         from conftest import Opts, case_matrix, load_case
         from telescope_amd.distributed import init_from_env
         from telescope_amd.likelihood import TelescopeLikelihood
+        from telescope_amd._lib import EngineError
+        try:
+            init_from_env(force=True)
+            raise SystemExit('the default must not fall back by itself')
+        except EngineError as e:
+            assert 'TSEM_ALLOW_TORCH_COLLECTIVES' in str(e) and 'TSEM_TORCH_COLLECTIVES=1' in str(e), str(e)
+        os.environ['TSEM_ALLOW_TORCH_COLLECTIVES'] = '1'
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter('always')
             comm = init_from_env(force=True)

@@ -387,25 +387,15 @@ def test_initial_report_pass_with_a_stored_zero_score_takes_the_full_kernel(gpu_
     assert np.allclose(fast['average'], gen['average'], rtol=1e-12, atol=1e-9)
 
 
-def _soak_case(fn, seed, tries=3):
-    """One case of tests/fuzz_reports.py.  The integer columns of the FINAL z hang on exact ties between z values: the
-    engine's parameters differ in their last bits from run to run (atomics), and once in ~1 000 cases of these adversarial matrices two
-    z values one ulp apart round together under scipy's row-sum order and not under the kernel's, or the other way round.  A defect
-    fails every time; such a flip does not survive a rerun with freshly rounded parameters — hence up to `tries` runs."""
-    last = None
-    for _ in range(tries):
-        try:
-            res = fn(seed)
-        except AssertionError as e:
-            last = e
-            continue
-        assert res.startswith('ok') or res.startswith('skipped'), res
-        return
-    raise last
+def _soak_case(fn, seed):
+    """One case of tests/fuzz_reports.py, ONE attempt (round 5 retried up to three times around near-ties of the final z; since round 6
+    the report and row passes redo such rows in the reference's order of additions — DESIGN 8.8 — and nothing is retried)."""
+    res = fn(seed)
+    assert res.startswith('ok') or res.startswith('skipped'), res
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('seed', [3, 10, 41, 85, 145, 146, 212, 301])
+@pytest.mark.parametrize('seed', [3, 10, 41, 85, 145, 146, 212, 301, 502])
 def test_reassign_column_sums_of_random_matrices_against_the_oracle(gpu_device, seed):
     """A slice of tests/fuzz_reports.py (the soak ran 400 seeds: profiles/r05_fuzz_reports.txt): a random small matrix through em()
     and all twelve reassign column sums — six methods x initial / final z, in random order with random thresholds, so that the report

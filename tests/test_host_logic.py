@@ -198,3 +198,47 @@ def test_family_distribution_keeps_a_row_inside_one_family():
             fam_rows[int(f[0])] = fam_rows.get(int(f[0]), 0) + 1
     assert len(fam_rows) == (3000 - 1) // synthetic.FAMILY and fam_rows[0] > 3 * fam_rows[max(fam_rows)]
     assert rw.min() >= 139 and rw.max() <= 300
+
+
+def test_row_sum_restatement_is_numpys_reduceat(tmp_path):
+    """telescope_amd/csrc/tsem_npsum.h restates the order of additions of np.add.reduceat (what scipy's CSR `sum(axis=1)` is, hence
+    what sparse_plus.py:51 normalises z by): a0 + pairwise(a1 ..).  The header has no HIP dependency: compiled here with g++ and checked
+    bit for bit against numpy and against scipy on random rows of 1 .. 5000 terms (the device runs the same code for near-tie rows)."""
+    import ctypes
+    import subprocess
+    import scipy.sparse as sp
+    src = tmp_path / 'h.cpp'
+    src.write_text('#include "tsem_npsum.h"\n'
+                   'struct Cur { const double* p; double operator()() { return *p++; } };\n'
+                   'extern "C" double nps(const double* a, long m) { Cur c{a}; return np_reduceat_sum(c, m); }\n')
+    so = tmp_path / 'libnps.so'
+    subprocess.run(['g++', '-O2', '-ffp-contract=off', '-shared', '-fPIC', '-I' + os.path.join(ROOT, 'telescope_amd', 'csrc'),
+                    str(src), '-o', str(so)], check=True)
+    L = ctypes.CDLL(str(so))
+    L.nps.restype = ctypes.c_double
+    L.nps.argtypes = [np.ctypeslib.ndpointer(np.float64), ctypes.c_long]
+    rng = np.random.RandomState(1)
+    for t in range(4000):
+        m = int(rng.choice([1, 2, 3, 5, 8, 9, 10, 16, 17, 40, 100, 129, 130, 137, 200, 257, 300, 1000, 5000, rng.randint(1, 3000)]))
+        a = rng.rand(m) * 10.0 ** rng.randint(-3, 3, m)
+        assert L.nps(a, m) == np.add.reduceat(a, [0])[0], m
+    lens = rng.randint(1, 400, 500)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    data = rng.rand(indptr[-1])
+    M = sp.csr_matrix((data, np.concatenate([np.arange(l) for l in lens]), indptr), shape=(500, 400))
+    s = np.asarray(M.sum(1)).ravel()
+    assert all(L.nps(data[indptr[i]:indptr[i + 1]].copy(), int(lens[i])) == s[i] for i in range(500))
+
+
+def test_the_torch_transport_is_opt_in():
+    """when the in-library RCCL communicator cannot be created the default is to END the run with the library's
+    message on every rank; torch.distributed collectives are taken only with TSEM_ALLOW_TORCH_COLLECTIVES=1 (distributed.py
+    decide_transport; the GPU leg is tests/test_gpu_round2.py test_torch_transport_fallback)."""
+    from telescope_amd.distributed import decide_transport
+    assert decide_transport(False, None, {}) == 'library'
+    with pytest.raises(_lib.EngineError) as e:
+        decide_transport(True, 'ncclCommInitRank did not return within the time limit', {})
+    assert 'ncclCommInitRank did not return' in str(e.value) and 'TSEM_ALLOW_TORCH_COLLECTIVES=1' in str(e.value)
+    assert decide_transport(True, 'x', {'TSEM_ALLOW_TORCH_COLLECTIVES': '1'}) == 'torch'
+    with pytest.raises(_lib.EngineError):
+        decide_transport(True, 'x', {'TSEM_ALLOW_TORCH_COLLECTIVES': '0', 'TSEM_TORCH_COLLECTIVES': '1'})
