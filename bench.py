@@ -53,6 +53,17 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', type=int, default=0, choices=(0, 2, 3, 4, 5),
+                    help='a BASELINE.json configuration by its number (sets --rows / --cols / --nnz-row / --scaling / --value-format): '
+                         '2 = 1M x 30k x ~20 on one GPU; 3 = 10M x 30k x ~40; 4 = 50M x 30k x ~40 row-sharded over --gpus N (strong scaling: '
+                         'the default workload); 5 = 200M x 50k x ~100 over 8 GPUs as 25M rows per rank (weak scaling, score codes: the '
+                         'library default) with the size-independent property checks — at --gpus 1 the half that fits one GPU (100M rows)')
+    ap.add_argument('--config-scale', type=float, default=1.0,
+                    help='with --config: the same configuration at this fraction of its rows (dry runs of the plumbing; the line says so)')
+    ap.add_argument('--properties', action='store_true',
+                    help='after the timed region run the size-independent checks (every rank takes part): pi / theta are distributions, '
+                         '`all` counts every stored entry, exclude + tied rows = all fragments, average sums to the fragments, no fall-back, '
+                         'and the same iterations on the two-pass kernels agree to 1e-10 (implied by --config 5)')
     ap.add_argument('--rows', type=int, default=50_000_000)
     ap.add_argument('--cols', type=int, default=30_000)
     ap.add_argument('--nnz-row', type=float, default=40.0)
@@ -101,7 +112,32 @@ def parse():
                     help='N > 1: skip the N = 1 run of the whole problem on rank 0\'s GPU (speedup_vs_n1, check.matches_n1)')
     ap.add_argument('--force-comm', action='store_true',
                     help='use the multi-rank code path (RCCL group, per-iteration all-reduce) even at world size 1')
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.config_note = None
+    if args.config:
+        n = max(1, args.gpus)
+        sc = args.config_scale
+        if args.config == 2:
+            args.rows, args.cols, args.nnz_row, args.scaling = int(1_000_000 * sc), 30_000, 20.0, 'strong'
+            args.config_note = 'BASELINE config 2 (synthetic 1M fragments x 30k loci, ~20 nnz/row, fp64, 1 GPU)'
+        elif args.config == 3:
+            args.rows, args.cols, args.nnz_row, args.scaling = int(10_000_000 * sc), 30_000, 40.0, 'strong'
+            args.config_note = 'BASELINE config 3 (synthetic 10M fragments x 30k loci, ~40 nnz/row, 1 GPU; the fp32-vs-fp64 sweep is the `precision_sweep` block)'
+        elif args.config == 4:
+            args.rows, args.cols, args.nnz_row, args.scaling = int(50_000_000 * sc), 30_000, 40.0, 'strong'
+            args.config_note = 'BASELINE config 4 (synthetic 50M fragments x 30k loci row-sharded across %d GPU(s), one all-reduce of the column sums per iteration)' % n
+        else:
+            # 200M x 50k x ~100 = 2e10 stored entries over 8 GPUs = 25M rows per rank; fewer ranks keep 25M rows each (weak scaling),
+            # one GPU alone takes the 1e10-entry half that fits it (tests/test_gpu_round5.py test_half_of_config5_on_one_gpu)
+            per_rank = 100_000_000 if n == 1 else 25_000_000
+            args.rows, args.cols, args.nnz_row, args.scaling = int(per_rank * sc), 50_000, 100.0, 'weak'
+            args.value_format = 'auto'
+            args.properties = True
+            args.config_note = ('BASELINE config 5 (pooled single-cell style: 200M fragments x 50k loci, ~100 nnz/row, 8 GPUs) as %d rank(s) x %dM rows%s'
+                                % (n, per_rank // 1_000_000, '' if n == 8 else ' — %s of the configuration' % ('the half that fits one GPU' if n == 1 else '%d / 8' % n)))
+        if sc != 1.0:
+            args.config_note += ' AT %g OF ITS ROWS (a dry run of the plumbing)' % sc
+    return args
 
 
 def cpu_baseline(args, dist_code, cdf):
@@ -379,6 +415,9 @@ def main():
     phases = eng.phase_times(reset=True)
     eng.set_option('phase_timing', 0)
     eng.set_option('kernel_timing', args.kernel_timing)
+    props = None
+    if args.properties:
+        props = properties_leg(tl, eng, comm, total_rows, nnz_total, args)     # collective: every rank
     if rank != 0:
         _shutdown(comm)
         return
@@ -473,10 +512,14 @@ def main():
         'speedup_vs_n1': (n1['ms_per_step'] / (elapsed / args.steps * 1e3)) if (n1 and 'ms_per_step' in n1) else None,
         'timed_call': 'TelescopeLikelihood.em(final_lnl=False): chunks of %d iterations per host synchronisation' % EM_CHUNK,
         'whole_em_call': whole,
+        'properties': props,
         'config': {
-            'workload': 'synthetic %dM fragments x %dk loci, ~%g nnz/row, %s columns, fp64 arithmetic, '
+            'workload': ((args.config_note + ': ') if args.config_note else '') +
+                        'synthetic %s fragments x %dk loci, ~%g nnz/row, %s columns, fp64 arithmetic, '
                         'pi_prior=0 theta_prior=200000, em_epsilon=0 (fixed iterations)'
-                        % (total_rows // 1_000_000, args.cols // 1000, args.nnz_row, args.dist),
+                        % ('%dM' % (total_rows // 1_000_000) if total_rows >= 1_000_000 else '%dk' % (total_rows // 1000),
+                           args.cols // 1000, args.nnz_row, args.dist),
+            'baseline_config': args.config or (4 if _is_default_workload(args, total_rows) else None),
             'rows': total_rows, 'cols': args.cols, 'nnz': nnz_total, 'dist': args.dist, 'seed': args.seed,
             'parallelism': (('row-sharded x%d, 1 in-library RCCL all-reduce(K+2 f64)/iter' % world) if comm.in_library else
                             ('row-sharded x%d, FALL-BACK transport: torch.distributed all-reduce(K+1 f64) + host round trip per iter' % world))
@@ -593,6 +636,65 @@ def main():
     except Exception:   # noqa: BLE001
         pass
     print(json.dumps(out), flush=True)
+
+
+def properties_leg(tl, eng, comm, total_rows, nnz_total, args, iters=4):
+    """Size-independent properties of a run no CPU oracle can follow (BASELINE config 5: 2e10 stored entries) — the checks of
+    tests/test_gpu_round5.py test_half_of_config5_on_one_gpu, collective over the ranks of a row-sharded run.  Every rank calls this;
+    the dictionary (all booleans + the numbers behind them) is the same on every rank."""
+    import logging
+    import math
+
+    def gsum(v):
+        return float(comm.sum_array(np.array([float(v)]))[0]) if comm is not None else float(v)
+
+    def gmax(v):
+        return float(comm.max_array(np.array([float(v)]))[0]) if comm is not None else float(v)
+    p = {}
+    cols = args.cols
+    eng.set_option('kernel_timing', 0)
+    eng.set_params(np.repeat(1. / cols, cols), np.repeat(1. / cols, cols))
+    tl.max_iter, tl.epsilon = iters, 0.0
+    tl.em(loglev=logging.DEBUG)
+    info = eng.layout_info()
+    pi_f, theta_f, lnl_f = tl.pi.copy(), tl.theta.copy(), float(tl.lnl)
+    p['iterations'] = iters
+    p['fallbacks_all_ranks'] = int(gsum(info['fallbacks']))
+    p['fused_kernel_on_every_rank'] = gmax(0 if info['fused'] else 1) == 0
+    p['no_fallback'] = p['fallbacks_all_ranks'] == 0 and (p['fused_kernel_on_every_rank'] or args.one_device)   # (the one-device dry run starts on the two-pass kernels)
+    p['lnl'] = lnl_f
+    p['lnl_finite'] = bool(math.isfinite(lnl_f))
+    p['pi_sum'], p['theta_sum'] = float(pi_f.sum()), float(theta_f.sum())
+    p['parameters_are_distributions'] = bool(abs(pi_f.sum() - 1.0) < 1e-11 and abs(theta_f.sum() - 1.0) < 1e-11 and (pi_f >= 0).all() and (theta_f >= 0).all())
+    mem = eng.device_memory()
+    p['resident_bytes_per_entry_max_rank'] = gmax(sum(mem['resident'].values()) / max(1, eng.dims()[2]))
+    p['all_initial_sum'] = int(tl.reassign_colsums('all', initial=True).sum())
+    p['all_counts_every_entry'] = p['all_initial_sum'] == int(nnz_total)
+    excl = tl.reassign_colsums('exclude')
+    rep = next(iter(tl._report_cache.values()))
+    ties = int(gsum(len(rep['rows'])))
+    empty = int(total_rows - gsum(info['N_amb'] + info['N_uni']))     # fragments without a stored entry (in no mask)
+    p['exclude_sum'], p['tied_rows'] = int(excl.sum()), ties
+    p['exclude_plus_ties_is_every_fragment'] = int(excl.sum()) + ties + empty == int(total_rows)
+    avg = tl.reassign_colsums('average')
+    p['average_sum'] = float(avg.sum())
+    p['average_sums_to_fragments'] = bool(abs(avg.sum() - (total_rows - empty)) < 1e-6 * total_rows)
+    p['near_tie_rows_all_ranks'] = int(gsum(eng.layout_info().get('near_tie_rows', 0)))
+    # the same iterations on the two-pass kernels (the layout is rebuilt with fp64 entries) from the same start
+    try:
+        eng.fallback_twopass()
+        eng.set_params(np.repeat(1. / cols, cols), np.repeat(1. / cols, cols))
+        tl.em(loglev=logging.DEBUG)
+        p['twopass_pi_max_rel_delta'] = float(np.max(np.abs(tl.pi - pi_f) / np.maximum(pi_f, 1e-300)))
+        p['twopass_lnl_rel_delta'] = abs(float(tl.lnl) - lnl_f) / abs(lnl_f)
+        p['twopass_agrees'] = bool(np.allclose(tl.pi, pi_f, rtol=1e-10, atol=1e-300) and np.allclose(tl.theta, theta_f, rtol=1e-10, atol=1e-300) and
+                                   p['twopass_lnl_rel_delta'] <= 1e-10 and np.array_equal(tl.reassign_colsums('exclude'), excl))
+    except Exception as e:   # noqa: BLE001
+        p['twopass_agrees'] = False
+        p['twopass_error'] = repr(e)
+    p['all_hold'] = bool(all(p[k] for k in ('no_fallback', 'lnl_finite', 'parameters_are_distributions', 'all_counts_every_entry',
+                                          'exclude_plus_ties_is_every_fragment', 'average_sums_to_fragments', 'twopass_agrees')))
+    return p
 
 
 def reproducible_leg(device, rows, args, cdf, dist_code, iters=10):

@@ -134,6 +134,13 @@ int  tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_co
  * GLOBAL maximum is known (model.py:640,653) */
 int  tsem_max_score(tsem_ctx* h, int32_t* max_score);
 int  tsem_set_lut(tsem_ctx* h, const double* lut, int32_t lut_len);
+/* The table for a host without numpy (the C host of tests/c_host/): lut[r] = expm1((r * (1 / max_score)) * scale_factor), r = 0 ..
+ * max_score, with the C library's expm1.  NOTE what this is not: numpy's `expm1` — what the reference evaluates (model.py:653) — is a
+ * SIMD routine on AVX-512 hosts and differs from libm's in the last bit of ~10 % of the entries (measured: 23 of 213 for max_score
+ * 212, 6493 of 65536).  Every result then agrees with the reference's to ~1e-15 relative instead of bit for bit; a host that needs the
+ * reference's bits passes the table the reference's own numpy produced (telescope_amd/likelihood.py score_lut does).  No handle, no
+ * device: host arithmetic only. */
+int  tsem_score_lut(int32_t max_score, double scale_factor, double* lut /* max_score + 1 */);
 int  tsem_dims(tsem_ctx* h, int64_t* n_rows, int32_t* n_cols, int64_t* nnz);
 /* copy the CSR back to the host (tests of the generator) */
 int  tsem_export_csr(tsem_ctx* h, int64_t* indptr, int32_t* indices, uint16_t* raw);

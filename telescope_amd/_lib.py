@@ -154,6 +154,7 @@ def lib():
     L.tsem_generate.argtypes = [vp, i64, i64, i32, vp, i32, u64, i32, dbl]
     L.tsem_max_score.argtypes = [vp, C.POINTER(i32)]
     L.tsem_set_lut.argtypes = [vp, vp, i32]
+    L.tsem_score_lut.argtypes = [i32, C.c_double, vp]
     L.tsem_dims.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]
     L.tsem_export_csr.argtypes = [vp, vp, vp, vp]
     L.tsem_rowstats.argtypes = [vp, vp, vp, vp, vp]

@@ -401,6 +401,17 @@ int tsem_max_score(tsem_ctx* h, int32_t* max_score) {
   return TSEM_OK;
 }
 
+// Q for every raw score with the C library's expm1: what a host WITHOUT numpy installs (tests/c_host/run_bundled.c).  Not a device
+// function and no handle: plain host arithmetic in the reference's operation order, (r * (1 / max)) * scale (model.py:653 via
+// sparse_plus.py:89-91).
+int tsem_score_lut(int32_t max_score, double scale_factor, double* lut) {
+  if (max_score < 0 || max_score > 65535 || !lut) return TSEM_ERR_ARG;
+  if (max_score == 0) { lut[0] = 0.0; return TSEM_OK; }
+  const double inv = 1.0 / (double)max_score;
+  for (int32_t r = 0; r <= max_score; ++r) lut[r] = std::expm1(((double)r * inv) * scale_factor);
+  return TSEM_OK;
+}
+
 int tsem_set_lut(tsem_ctx* h, const double* lut, int32_t lut_len) {
   if (!h || !h->d_indptr) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;

@@ -162,3 +162,55 @@ def test_use_likelihood_on_two_gpus(two_gpus, tmp_path):
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=_clean_env())
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'EM converged after 25 iterations.' in r.stderr and 'Final log-likelihood: 95252.596614.' in r.stderr
+
+
+# ---- BASELINE configs 4 and 5 at their stated sizes: one command each the day an 8-GPU node runs `pytest -m gpu` --------
+
+@pytest.fixture(scope='module')
+def eight_gpus(gpu_device):
+    n = _n_gpus()
+    if n < 8:
+        pytest.skip('needs 8 GPUs (this box has %d): BASELINE configs 4 / 5 at full size' % n)
+    import torch
+    free = min(torch.cuda.mem_get_info(d)[0] for d in range(8))
+    if free < 200 * 2 ** 30:
+        pytest.skip('needs 200 GB of free HBM on each of the 8 GPUs (least: %.0f GB)' % (free / 2 ** 30))
+    return n
+
+
+def _bench_config(extra, timeout=3000):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra + ['--no-cpu-baseline', '--no-alt-layout', '--no-precision-sweep',
+                                                                                 '--no-reproducible-leg'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_config5_at_full_size_on_eight_gpus(eight_gpus):
+    """`python bench.py --config 5 --gpus 8`: 200M fragments x 50k loci x ~100 per row = 2e10 stored entries, 25M rows per rank, score
+    codes, one in-library RCCL all-reduce per iteration.  No CPU oracle follows this size: the line's `properties` block holds the
+    checks of test_half_of_config5_on_one_gpu made collectively — no fall-back on any rank, pi / theta distributions, `all` counts every
+    stored entry, exclude + tied rows = every fragment, `average` sums to the fragments, and the same four iterations on the two-pass
+    kernels (every rank's layout rebuilt with fp64 entries) agree to 1e-10."""
+    line = _bench_config(['--config', '5', '--gpus', '8', '--steps', '6', '--warmup', '2'])
+    assert line['n_gpus'] == 8 and line['scaling'] == 'weak' and line['config']['baseline_config'] == 5
+    assert 'BASELINE config 5' in line['config']['workload'] and 'AT ' not in line['config']['workload']
+    assert line['config']['rows'] == 200_000_000 and abs(line['config']['nnz'] - 2.0e10) < 2e8
+    assert 'in-library RCCL all-reduce' in line['config']['parallelism'], line['config']['parallelism']
+    p = line['properties']
+    assert p['all_hold'] is True and p['fallbacks_all_ranks'] == 0 and p['fused_kernel_on_every_rank'], p
+    assert p['resident_bytes_per_entry_max_rank'] < 11.5, p
+    assert line['config']['layout']['value_bytes'] == 2 and line['roofline']['frac'] > 0.2
+
+
+def test_config4_at_full_size_on_eight_gpus(eight_gpus):
+    """`python bench.py --config 4 --gpus 8` — the driver's scaling run at its last point: 50M x 30k x ~40 row-sharded over 8 ranks,
+    checked against the N = 1 run of the whole problem made in the same process on rank 0's GPU (`check.matches_n1`, rtol 1e-11), with
+    the phases of an iteration timed and the speed-up quoted (north_star: >= 6 x)."""
+    line = _bench_config(['--config', '4', '--gpus', '8', '--steps', '20', '--warmup', '3'])
+    assert line['n_gpus'] == 8 and line['scaling'] == 'strong' and line['config']['baseline_config'] == 4
+    assert line['config']['rows'] == 50_000_000 and 'BASELINE config 4' in line['config']['workload']
+    _self_validating(line, 8)
+    assert line['check'].get('matches_embedded', True) is True
+    assert line['config']['layout']['fallbacks'] == 0
+    print('config 4 on 8 GPUs: %.3f ms per iteration, %.2f x the N = 1 run' % (line['ms_per_step'], line['speedup_vs_n1']))

@@ -104,3 +104,102 @@ def test_no_near_tie_rows_on_the_bundled_matrix(gpu_device):
         tl.reassign_colsums(m)
         sp.csr_matrix(tl.reassign(m))
     assert tl._eng.layout_info()['near_tie_rows'] == 0
+
+
+# ---- BASELINE configs 4 and 5 through bench.py's presets: the plumbing, at 1/100 of the rows, two ranks sharing this GPU (VERDICT r5 #2c) ----
+
+def _bench_json(extra, timeout=1500):
+    env = dict(os.environ)
+    for k in ('TSEM_ONE_DEVICE', 'TSEM_GLOO_HOST_STAGED', 'TSEM_BACKEND', 'TSEM_TORCH_COLLECTIVES', 'RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra + ['--no-cpu-baseline', '--no-alt-layout', '--no-precision-sweep',
+                                                                                 '--no-reproducible-leg', '--steps', '4', '--warmup', '1'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    import json
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_config5_preset_dry_run_on_one_gpu(gpu_device):
+    """`bench.py --config 5 --config-scale 0.01 --gpus 2 --one-device`: the preset's geometry (50k loci, ~100 per row, 250k rows per rank,
+    weak scaling), the collective property checks and the result line — what the 8-GPU test of tests/test_gpu_multi.py runs at full size —
+    on two rank processes sharing this GPU; the parameters equal the single-process run of the same 500k rows, and so do its properties."""
+    two = _bench_json(['--config', '5', '--config-scale', '0.01', '--gpus', '2', '--one-device'])
+    one = _bench_json(['--gpus', '1', '--rows', '500000', '--cols', '50000', '--nnz-row', '100', '--value-format', 'auto', '--properties'])
+    assert two['n_gpus'] == 2 and two['scaling'] == 'weak' and two['config']['baseline_config'] == 5
+    assert 'BASELINE config 5' in two['config']['workload'] and 'AT 0.01 OF ITS ROWS' in two['config']['workload']
+    assert two['config']['rows'] == 500_000 == one['config']['rows'] and two['config']['nnz'] == one['config']['nnz']
+    for key in ('pi_sum', 'pi_weighted', 'theta_weighted'):
+        assert abs(two['check'][key] - one['check'][key]) <= 1e-11 * abs(one['check'][key]), key
+    for line in (one, two):
+        p = line['properties']
+        assert p['all_hold'] is True and p['fallbacks_all_ranks'] == 0, p
+        assert p['all_initial_sum'] == line['config']['nnz']
+    assert one['properties']['fused_kernel_on_every_rank'] and one['properties']['twopass_pi_max_rel_delta'] < 1e-10
+    assert two['properties']['exclude_sum'] == one['properties']['exclude_sum'] and two['properties']['tied_rows'] == one['properties']['tied_rows']
+    assert abs(two['properties']['lnl'] - one['properties']['lnl']) <= 1e-10 * abs(one['properties']['lnl'])
+
+
+def test_config4_preset_dry_run_on_one_gpu(gpu_device):
+    """`bench.py --config 4 --config-scale 0.01 --gpus 2 --one-device`: the strong-scaling preset with its own N = 1 reference."""
+    two = _bench_json(['--config', '4', '--config-scale', '0.01', '--gpus', '2', '--one-device'])
+    assert two['n_gpus'] == 2 and two['scaling'] == 'strong' and two['config']['baseline_config'] == 4 and two['config']['rows'] == 500_000
+    assert two['check']['matches_n1'] is True and two['n1_reference']['check']['iterations'] == 5
+
+
+def test_config5_half_through_the_preset(gpu_device):
+    """`bench.py --config 5 --gpus 1`: the 1e10-entry half that fits one GPU, with the property checks in the line (skips below 200 GB free)."""
+    from telescope_amd import _lib
+    free, total = _lib.device_memory(0)
+    if free < 200 * 2 ** 30:
+        pytest.skip('needs 200 GB of free HBM, %.0f GB free of %.0f' % (free / 2 ** 30, total / 2 ** 30))
+    line = _bench_json(['--config', '5', '--gpus', '1'], timeout=2400)
+    assert line['config']['rows'] == 100_000_000 and abs(line['config']['nnz'] - 1.0e10) < 1e8 and 'the half that fits one GPU' in line['config']['workload']
+    p = line['properties']
+    assert p['all_hold'] is True and p['fused_kernel_on_every_rank'] and p['resident_bytes_per_entry_max_rank'] < 11.5, p
+
+
+# ---- a C host of the boundary, no Python in the process (VERDICT r5 #7) --------------------------------------------------------------------
+
+def _build_c_host(tmp_path):
+    exe = str(tmp_path / 'run_bundled')
+    lib_dir = os.path.join(ROOT, 'telescope_amd')
+    subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-O2', '-I' + os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'tests', 'c_host', 'run_bundled.c'), '-o', exe, '-L' + lib_dir, '-ltelescope_em',
+                    '-Wl,-rpath,' + lib_dir, '-Wl,-rpath-link,/opt/rocm/lib'], check=True)
+    return exe
+
+
+def _parse_c_host(stdout):
+    kv = {}
+    for ln in stdout.splitlines():
+        parts = ln.split()
+        if parts:
+            kv[parts[0]] = parts[1:]
+    return kv
+
+
+@pytest.mark.parametrize('table', ['numpy', 'libm'])
+def test_c_host_runs_the_bundled_matrix_without_python(gpu_device, tmp_path, table):
+    """tests/c_host/run_bundled.c — C99, `#include "telescope_em.h"`, linked against libtelescope_em.so — loads the bundled matrix
+    from a flat file and runs create -> load_scores -> max_score -> set_lut -> rowstats -> set_model -> em_run -> report_colsums in a
+    process that never loaded Python, torch or numpy: 16 iterations, lnl 95252.596293, the per-locus `exclude` counts of the golden
+    case.  With the numpy score table of the fixture the counts are the reference's bit for bit and lnl agrees to 1e-12; with
+    tsem_score_lut (libm's expm1: 1 ulp apart from numpy's in ~10 % of the entries, telescope_em.h) to 1e-9."""
+    from conftest import load_case
+    exe = _build_c_host(tmp_path)
+    env = {k: v for k, v in os.environ.items() if not k.startswith('PYTHON')}
+    r = subprocess.run([exe, os.path.join(GOLD, 'bundled_flat.bin')] + (['libm'] if table == 'libm' else []), capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    kv = _parse_c_host(r.stdout)
+    c = load_case('bundled')
+    assert int(kv['iterations'][0]) == int(c['n_iter']) == 16 and int(kv['iterations'][2]) == 1
+    lnl = float(kv['lnl'][0])
+    assert abs(lnl - 95252.596293) < 1e-5
+    assert abs(lnl - float(c['lnl'])) <= (1e-12 if table == 'numpy' else 1e-9) * abs(float(c['lnl'])), (lnl, float(c['lnl']))
+    assert np.array_equal(np.array(kv['exclude'], dtype=np.int64), np.asarray(c['ra_exclude_0_colsum']).astype(np.int64))
+    assert int(kv['ties'][2]) == 0                                   # near_tie_rows: none on ordinary data
+    # the process really had no Python in it: its only link-time dependencies are the engine and the C library
+    ldd = subprocess.run(['ldd', exe], capture_output=True, text=True).stdout
+    assert 'libtelescope_em.so' in ldd and 'python' not in ldd.lower() and 'torch' not in ldd.lower()

@@ -242,3 +242,51 @@ def test_the_torch_transport_is_opt_in():
     assert decide_transport(True, 'x', {'TSEM_ALLOW_TORCH_COLLECTIVES': '1'}) == 'torch'
     with pytest.raises(_lib.EngineError):
         decide_transport(True, 'x', {'TSEM_ALLOW_TORCH_COLLECTIVES': '0', 'TSEM_TORCH_COLLECTIVES': '1'})
+
+
+def test_bench_config_presets(monkeypatch):
+    """`bench.py --config N` names BASELINE.json's configurations (VERDICT r5 #2): rows / columns / row length / scaling per preset."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+
+    def parse(*argv):
+        monkeypatch.setattr(sys, 'argv', ['bench.py'] + list(argv))
+        return bench.parse()
+    a = parse('--config', '5', '--gpus', '8')
+    assert (a.rows, a.cols, a.nnz_row, a.scaling, a.value_format, a.properties) == (25_000_000, 50_000, 100.0, 'weak', 'auto', True)
+    assert 'BASELINE config 5' in a.config_note and '8 rank(s) x 25M rows' in a.config_note
+    a = parse('--config', '5')
+    assert a.rows == 100_000_000 and 'the half that fits one GPU' in a.config_note
+    a = parse('--config', '5', '--gpus', '2', '--config-scale', '0.01')
+    assert a.rows == 250_000 and 'AT 0.01 OF ITS ROWS' in a.config_note
+    a = parse('--config', '4', '--gpus', '8')
+    assert (a.rows, a.cols, a.nnz_row, a.scaling) == (50_000_000, 30_000, 40.0, 'strong')
+    a = parse('--config', '2')
+    assert (a.rows, a.cols, a.nnz_row) == (1_000_000, 30_000, 20.0)
+    a = parse()
+    assert a.config == 0 and a.rows == 50_000_000 and a.config_note is None
+
+
+def test_c_host_compiles_as_c99_and_fails_loudly_without_a_device(built, tmp_path):
+    """tests/c_host/run_bundled.c against include/telescope_em.h with `gcc -std=c99 -pedantic -Werror`, linked against the in-tree
+    libtelescope_em.so; in this container (no GPU) it must stop at tsem_create with the library's message — no CPU path (the run on
+    a GPU is tests/test_gpu_round6.py).  Also: tsem_score_lut is libm's table, within 1 ulp of the reference's numpy table."""
+    import subprocess
+    exe = str(tmp_path / 'run_bundled')
+    lib_dir = os.path.join(ROOT, 'telescope_amd')
+    subprocess.run(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-O2', '-I' + os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'tests', 'c_host', 'run_bundled.c'), '-o', exe, '-L' + lib_dir, '-ltelescope_em',
+                    '-Wl,-rpath,' + lib_dir, '-Wl,-rpath-link,/opt/rocm/lib'], check=True)
+    lut = np.zeros(213)
+    assert built.tsem_score_lut(212, 100.0, lut.ctypes.data_as(ctypes.c_void_p)) == 0
+    ref = score_lut(212)
+    assert np.all(np.abs(lut - ref) <= np.spacing(ref)) and lut[0] == 0.0
+    try:
+        _lib.Engine(0).close()
+        pytest.skip('a GPU is present: the loud failure is a CPU-box property')
+    except _lib.EngineError:
+        pass
+    r = subprocess.run([exe, os.path.join(ROOT, 'tests', 'golden', 'bundled_flat.bin')], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and 'tsem_create' in r.stderr and 'HIP' in r.stderr, (r.returncode, r.stderr)
