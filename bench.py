@@ -532,7 +532,7 @@ def main():
         },
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'GB per launch (PMC, profiles/pmc_traffic.json)',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': _pmc_stamp(),
             'peak_nominal': HBM_PEAK_GBS, 'peak_measured': peak_measured,
             'frac_of_measured': (achieved / peak_measured) if peak_measured else None,
             'peak_measured_how': 'pure streaming read of 8 GB in this run (tsem_debug_stream_read), GB/s',
@@ -746,6 +746,21 @@ def _pmc_traffic(total_rows, args, world, value_bytes):
     except (OSError, KeyError, ValueError, TypeError):
         pass
     return None
+
+
+def _pmc_stamp():
+    """Where `roofline.traffic` comes from — a constant read from profiles/pmc_traffic.json, not something this run measured — with the
+    stamp of that measurement and whether the library's sources are still the ones it was made on."""
+    try:
+        from telescope_amd._lib import sources_fingerprint
+        m = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('measured', {})
+        now = sources_fingerprint()
+        state = 'the sources of this run are the measured ones' if m.get('sources_sha16') == now else \
+            'STALE: the library sources changed since (now %s)' % now
+        return 'GB per launch (PMC, profiles/pmc_traffic.json: measured %s at commit %s, sources %s — %s)' % (
+            m.get('date', '?'), m.get('commit', '?'), m.get('sources_sha16', '?'), state)
+    except Exception:   # noqa: BLE001
+        return 'GB per launch (PMC, profiles/pmc_traffic.json)'
 
 
 def _shutdown(comm):

@@ -75,6 +75,10 @@ int  tsem_set_stream(tsem_ctx* h, void* hip_stream); /* launch on this hipStream
  *   "row_offset"   global index of this rank's first row (synthetic generator, column signatures)
  *   "report_shortcuts" 1 (default): tsem_reassign answers `all` (initial) and `unique` from counts taken at
  *                  setup instead of a pass over the matrix (the same numbers; 0 forces the pass)
+ *   "report_kernel" which kernels serve tsem_report_colsums / tsem_reassign_rows / tsem_reassign_groups: 1 (default) the streaming
+ *                  report kernels, incl. the passes over the INITIAL z that run on the 2-byte score codes alone (no `conf` column
+ *                  wanted, a strictly increasing score table, no stored score of 0); 2 the streaming kernels without those
+ *                  codes-only passes (timing comparisons); 0 the generic 16-lanes-per-row pass for everything (same results)
  *   "kernel_timing" n: HIP events around every n-th EM pass for tsem_kernel_stats (default 1, 0 = off)
  *   "phase_timing" 1: HIP events at the phase boundaries of every chunked iteration (tsem_phase_times)
  *   "drop_csr_indices" free the CSR column ids (4 of the 14 B per stored entry the default layout keeps resident) once the

@@ -109,6 +109,19 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
     return target
 
 
+def sources_fingerprint():
+    """sha256 (16 hex digits) over the library's sources — what a measurement kept under profiles/ is stamped with, so that a later
+    run can tell whether the kernels it describes are still the ones in the tree (bench.py `roofline.traffic_unit`)."""
+    import hashlib
+    csrc = os.path.join(HERE, 'csrc')
+    names = sorted(f for f in os.listdir(csrc) if f.endswith(('.hip', '.h')))
+    hsh = hashlib.sha256()
+    for f in names + [os.path.join(ROOT, 'include', 'telescope_em.h')]:
+        with open(f if os.path.isabs(f) else os.path.join(csrc, f), 'rb') as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
 _lib = None
 
 

@@ -289,9 +289,22 @@ def run_assign(args):
         finish(comm)
         lg.info('telescope assign complete (%s)' % format_minutes(time() - total_time))
         return 0
+    # The other ranks read THEIR fragments from the checkpoint rank 0 has just written: <outdir> must be a directory every rank sees
+    # (one node, or a shared file system that is coherent behind the barrier above).  A rank that cannot read it says so through a
+    # second status word — like rank 0's parse failure above — so that no rank walks into the model's collectives alone.
+    load_failure = None
     if rank != 0:
-        ts = Telescope.load_shard(opts.outfile_path('checkpoint') + '.npz', world, rank)
-        ts.opts = opts
+        try:
+            ts = Telescope.load_shard(opts.outfile_path('checkpoint') + '.npz', world, rank)
+            ts.opts = opts
+        except BaseException as e:                           # noqa: BLE001 — re-raised below, once every rank knows
+            load_failure = e
+    if comm is not None and comm.max_scalar(1 if load_failure is not None else 0):
+        finish(comm)
+        if load_failure is not None:
+            raise load_failure
+        raise SystemExit('telescope assign: another rank could not read its fragments from %s.npz — a row-sharded `assign` needs '
+                         '--outdir on a file system all ranks share (see that rank\'s message)' % opts.outfile_path('checkpoint'))
     seed = ts.get_random_seed()
     lg.debug('Random seed: {}'.format(seed))
     np.random.seed(seed)

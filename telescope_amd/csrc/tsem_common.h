@@ -96,6 +96,7 @@ struct tsem_ctx {
   double W_tot = 0, W_amb = 0, w_max = 0, pi_prior = 0, theta_prior = 0;
   double* d_pisum0 = nullptr;  // [K]
   uint32_t* d_ucount = nullptr;            // [K+1] unique rows with a positive score per column (local); [K]: some stored score is 0
+  bool has_zero_score = false;             // ... read back once by tsem_rowstats
   unsigned long long* d_colcount = nullptr;   // [K] stored entries per column (local rows)
   bool em_cur = false, em_prev = false;    // current / previous pi, theta come from tsem_set_model or the M-step, not from tsem_set_params
   int64_t opt_split = -1;                  // split layout: -1 when K needs it, 1 forced (tests), 0 never

@@ -1110,6 +1110,15 @@ static void redrop_indices(tsem_ctx* h) {
   }
 }
 
+// The passes over the INITIAL z that work on the 2-byte score codes alone (k_report_init_codes, k_choose_init_codes): a row's best
+// hits are its largest codes — true when the score table is strictly increasing and no stored score is 0 (code 0 is their padding).
+// Option "report_kernel": 1 (default) streaming kernels incl. the codes-only ones; 2 streaming kernels WITHOUT the codes-only ones
+// (timing comparisons); 0 the generic row pass for everything.
+static bool codes_path_ok(const tsem_ctx* h) {
+  return h->opt_report_kernel == 1 && h->lut_increasing && !h->opt_reproducible && h->have_rowstats && !h->has_zero_score &&
+         h->d_rid16 && h->d_col_of_id;
+}
+
 struct IndicesGuard {                                      // at the top of an entry point: ids this call had to rebuild do not outlive it
   tsem_ctx* h; bool had;
   explicit IndicesGuard(tsem_ctx* c) : h(c), had(c && c->d_indices != nullptr) {}
@@ -1311,10 +1320,7 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
   //     score — z = n * (1/n) in (0, 1] whenever n = q * pi_j is a normal positive number, which holds for the
   //     parameters the M-step produces (pi_j >= pisum0_j / W_tot > 1e-60 for a column that has such a row).
   if (!mask && h->opt_shortcuts && h->d_ucount && h->have_rowstats && which != TSEM_Z_USER) {
-    uint32_t has_zero = 0;
-    TSEM_HIP(hipMemcpyAsync(&has_zero, h->d_ucount + h->K, 4, hipMemcpyDeviceToHost, h->stream));
-    TSEM_HIP(hipStreamSynchronize(h->stream));
-    if (method == TSEM_RA_ALL && which == TSEM_Z_INITIAL && !has_zero && h->d_colcount) {
+    if (method == TSEM_RA_ALL && which == TSEM_Z_INITIAL && !h->has_zero_score && h->d_colcount) {
       std::vector<unsigned long long> c(h->K);
       TSEM_HIP(hipMemcpy(c.data(), h->d_colcount, sizeof(unsigned long long) * h->K, hipMemcpyDeviceToHost));
       for (int j = 0; j < h->K; ++j) colsums[j] = (double)c[j];
@@ -1397,13 +1403,7 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       const bool init = A.pi == nullptr;
       // thresh < 0: the caller wants no `conf` column.  The initial z then needs no arithmetic at all — the best hits of a row are its
       // largest score codes (k_report_init_codes) — provided the score table is strictly increasing and no stored score is 0.
-      bool codes_only = false;
-      if (init && !want_conf && h->lut_increasing && !h->opt_reproducible && h->d_ucount && h->opt_report_kernel != 2) {
-        uint32_t has_zero = 1;
-        TSEM_HIP(hipMemcpyAsync(&has_zero, h->d_ucount + K, 4, hipMemcpyDeviceToHost, h->stream));
-        TSEM_HIP(hipStreamSynchronize(h->stream));
-        codes_only = has_zero == 0;
-      }
+      const bool codes_only = init && !want_conf && codes_path_ok(h);
       double *d_g = nullptr, *d_c2 = nullptr;
       TSEM_SCOPED(d_g); TSEM_SCOPED(d_c2);
       const bool exact = h->opt_reproducible != 0;
@@ -1540,12 +1540,8 @@ int tsem_reassign_rows(tsem_ctx* h, int method, double thresh, int which, const 
   }
   // `choose` over the initial z: the picked best hit is the picks[i]-th entry with the row's largest score code — no score table,
   // no column ids (the popularity ids do), no floating point — under the premises of k_report_init_codes
-  if (method == TSEM_RA_CHOOSE && which == TSEM_Z_INITIAL && h->lut_increasing && !h->opt_reproducible && h->opt_report_kernel == 1 &&
-      h->d_rid16 && h->d_col_of_id && h->d_ucount) {
-    uint32_t has_zero = 1;
-    TSEM_HIP(hipMemcpyAsync(&has_zero, h->d_ucount + h->K, 4, hipMemcpyDeviceToHost, h->stream));
-    TSEM_HIP(hipStreamSynchronize(h->stream));
-    if (!has_zero) {
+  if (method == TSEM_RA_CHOOSE && which == TSEM_Z_INITIAL) {
+    if (codes_path_ok(h)) {
       const int Hs = std::min(h->Kpad, (TS_LDS_MAX - 2048) / 4);
       const int grid = (int)std::min<int64_t>(h->n_cu, std::max<int64_t>(1, (n + 63) / 64));
       TSEM_HIP(hipFuncSetAttribute((const void*)k_choose_init_codes, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));

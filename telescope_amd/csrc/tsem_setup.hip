@@ -967,7 +967,10 @@ int tsem_rowstats(tsem_ctx* h, double* stats3, double* pisum0, uint64_t* col_cou
   uint32_t maxcode = 0;
   TSEM_HIP(hipMemcpyAsync(wpart.data(), d_wpart, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipMemcpyAsync(&maxcode, h->d_maxcode, 4, hipMemcpyDeviceToHost, h->stream));
+  uint32_t has_zero = 0;                                     // some stored score is 0 (fixed from here on: kept on the host)
+  TSEM_HIP(hipMemcpyAsync(&has_zero, h->d_ucount + K, 4, hipMemcpyDeviceToHost, h->stream));
   TSEM_HIP(hipStreamSynchronize(h->stream));
+  h->has_zero_score = has_zero != 0;
   double wt = 0, wa = 0;
   for (int i = 0; i < grid; ++i) { wt += wpart[2 * i]; wa += wpart[2 * i + 1]; }
   if (stats3) { stats3[0] = wt; stats3[1] = wa; stats3[2] = (N && h->nnz) ? h->lut_host[maxcode] : 0.0; }

@@ -508,19 +508,22 @@ class TelescopeLikelihood(object):
         # and never its conf (model.py:441-446); a later reassign('conf', initial=True) runs the full pass.
         return -1.0 if which == Z_INITIAL else thresh
 
-    def reassign_group_sums(self, method, group_rows, thresh=0.9, initial=False):
+    def reassign_group_sums(self, method, group_rows, thresh=0.9, initial=False, group_token=None):
         """Per-group column sums of the assignment matrix: row g of the result is
         `reassign(method, thresh, initial)[group_rows[g], :].sum(0).A1` — the per-barcode count matrix
         of `scTelescope.output_report` (model.py:611-625) for `group_rows = barcode_read_indices
         .values()` — computed in one device pass, without materialising the N x K assignment.
         A row listed in several groups (or twice in one) counts once per listing, like fancy
         indexing does.  Row-sharded runs pass the indices local to this rank's rows; the sums are
-        all-reduced."""
+        all-reduced.  The grouping's layers are cached under a hash of its CONTENT (a caller may refill the
+        same list between two reports); hashing tens of millions of listings held in Python lists or sets
+        costs more than the device pass, and a report asks up to six methods of one grouping — a caller that
+        passes the same hashable `group_token` with the same grouping skips the hash."""
         if method not in REASSIGN_METHODS:
             raise ValueError('Argument "method" should be one of (exclude, choose, average, conf, unique, all)')
         which = self._which(initial)
         picks = self._picks(which) if method == 'choose' else None
-        layers, n_groups, digest = self._group_layers(group_rows)
+        layers, n_groups, digest = self._group_layers(group_rows, group_token)
         out = np.zeros((n_groups, self.K))
         for li, grp in enumerate(layers):
             # the map of a layer goes to the device once and serves every method asked of it (a report asks for up to six); the engine
@@ -538,18 +541,21 @@ class TelescopeLikelihood(object):
             out = np.rint(out).astype(np.int64)
         return out
 
-    def _group_layers(self, group_rows):
+    def _group_layers(self, group_rows, token=None):
         """Row -> group maps for `reassign_group_sums`, one per LAYER: within a layer every row belongs to at most one group; the
         k-th listing of a row (over all groups, duplicates inside a group included) goes to layer k.  Built once per grouping
         (vectorised: one stable sort of the listings)."""
         import hashlib
+        cached = getattr(self, '_group_layer_cache', None)
+        if token is not None and cached is not None and cached[0] == ('token', token):
+            return cached[1], cached[2], cached[0]              # the caller vouches for the grouping behind the token
         groups = [np.asarray(list(g) if not isinstance(g, np.ndarray) else g, dtype=np.int64) for g in group_rows]
         n_groups = len(groups)
         lens = np.array([len(g) for g in groups], dtype=np.int64)
         rows = np.concatenate(groups) if n_groups and lens.sum() else np.zeros(0, np.int64)
         # keyed on the grouping's CONTENT (a caller may refill the same list object between two reports)
-        digest = hashlib.blake2b(lens.tobytes() + np.ascontiguousarray(rows).tobytes(), digest_size=16).hexdigest()
-        cached = getattr(self, '_group_layer_cache', None)
+        digest = ('token', token) if token is not None else \
+            hashlib.blake2b(lens.tobytes() + np.ascontiguousarray(rows).tobytes(), digest_size=16).hexdigest()
         if cached is not None and cached[0] == digest:
             return cached[1], cached[2], digest
         gid = np.repeat(np.arange(n_groups, dtype=np.int32), lens)

@@ -1,4 +1,4 @@
-"""Ad-hoc GPU bring-up script (not a pytest file): python tests/gpu_quick.py"""
+"""Ad-hoc GPU bring-up script (not a pytest file): python tools/gpu_quick.py"""
 import logging, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

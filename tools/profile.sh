@@ -39,7 +39,6 @@ import json,sys; d=json.loads(sys.stdin.read()); print('rows $r kernel_timing 1:
 done >> $OUT/comm_overhead.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-layout --no-precision-sweep --no-reproducible-leg --kernel-timing 0 --rows 6250000 > /dev/null 2>&1
 python tools/iter_timeline.py $(ls $OUT/tl/*/*_kernel_trace.csv | head -1) 12 2 > $OUT/iter_timeline.txt 2>&1
-tools/sweep_r02.sh > $OUT/sweep.txt 2>&1
 python tools/time_setup.py > $OUT/time_setup.txt 2>&1
 python tools/time_e2e.py > $OUT/time_e2e.txt 2>&1
 python bench.py --steps 20 --warmup 3 > $OUT/bench.log 2>&1

@@ -99,7 +99,14 @@ def main():
         f.write('## rocprofv3 --pmc WRITE_SIZE --kernel-trace -- %s\n' % cmd + '\n'.join(wl) + '\n\n')
         f.write('# per EM pass; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced streaming read)\n')
         f.write('\n'.join(notes) + '\n')
+    import datetime
+    sys.path.insert(0, ROOT)
+    from telescope_amd._lib import sources_fingerprint
     json.dump({'runs': runs,
+               # what the numbers were measured on: bench.py prints this stamp beside `roofline.traffic` and says whether the
+               # library's sources still are the ones measured (the constant must not go stale silently)
+               'measured': {'date': datetime.date.today().isoformat(), 'sources_sha16': sources_fingerprint(),
+                            'commit': os.environ.get('TSEM_COMMIT', 'unknown (the GPU box has no .git; see the commit that added this file)')},
                'source': 'profiles/%s_pmc_hbm_traffic_fused.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; '
                          'FETCH_SIZE x2 gfx950 correction)' % prefix},
               open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# profiles/<prefix>_* from the output of tools/profile.sh (+ tools/sweep_short_r02.sh) under gpurun_out/prof/<tag>:
+# profiles/<prefix>_* from the output of tools/profile.sh (+ tools/sweep_short_r03.sh) under gpurun_out/prof/<tag>:
 #   tools/regen_profiles.sh <tag> <prefix>          e.g.  tools/regen_profiles.sh r02 r02
 # Files with hand-written header lines keep them (the first '#' lines of the tracked file).
 set -u
@@ -13,7 +13,7 @@ python tools/profile_summary.py $O ${2:-r02} | tail -2
 clean $O/lds_ubench.log > ${P}_lds_ubench.log
 clean $O/stream_ubench.log > ${P}_stream_ubench.log
 { hdr ${P}_comm_overhead.txt 3; cat $O/comm_overhead.txt; echo; cat $O/iter_timeline.txt; } > /tmp/_p && mv /tmp/_p ${P}_comm_overhead.txt
-{ hdr ${P}_sweep.txt 1; cat $O/sweep.txt; } > /tmp/_p && mv /tmp/_p ${P}_sweep.txt
+[ -f $O/sweep.txt ] && { hdr ${P}_sweep.txt 1; cat $O/sweep.txt; } > /tmp/_p && mv /tmp/_p ${P}_sweep.txt
 [ -f $O/sweep_short.txt ] && { hdr ${P}_sweep_short.txt 1; cat $O/sweep_short.txt; } > /tmp/_p && mv /tmp/_p ${P}_sweep_short.txt
 cp $O/bench.json ${P}_bench.json
 python -c "
