@@ -82,7 +82,7 @@ def test_near_ties_are_decided_with_the_references_row_sum(gpu_device, seed, kw,
     for m in ('exclude', 'average', 'conf', 'all', 'unique'):
         cs, mask = eng.reassign(m, thresh, _lib.Z_CUR, want_mask=True)
         mo = sp.csr_matrix(om.reassign(m, thresh)).astype(np.float64)
-        dense_mask = sp.csr_matrix((mask, raw.indices, raw.indptr), shape=raw.shape)
+        dense_mask = sp.csr_matrix((mask, raw.indices.copy(), raw.indptr.copy()), shape=raw.shape)   # (eliminate_zeros works in place)
         dense_mask.eliminate_zeros()
         d = (dense_mask - mo)
         assert abs(d).max() <= 1e-12 if d.nnz else True, (m, abs(d).max())
