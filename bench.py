@@ -240,6 +240,10 @@ def cpu_baseline(args, dist_code, cdf):
                 lnl_rel_delta=abs(tl.lnl - lnl_ref) / abs(lnl_ref),
                 pi_max_rel_delta=float(np.max(np.abs(tl.pi - om.pi) / np.maximum(om.pi, 1e-300))),
                 final_count_mismatches=int(np.count_nonzero(g_excl != o_excl)),
+                # rows of the sample whose best hits hung on the last bits of 1 / rowsum: redone with the reference's order of additions
+                # (tsem_npsum.h).  The end-to-end rate on adversarial matrices (the oracle's OWN parameters, two-score matrices) is measured
+                # by tests/fuzz_reports.py `own`: profiles/r06_fuzz_reports.txt
+                near_tie_rows=int(tl._eng.layout_info().get('near_tie_rows', 0)),
                 final_conf_max_rel_delta=float(np.max(np.abs(g_conf - o_conf) / np.maximum(np.abs(o_conf), 1e-300))),
                 converged_run=dict(rows=nc, em_epsilon=eps_c, max_iter=cap_c, iterations_gpu=int(tlc.n_iter), iterations_ref=int(omc.n_iter),
                                    converged_gpu=bool(tlc.converged), converged_ref=bool(omc.converged),
@@ -608,7 +612,7 @@ def main():
         elif fc:
             out['cpu_baseline_fused_c'] = fc
         out['parity_on_sample'] = {k: cb[k] for k in ('lnl_ref', 'lnl_gpu', 'lnl_rel_delta', 'pi_max_rel_delta',
-                                                      'final_count_mismatches', 'final_conf_max_rel_delta',
+                                                      'final_count_mismatches', 'near_tie_rows', 'final_conf_max_rel_delta',
                                                       'sample_rows', 'iters', 'converged_run')}
     if world == 1 and not args.no_precision_sweep:
         # BASELINE config 3 (10M x 30k x ~40): error of reduced-precision storage / accumulation against fp64

@@ -110,6 +110,7 @@ void tsem_free_matrix(tsem_ctx* h) {
   dfree(h->d_c32); dfree(h->d_cs32); dfree(h->d_lut32); dfree(h->d_cnat);
   dfree(h->d_ctl); dfree(h->d_ctld); dfree(h->d_lnls); dfree(h->d_pi_first); dfree(h->d_theta_first); dfree(h->d_user_z);
   dfree(h->d_tie_rows); dfree(h->d_tie_cnt); h->n_ties = 0;
+  if (h->d_rep_chunks) { (void)hipFree(h->d_rep_chunks); h->d_rep_chunks = nullptr; h->n_rep_chunks = 0; }
   dfree(h->d_rep_nb); dfree(h->d_rep_rows); dfree(h->d_rep_n); dfree(h->d_exact_n); dfree(h->d_flag_bits); h->flag_words = 0;
   dfree(h->d_group); h->n_groups = 0;
   if (h->d_gtile) { (void)hipFree(h->d_gtile); h->d_gtile = nullptr; h->gtile_bytes = 0; }
@@ -222,6 +223,7 @@ static int set_lut(tsem_ctx* h, const double* lut, int32_t lut_len) {
   h->lut_len = lut_len;
   dfree(h->d_lut32); dfree(h->d_c32); dfree(h->d_cs32);      // (the fp32 diagnostic tables follow the score table)
   h->lut_host.assign(lut, lut + lut_len);
+  h->lut0_zero = lut[0] == 0.0;
   h->lut_increasing = lut_len >= 2 && lut[1] > 0.0;
   for (int i = 2; i < lut_len && h->lut_increasing; ++i) h->lut_increasing = lut[i] > lut[i - 1];
   dfree(h->d_lqtab); h->lq_n = 0; h->lq_tried = false;       // (log Q follows the score table)

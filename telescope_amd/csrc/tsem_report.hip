@@ -527,6 +527,8 @@ struct ReportEmit {                                        // where a row's valu
   }
 };
 
+#include "tsem_report_pack.h"
+
 // threads per workgroup: the pass over the final z needs ~92 VGPRs (pi*theta gathers in flight) and spills under the 128 of a 1024-thread
 // workgroup (15.6 vs 5.3 ms); the pass over the initial z needs 68 and gains from 16 waves per CU instead of 8 (7.8 -> 6.9 ms with its tie list)
 constexpr int rr_nt(bool init) { return init ? 1024 : 512; }
@@ -1371,6 +1373,30 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
 
 // One pass for the column sums output_report takes from one z (model.py:432-457): conf | exclude | average, and the rows
 // with several best hits (the only rows `choose` treats differently from `exclude`) compacted in row order.
+// the chunk table of k_report_pack: built on the first report of a matrix, kept until the matrix goes
+static int ensure_report_chunks(tsem_ctx* h) {
+  if (h->d_rep_chunks) return TSEM_OK;
+  const int64_t cap = rp_chunk_cap(h->N, h->nnz);
+  RpChunk* d = nullptr;
+  unsigned long long* d_n = nullptr;
+  TSEM_SCOPED(d_n);
+  TSEM_ALLOC(d_n, 1);
+  TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
+  if (hipMalloc((void**)&d, (size_t)cap * sizeof(RpChunk)) != hipSuccess) TSEM_FAIL(TSEM_ERR_NOMEM, "report chunk table");
+  k_report_chunks<<<(unsigned)cdiv64(h->N, RC_TILE), 256, 0, h->stream>>>(h->N, h->d_indptr, d, d_n, cap);
+  unsigned long long n = 0;
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess || (int64_t)n > cap || n == 0) {
+    (void)hipFree(d);
+    if (e != hipSuccess) TSEM_HIP(e);
+    TSEM_FAIL(TSEM_ERR_ARG, "report chunk table: bad chunk count");
+  }
+  h->d_rep_chunks = d; h->n_rep_chunks = (int64_t)n;
+  return TSEM_OK;
+}
+
 int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, int64_t* n_ties) {
   if (!h || !h->d_indptr || !out3K) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
@@ -1410,12 +1436,16 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       TSEM_ALLOC(d_g, 6 * (int64_t)IDN);
       TSEM_HIP(hipMemsetAsync(d_g, 0, sizeof(double) * 6 * IDN, h->stream));
       if (!init) {
-        TSEM_ALLOC(d_c2, 2 * (int64_t)IDN);
+        TSEM_ALLOC(d_c2, 2 * (int64_t)IDN + 1);              // (+ a 0.0: what k_report_pack's hot ids read from the global table)
         k_cnat2_id<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, h->d_col_of_id, A.pi, A.theta, d_c2);
+        TSEM_HIP(hipMemsetAsync(d_c2 + 2 * (int64_t)IDN, 0, sizeof(double), h->stream));
         R.cnat2 = d_c2;
       }
       R.g_conf = d_g; R.g_n1 = d_g + IDN; R.g_n2 = d_g + 2 * (int64_t)IDN; R.g_avgt = d_g + 3 * (int64_t)IDN;
       if (exact) { R.g_conf_lo = d_g + 4 * (int64_t)IDN; R.g_avgt_lo = d_g + 5 * (int64_t)IDN; }
+      // the final z at conf_prob > 0.51: rows packed into the lanes without padding (tsem_report_pack.h)
+      const bool packed = !init && !exact && thresh > 0.51 && h->lut0_zero && !(h->opt_report_dbg & 8) && h->opt_report_lanes == 0 &&
+                          h->N < 0x7FFFFFFF;
       // LDS: one workgroup of rr_nt() threads per CU (or two, option rowpass_wgs).  The final z wants pi*theta of as many
       // ids as fit (8 B each) next to a few thousand accumulator slots (16 B each); the initial z has no pi*theta.
       const int wgs = h->opt_rowpass_wgs >= 2 && h->opt_report_wgs2 ? 2 : 1;
@@ -1441,13 +1471,28 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       R.dbg = (int)h->opt_report_dbg;
       R.defer_rows = d_rows; R.defer_n = d_n;               // (d_rows is the tie list later: the slow kernel is done with it by then)
       TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
-      if (codes_only) rk<<<h->n_cu * cw, 1024, (size_t)R.Hs * 8, h->stream>>>(R);
+      if (packed) {
+        if (int rc = ensure_report_chunks(h)) return rc;
+        // LDS: pi*theta of the HC most popular ids next to two 32-bit counters for the Hs most popular winners — a missed counter
+        // costs a global atomic (22 G/s), a missed pi*theta an L2 gather (one address per clock and CU), and a row has one winner
+        // per ~40 entries: two table slots per counter slot
+        constexpr int nwv = 16;
+        const int fixed = R.lut_len * 8 + 8 + nwv * 64 * (int)(sizeof(RpSlot) + 4) + 1024;
+        const int slots = (TS_LDS_MAX - fixed) / 8;
+        R.Hs = std::min(IDN, slots / 3);
+        R.HC = std::min(IDN, slots - R.Hs);
+        TSEM_HIP(hipFuncSetAttribute((const void*)k_report_pack, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        k_report_pack<<<h->n_cu, nwv * 64, (size_t)(TS_LDS_MAX - 1024), h->stream>>>(R, h->d_rep_chunks, h->n_rep_chunks,
+                                                                               reinterpret_cast<unsigned long long*>(d_g + 4 * (int64_t)IDN));
+      } else if (codes_only) rk<<<h->n_cu * cw, 1024, (size_t)R.Hs * 8, h->stream>>>(R);
       else
       rk<<<h->n_cu * wgs, rr_nt(init), (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * slot_bytes, h->stream>>>(R);
       TSEM_HIP(hipGetLastError());
       if (init) k_report_slow<true><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
       else k_report_slow<false><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
       TSEM_HIP(hipGetLastError());
+      if (packed)                                            // (the fifth IDN-vector of d_g: the low pieces of `reproducible`, which `packed` excludes)
+        k_report_unpack<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, reinterpret_cast<const unsigned long long*>(d_g + 4 * (int64_t)IDN), R.g_n1, R.g_conf);
       k_report_finish<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, K, h->d_col_of_id, R.g_conf, R.g_n1, R.g_n2, R.g_avgt, R.g_conf_lo, R.g_avgt_lo, d_cs);
       TSEM_HIP(hipGetLastError());
       TSEM_HIP(hipStreamSynchronize(h->stream));

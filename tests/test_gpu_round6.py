@@ -203,3 +203,74 @@ def test_c_host_runs_the_bundled_matrix_without_python(gpu_device, tmp_path, tab
     # the process really had no Python in it: its only link-time dependencies are the engine and the C library
     ldd = subprocess.run(['ldd', exe], capture_output=True, text=True).stdout
     assert 'libtelescope_em.so' in ldd and 'python' not in ldd.lower() and 'torch' not in ldd.lower()
+
+
+# ---- the packed report kernel (tsem_report_pack.h): rows of every shape against the capacity kernel, the generic pass and the oracle ----
+
+def _shape_matrix(seed, n, k, kind):
+    rng = np.random.RandomState(seed)
+    if kind == 'short':            # 0 .. 9 entries, many empty and single-entry rows: chunks of 64 one-lane rows
+        lens = rng.randint(0, 10, n)
+    elif kind == 'mixed':          # around 40 with a tail up to 700: rows of 1 .. 64 lanes, and rows beyond the kernel's 512 entries
+        lens = rng.poisson(40, n)
+        big = rng.rand(n) < 0.02
+        lens[big] = rng.randint(400, min(700, k) + 1, int(big.sum()))
+        lens[rng.rand(n) < 0.05] = 1
+        lens[rng.rand(n) < 0.01] = 0
+    elif kind == 'lane_edges':     # lengths at the lane boundaries: 7, 8, 9, 15, 16, 17, .. 512, 513
+        base = np.array([7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513])
+        lens = base[rng.randint(0, len(base), n)]
+    else:
+        raise ValueError(kind)
+    lens = np.minimum(lens, k)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.empty(indptr[-1], np.int32)
+    for i, l in enumerate(lens):
+        if l:
+            # hot-locus skew, so that both the LDS table and the L2 tail of pi * theta are hit
+            c = np.unique((k * rng.rand(3 * l + 8) ** 3).astype(np.int64))
+            while len(c) < l:
+                c = np.unique(np.concatenate([c, rng.randint(0, k, l)]))
+            indices[indptr[i]:indptr[i + 1]] = np.sort(rng.choice(c, l, replace=False))
+    data = rng.randint(1, 6, indptr[-1]).astype(np.uint16)     # five distinct scores: exact ties are common
+    return sp.csr_matrix((data, indices, indptr), shape=(n, k))
+
+
+@pytest.mark.parametrize('kind,n,k', [('short', 30000, 700), ('mixed', 6000, 20000), ('lane_edges', 1500, 40000), ('mixed', 4000, 900)])
+def test_packed_report_kernel_on_rows_of_every_shape(gpu_device, kind, n, k):
+    """k_report_pack (the default for the final z at conf_prob > 0.51) against the capacity kernel it replaces (report_dbg = 8), the generic
+    row pass (report_kernel = 0) and the oracle: column sums of conf / exclude / average, the tied rows and their best-hit counts —
+    integer outputs equal bit for bit — on empty rows, single-entry rows, rows that end exactly on a lane, rows of 64 lanes, rows longer
+    than the kernel takes (-> k_report_slow), K above and below the LDS table, exact ties (five distinct scores)."""
+    from oracle.telescope_oracle import OracleModel, binmax_rows
+    from telescope_amd import _lib
+    from telescope_amd.likelihood import TelescopeLikelihood, score_lut
+    raw = _shape_matrix(11 + n, n, k, kind)
+    eng = _lib.Engine(0)
+    eng.load_scores(raw.indptr, raw.indices, raw.data.astype(np.uint16), k, score_lut(int(raw.data.max())))
+    tl = TelescopeLikelihood.from_engine(eng, Opts(max_iter=3, em_epsilon=0.0))
+    tl._raw = raw
+    tl.em()
+    out = {}
+    for name, kern, dbg in (('packed', 1, 0), ('capacity', 1, 8), ('generic', 0, 0)):
+        eng.set_option('report_kernel', kern); eng.set_option('report_dbg', dbg)
+        for th in (0.9, 0.6):
+            sums, r, c = eng.report_colsums(_lib.Z_PREV, th)
+            out[(name, th)] = (sums['exclude'].copy(), sums['average'].copy(), sums['conf'].copy(), r.copy(), c.copy())
+    eng.set_option('report_kernel', 1); eng.set_option('report_dbg', 0)
+    om = OracleModel(raw, 0, 200000)
+    om.em(0.0, 3)
+    zo = sp.csr_matrix(om.z)
+    nb = np.diff(binmax_rows(zo).indptr)
+    for th in (0.9, 0.6):
+        a = out[('packed', th)]
+        for other in ('capacity', 'generic'):
+            b = out[(other, th)]
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]), (other, th)
+            assert np.allclose(a[1], b[1], rtol=1e-12, atol=1e-9) and np.allclose(a[2], b[2], rtol=1e-12, atol=1e-9), (other, th)
+        # against the oracle (its z comes from its own parameters: equal to ~1e-13; a flip would need a near-tie, and those are redone)
+        want = np.rint(np.asarray(om.reassign('exclude', th).sum(0)).ravel()).astype(np.int64)
+        assert np.array_equal(a[0].astype(np.int64), want), th
+        assert np.allclose(a[2], np.asarray(om.reassign('conf', th).sum(0)).ravel(), rtol=1e-9, atol=1e-9), th
+        assert np.array_equal(a[3], np.flatnonzero(nb > 1)) and np.array_equal(a[4], nb[nb > 1]), th
+    eng.close()
