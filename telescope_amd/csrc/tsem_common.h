@@ -207,7 +207,7 @@ struct tsem_ctx {
   int64_t opt_group_tile = 0;       // bytes of per-group output computed per pass over the matrix (0 = 1 GB)
   int32_t *d_rep_nb = nullptr, *d_rep_rows = nullptr;   // [N] scratch of tsem_report_colsums, kept between calls
   unsigned long long* d_rep_n = nullptr;
-  struct RpChunk* d_rep_chunks = nullptr; int64_t n_rep_chunks = 0;   // k_report_pack's packing of the rows into wave-sized chunks (tsem_report_pack.h)
+  struct RpChunk* d_rep_chunks = nullptr; int64_t n_rep_chunks = 0; int rep_chunk_E = 0;   // k_report_pack's packing of the rows into wave-sized chunks (tsem_report_pack.h)
   uint32_t* d_flag_bits = nullptr; int64_t flag_words = 0;   // near-tie bitmap of the generic row passes (+ their counter), kept between calls
   unsigned long long* d_exact_n = nullptr;   // [1] rows whose sum a report / row pass redid in the reference's order of additions (near-ties, tsem_npsum.h)
                                              //     since the matrix was loaded; tsem_layout_info[31]

@@ -4,6 +4,7 @@
 #include "tsem_internal.h"
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include "tsem_npsum.h"
 
@@ -1373,27 +1374,44 @@ int tsem_reassign(tsem_ctx* h, int method, double thresh, int which, const int32
 
 // One pass for the column sums output_report takes from one z (model.py:432-457): conf | exclude | average, and the rows
 // with several best hits (the only rows `choose` treats differently from `exclude`) compacted in row order.
-// the chunk table of k_report_pack: built on the first report of a matrix, kept until the matrix goes
-static int ensure_report_chunks(tsem_ctx* h) {
-  if (h->d_rep_chunks) return TSEM_OK;
-  const int64_t cap = rp_chunk_cap(h->N, h->nnz);
-  RpChunk* d = nullptr;
+// packed report pass: a row with several best hits is a row the fp32 filter left to k_report_slow — the tied rows are picked from the
+// deferred list (a few thousand entries) instead of a select over all N best-hit counts (0.5 ms at 5e7 rows); sorted afterwards
+__global__ void k_ties_of_deferred(const unsigned long long* __restrict__ nd, const int32_t* __restrict__ defer_rows, const int32_t* __restrict__ nbest,
+                                   int32_t* __restrict__ out, unsigned long long* __restrict__ n_out) {
+  const int64_t n = (int64_t)*nd;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t rc = defer_rows[i];
+    const int32_t row = rc < 0 ? ~rc : rc;
+    if (nbest[row] > 1) out[atomicAdd(n_out, 1ull)] = row;
+  }
+}
+// the chunk table of k_report_pack32: built on the first report of a matrix (or when the entries per lane change), kept until the matrix goes
+static int ensure_report_chunks(tsem_ctx* h, int E) {
+  if (h->d_rep_chunks && h->rep_chunk_E == E) return TSEM_OK;
+  if (h->d_rep_chunks) { (void)hipFree(h->d_rep_chunks); h->d_rep_chunks = nullptr; h->n_rep_chunks = 0; }
   unsigned long long* d_n = nullptr;
   TSEM_SCOPED(d_n);
   TSEM_ALLOC(d_n, 1);
+  const unsigned grid = (unsigned)cdiv64(h->N, RC_TILE);
+  unsigned long long n = 0, n2 = 0;
   TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
-  if (hipMalloc((void**)&d, (size_t)cap * sizeof(RpChunk)) != hipSuccess) TSEM_FAIL(TSEM_ERR_NOMEM, "report chunk table");
-  k_report_chunks<<<(unsigned)cdiv64(h->N, RC_TILE), 256, 0, h->stream>>>(h->N, h->d_indptr, d, d_n, cap);
-  unsigned long long n = 0;
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, h->stream);
+  k_report_chunks<<<grid, 256, 0, h->stream>>>(h->N, h->d_indptr, E, nullptr, d_n, 0);          // count
+  TSEM_HIP(hipGetLastError());
+  TSEM_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, h->stream));
+  TSEM_HIP(hipStreamSynchronize(h->stream));
+  if (n == 0) TSEM_FAIL(TSEM_ERR_ARG, "report chunk table: no chunks");
+  RpChunk* d = nullptr;
+  if (hipMalloc((void**)&d, (size_t)n * sizeof(RpChunk)) != hipSuccess) TSEM_FAIL(TSEM_ERR_NOMEM, "report chunk table");
+  hipError_t e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream);
+  if (e == hipSuccess) { k_report_chunks<<<grid, 256, 0, h->stream>>>(h->N, h->d_indptr, E, d, d_n, (int64_t)n); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(&n2, d_n, 8, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  if (e != hipSuccess || (int64_t)n > cap || n == 0) {
+  if (e != hipSuccess || n2 != n) {
     (void)hipFree(d);
     if (e != hipSuccess) TSEM_HIP(e);
-    TSEM_FAIL(TSEM_ERR_ARG, "report chunk table: bad chunk count");
+    TSEM_FAIL(TSEM_ERR_ARG, "report chunk table: the two packing launches disagree");
   }
-  h->d_rep_chunks = d; h->n_rep_chunks = (int64_t)n;
+  h->d_rep_chunks = d; h->n_rep_chunks = (int64_t)n; h->rep_chunk_E = E;
   return TSEM_OK;
 }
 
@@ -1436,16 +1454,20 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       TSEM_ALLOC(d_g, 6 * (int64_t)IDN);
       TSEM_HIP(hipMemsetAsync(d_g, 0, sizeof(double) * 6 * IDN, h->stream));
       if (!init) {
-        TSEM_ALLOC(d_c2, 2 * (int64_t)IDN + 1);              // (+ a 0.0: what k_report_pack's hot ids read from the global table)
+        TSEM_ALLOC(d_c2, 2 * (int64_t)IDN);
         k_cnat2_id<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, h->d_col_of_id, A.pi, A.theta, d_c2);
-        TSEM_HIP(hipMemsetAsync(d_c2 + 2 * (int64_t)IDN, 0, sizeof(double), h->stream));
         R.cnat2 = d_c2;
       }
       R.g_conf = d_g; R.g_n1 = d_g + IDN; R.g_n2 = d_g + 2 * (int64_t)IDN; R.g_avgt = d_g + 3 * (int64_t)IDN;
       if (exact) { R.g_conf_lo = d_g + 4 * (int64_t)IDN; R.g_avgt_lo = d_g + 5 * (int64_t)IDN; }
       // the final z at conf_prob > 0.51: rows packed into the lanes without padding (tsem_report_pack.h)
-      const bool packed = !init && !exact && thresh > 0.51 && h->lut0_zero && !(h->opt_report_dbg & 8) && h->opt_report_lanes == 0 &&
-                          h->N < 0x7FFFFFFF;
+      int lut_sq = 0;                                        // lut 2^-lut_sq: the largest score table entry in [2^40, 2^41)
+      double lut_max = 0.0;
+      for (double v : h->lut_host) lut_max = std::max(lut_max, v);
+      if (lut_max > 0.0 && std::isfinite(lut_max)) lut_sq = std::ilogb(lut_max) - 40;
+      const bool packed = !init && !exact && thresh > 0.51 && thresh <= 0.99999 &&   // (at 1.0 a unique row's z = fl(n fl(1 / n)) may miss the threshold)
+                          h->lut0_zero && lut_max > 0.0 && std::isfinite(lut_max) &&
+                          (int)h->lut_host.size() == R.lut_len && !(h->opt_report_dbg & 8) && h->opt_report_lanes == 0 && h->N < 0x7FFFFFFF;
       // LDS: one workgroup of rr_nt() threads per CU (or two, option rowpass_wgs).  The final z wants pi*theta of as many
       // ids as fit (8 B each) next to a few thousand accumulator slots (16 B each); the initial z has no pi*theta.
       const int wgs = h->opt_rowpass_wgs >= 2 && h->opt_report_wgs2 ? 2 : 1;
@@ -1472,18 +1494,35 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       R.defer_rows = d_rows; R.defer_n = d_n;               // (d_rows is the tie list later: the slow kernel is done with it by then)
       TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
       if (packed) {
-        if (int rc = ensure_report_chunks(h)) return rc;
-        // LDS: pi*theta of the HC most popular ids next to two 32-bit counters for the Hs most popular winners — a missed counter
-        // costs a global atomic (22 G/s), a missed pi*theta an L2 gather (one address per clock and CU), and a row has one winner
-        // per ~40 entries: two table slots per counter slot
+        // tsem_report_pack.h: fp32 tables (by id), the per-row winner records, the chunk table; LDS = the table of as many ids as fit
+        // (all of them up to ~34 000 slots) + the score table + 16 B per lane of row slots
+        // entries per lane: 16 amortise the per-chunk work (row map, scan, prefetch) over twice the entries; short rows fill 8 better
+        const int pkE = (h->opt_report_dbg & 128) ? 8 : ((h->opt_report_dbg & 256) ? 16 : (h->nnz >= 24 * h->N ? 16 : 8));
+        if (int rc = ensure_report_chunks(h, pkE)) return rc;
+        uint32_t* d_t32 = nullptr; float* d_l32 = nullptr;
+        TSEM_SCOPED(d_t32); TSEM_SCOPED(d_l32);
+        TSEM_ALLOC(d_t32, (int64_t)IDN + 1); TSEM_ALLOC(d_l32, R.lut_len);
+        k_rp32_tables<<<cdiv64(std::max(IDN + 1, R.lut_len), 256), 256, 0, h->stream>>>(IDN, d_c2, R.lut_len, R.lut, lut_sq, d_t32, d_l32);
         constexpr int nwv = 16;
-        const int fixed = R.lut_len * 8 + 8 + nwv * 64 * (int)(sizeof(RpSlot) + 4) + 1024;
-        const int slots = (TS_LDS_MAX - fixed) / 8;
-        R.Hs = std::min(IDN, slots / 3);
-        R.HC = std::min(IDN, slots - R.Hs);
-        TSEM_HIP(hipFuncSetAttribute((const void*)k_report_pack, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
-        k_report_pack<<<h->n_cu, nwv * 64, (size_t)(TS_LDS_MAX - 1024), h->stream>>>(R, h->d_rep_chunks, h->n_rep_chunks,
-                                                                               reinterpret_cast<unsigned long long*>(d_g + 4 * (int64_t)IDN));
+        const int words = (TS_LDS_MAX - 1024) / 4 - 8 - (pkE + 1) * (pkE / 2);   // LDS words for the table of the ids and the copies of the score table
+        Rp32Args P;
+        P.N = h->N; P.IDN = IDN; P.lut_len = R.lut_len; P.indptr = h->d_indptr; P.rid = h->d_rid16; P.raw = h->d_raw;
+        P.HC = std::min(IDN, std::max(0, words - R.lut_len));
+        P.lut_rep = 0;
+        while (P.lut_rep < 5 && P.HC + 1 + (R.lut_len << (P.lut_rep + 1)) <= words) ++P.lut_rep;
+        P.t32 = d_t32; P.l32 = d_l32; P.thresh = (float)thresh; P.win = reinterpret_cast<uint32_t*>(d_nb); P.defer_rows = d_rows; P.defer_n = d_n;
+        P.chunks = h->d_rep_chunks; P.nchunks = h->n_rep_chunks; P.dbg = (int)h->opt_report_dbg;
+        const size_t lds = (size_t)((pkE + 1) * (pkE / 2) + P.HC + 1 + (P.lut_len << P.lut_rep)) * 4;
+        void (*pk)(Rp32Args) = pkE == 16 ? (P.HC < IDN ? k_report_pack32<16, true> : k_report_pack32<16, false>)
+                                         : (P.HC < IDN ? k_report_pack32<8, true> : k_report_pack32<8, false>);
+        TSEM_HIP(hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        pk<<<h->n_cu, nwv * 64, lds, h->stream>>>(P);
+        TSEM_HIP(hipGetLastError());
+        // the winners per id: the whole LDS for counters, the ids in windows
+        const int W = std::min(IDN, (TS_LDS_MAX - 1024) / 8);
+        TSEM_HIP(hipFuncSetAttribute((const void*)k_report_hist, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        for (int id0 = 0; id0 < IDN; id0 += W)
+          k_report_hist<<<h->n_cu, 1024, (size_t)std::min(W, IDN - id0) * 8, h->stream>>>(h->N, reinterpret_cast<const uint32_t*>(d_nb), id0, std::min(W, IDN - id0), R.g_n1, R.g_conf);
       } else if (codes_only) rk<<<h->n_cu * cw, 1024, (size_t)R.Hs * 8, h->stream>>>(R);
       else
       rk<<<h->n_cu * wgs, rr_nt(init), (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * slot_bytes, h->stream>>>(R);
@@ -1491,10 +1530,45 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       if (init) k_report_slow<true><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
       else k_report_slow<false><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
       TSEM_HIP(hipGetLastError());
-      if (packed)                                            // (the fifth IDN-vector of d_g: the low pieces of `reproducible`, which `packed` excludes)
-        k_report_unpack<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, reinterpret_cast<const unsigned long long*>(d_g + 4 * (int64_t)IDN), R.g_n1, R.g_conf);
       k_report_finish<<<cdiv64(IDN, 256), 256, 0, h->stream>>>(IDN, K, h->d_col_of_id, R.g_conf, R.g_n1, R.g_n2, R.g_avgt, R.g_conf_lo, R.g_avgt_lo, d_cs);
       TSEM_HIP(hipGetLastError());
+      if (packed) {
+        // the tied rows: among the deferred ones (the fp32 filter decides only rows with ONE best hit) — picked from the list, sorted
+        unsigned long long nd = 0, nt = 0;
+        TSEM_HIP(hipMemcpyAsync(&nd, d_n, 8, hipMemcpyDeviceToHost, h->stream));
+        TSEM_HIP(hipMemcpyAsync(out3K, d_cs, sizeof(double) * 3 * K, hipMemcpyDeviceToHost, h->stream));
+        TSEM_HIP(hipStreamSynchronize(h->stream));
+        if (nd) {
+          int32_t *d_unsorted = nullptr, *d_sorted = nullptr;
+          unsigned long long* d_nt = nullptr;
+          TSEM_SCOPED(d_unsorted); TSEM_SCOPED(d_sorted); TSEM_SCOPED(d_nt);
+          TSEM_ALLOC(d_unsorted, nd); TSEM_ALLOC(d_nt, 1);
+          TSEM_HIP(hipMemsetAsync(d_nt, 0, sizeof(unsigned long long), h->stream));
+          k_ties_of_deferred<<<256, 256, 0, h->stream>>>(d_n, d_rows, d_nb, d_unsorted, d_nt);
+          TSEM_HIP(hipGetLastError());
+          TSEM_HIP(hipMemcpyAsync(&nt, d_nt, 8, hipMemcpyDeviceToHost, h->stream));
+          TSEM_HIP(hipStreamSynchronize(h->stream));
+          if (nt) {
+            TSEM_ALLOC(d_sorted, nt);
+            size_t tb = 0;
+            TSEM_HIP(rocprim::radix_sort_keys(nullptr, tb, d_unsorted, d_sorted, (size_t)nt, 0, 32, h->stream));
+            if (h->rep_tmp_bytes < tb || !h->d_rep_tmp) {
+              if (h->d_rep_tmp) (void)hipFree(h->d_rep_tmp);
+              h->d_rep_tmp = nullptr; h->rep_tmp_bytes = 0;
+              TSEM_HIP(hipMalloc(&h->d_rep_tmp, tb ? tb : 1));
+              h->rep_tmp_bytes = tb;
+            }
+            TSEM_HIP(rocprim::radix_sort_keys(h->d_rep_tmp, tb, d_unsorted, d_sorted, (size_t)nt, 0, 32, h->stream));
+            TSEM_ALLOC(h->d_tie_rows, nt); TSEM_ALLOC(h->d_tie_cnt, nt);
+            TSEM_HIP(hipMemcpyAsync(h->d_tie_rows, d_sorted, sizeof(int32_t) * nt, hipMemcpyDeviceToDevice, h->stream));
+            k_gather_i32<<<cdiv64((int64_t)nt, 256), 256, 0, h->stream>>>((int64_t)nt, d_sorted, d_nb, h->d_tie_cnt);
+            TSEM_HIP(hipStreamSynchronize(h->stream));
+          }
+        }
+        h->n_ties = (int64_t)nt;
+        if (n_ties) *n_ties = (int64_t)nt;
+        return TSEM_OK;
+      }
       TSEM_HIP(hipStreamSynchronize(h->stream));
     } else if (h->d_colmap && h->d_col_of_pc && h->P > 0) {
       if (int rc = with_indices(h, A)) return rc;

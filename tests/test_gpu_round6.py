@@ -238,7 +238,8 @@ def _shape_matrix(seed, n, k, kind):
 
 @pytest.mark.parametrize('kind,n,k', [('short', 30000, 700), ('mixed', 6000, 20000), ('lane_edges', 1500, 40000), ('mixed', 4000, 900)])
 def test_packed_report_kernel_on_rows_of_every_shape(gpu_device, kind, n, k):
-    """k_report_pack (the default for the final z at conf_prob > 0.51) against the capacity kernel it replaces (report_dbg = 8), the generic
+    """k_report_pack32 (the default for the final z at conf_prob > 0.51; 8 and 16 entries per lane: report_dbg = 128 / 256) against the
+    capacity kernel it replaces (report_dbg = 8), the generic
     row pass (report_kernel = 0) and the oracle: column sums of conf / exclude / average, the tied rows and their best-hit counts —
     integer outputs equal bit for bit — on empty rows, single-entry rows, rows that end exactly on a lane, rows of 64 lanes, rows longer
     than the kernel takes (-> k_report_slow), K above and below the LDS table, exact ties (five distinct scores)."""
@@ -252,7 +253,7 @@ def test_packed_report_kernel_on_rows_of_every_shape(gpu_device, kind, n, k):
     tl._raw = raw
     tl.em()
     out = {}
-    for name, kern, dbg in (('packed', 1, 0), ('capacity', 1, 8), ('generic', 0, 0)):
+    for name, kern, dbg in (('packed', 1, 0), ('packed8', 1, 128), ('packed16', 1, 256), ('capacity', 1, 8), ('generic', 0, 0)):
         eng.set_option('report_kernel', kern); eng.set_option('report_dbg', dbg)
         for th in (0.9, 0.6):
             sums, r, c = eng.report_colsums(_lib.Z_PREV, th)
@@ -264,7 +265,7 @@ def test_packed_report_kernel_on_rows_of_every_shape(gpu_device, kind, n, k):
     nb = np.diff(binmax_rows(zo).indptr)
     for th in (0.9, 0.6):
         a = out[('packed', th)]
-        for other in ('capacity', 'generic'):
+        for other in ('packed8', 'packed16', 'capacity', 'generic'):
             b = out[(other, th)]
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]), (other, th)
             assert np.allclose(a[1], b[1], rtol=1e-12, atol=1e-9) and np.allclose(a[2], b[2], rtol=1e-12, atol=1e-9), (other, th)
