@@ -356,6 +356,12 @@ int  tsem_csr_scale(int device, int mode, int64_t n_rows, int32_t n_cols, const 
  * algorithmic bytes one EM pass reads.  */
 int  tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launches,
                        int64_t* algo_bytes_per_pass);
+/* The last tsem_report_colsums of the handle: HIP-event time (ms) of its dominant kernel — the pass over the stored entries — when
+ * option "kernel_timing" is not 0 (else 0), the algorithmic bytes that pass reads and writes (4 B per stored entry: popularity id +
+ * score code; 8 B row pointer + 4 B output per row), the rows it left to the exact row kernel (too long, tied, near-tied, on the
+ * threshold), and which kernel it was: 0 none yet, 1 generic row pass, 2 capacity kernel (k_report_rows), 3 score codes only
+ * (k_report_init_codes), 4 packed fp32 filter (k_report_pack32).  model.py:432-457 is what the pass computes. */
+int  tsem_report_stats(tsem_ctx* h, double* kernel_ms, int64_t* algo_bytes, int64_t* deferred_rows, int32_t* kernel);
 /* Option "phase_timing" = 1: tsem_em_chunk records a HIP event at every phase boundary of every iteration it enqueues (a
  * diagnostic: ~5 events per iteration on the engine's stream).  ms6 = summed milliseconds over *n_iter iterations of
  * { EM pass | column reduce | all-reduce of the K+2 sums (0 without a communicator) | update | gap to the next iteration's

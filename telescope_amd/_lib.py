@@ -223,6 +223,7 @@ def lib():
     L.tsem_csr_binmax_rows.argtypes = [C.c_int, i64, i32, vp, vp, vp]
     L.tsem_csr_scale.argtypes = [C.c_int, C.c_int, i64, i32, vp, vp, vp]
     L.tsem_kernel_stats.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)]
+    L.tsem_report_stats.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_int32)]
     L.tsem_phase_times.argtypes = [vp, C.c_int, vp, C.POINTER(i64)]
     L.tsem_device_memory.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i64), vp]
     L.tsem_layout_info.argtypes = [vp, vp]
@@ -579,6 +580,13 @@ class Engine(object):
         ms, n, b = C.c_double(), C.c_int64(), C.c_int64()
         self._ck(self._L.tsem_kernel_stats(self._h, int(reset), C.byref(ms), C.byref(n), C.byref(b)))
         return dict(em_ms=ms.value, em_launches=n.value, algo_bytes_per_pass=b.value)
+
+    def report_stats(self):
+        """The last report_colsums: dict(kernel_ms (option kernel_timing != 0), algo_bytes, deferred_rows, kernel)."""
+        ms, b, d, k = C.c_double(), C.c_int64(), C.c_int64(), C.c_int32()
+        self._ck(self._L.tsem_report_stats(self._h, C.byref(ms), C.byref(b), C.byref(d), C.byref(k)))
+        return dict(kernel_ms=ms.value, algo_bytes=b.value, deferred_rows=d.value,
+                    kernel={0: None, 1: 'k_rowpass', 2: 'k_report_rows', 3: 'k_report_init_codes', 4: 'k_report_pack32'}[k.value])
 
     def device_memory(self):
         """dict(free, total, resident=dict(csr, csr_indices, ids, layout, rows)) in bytes."""

@@ -246,6 +246,8 @@ struct tsem_ctx {
   double phase_ms[6] = {0, 0, 0, 0, 0, 0};   // pass | column reduce | all-reduce | update | gap to the next iteration | first mark to last mark
   int64_t phase_n = 0;              // iterations summed into phase_ms
   std::vector<hipEvent_t> ev;       // pairs
+  hipEvent_t ev_rep[2] = {nullptr, nullptr};   // around the dominant kernel of the last tsem_report_colsums (tsem_report_stats)
+  bool rep_timed = false; int rep_kernel = 0; int64_t rep_deferred = 0;
   size_t ev_used = 0;
   double em_ms_acc = 0;
   int64_t em_launches = 0, em_timed = 0;

@@ -162,6 +162,7 @@ void tsem_destroy(tsem_ctx* h) {
   dfree(h->d_diffs); dfree(h->d_lnl_part); dfree(h->d_maxcode); dfree(h->d_xerr);
   for (auto& ev : h->ev) (void)hipEventDestroy(ev);
   for (auto& ev : h->pev) (void)hipEventDestroy(ev);
+  for (auto& ev : h->ev_rep) if (ev) (void)hipEventDestroy(ev);
   delete h;
 }
 
@@ -464,6 +465,21 @@ int tsem_kernel_stats(tsem_ctx* h, int reset, double* em_ms, int64_t* em_launche
   // + 2 B row weight code per row
   if (algo_bytes) *algo_bytes = h->nnz_amb * (h->fmt_code ? 6 : 12) + h->N_amb * 2;
   if (reset) { h->em_ms_acc = 0; h->em_launches = 0; h->em_timed = 0; }
+  return TSEM_OK;
+}
+
+int tsem_report_stats(tsem_ctx* h, double* kernel_ms, int64_t* algo_bytes, int64_t* deferred_rows, int32_t* kernel) {
+  if (!h) return TSEM_ERR_ARG;
+  if (int rc = ensure_device(h)) return rc;
+  float ms = 0.f;
+  if (h->rep_timed && h->ev_rep[0] && h->ev_rep[1]) {
+    TSEM_HIP(hipStreamSynchronize(h->stream));
+    if (hipEventElapsedTime(&ms, h->ev_rep[0], h->ev_rep[1]) != hipSuccess) ms = 0.f;
+  }
+  if (kernel_ms) *kernel_ms = ms;
+  if (algo_bytes) *algo_bytes = h->nnz * 4 + h->N * 12;
+  if (deferred_rows) *deferred_rows = h->rep_deferred;
+  if (kernel) *kernel = h->rep_kernel;
   return TSEM_OK;
 }
 

@@ -169,6 +169,7 @@ int tsem_choose_geometry(tsem_ctx* h);
 int tsem_build_layout(tsem_ctx* h);
 int tsem_bin_reset(tsem_ctx* h);                           // option "reproducible": the slots' bounds as a run finds them
 int tsem_make_ctabs(tsem_ctx* h);                          // the permuted pi * theta tables (current and previous) from the parameters
+void tsem_report_preload(void);                            // the same for the report unit (build_layout, behind the fill)
 void tsem_setup_preload(void);                             // load the set-up unit's code object now (behind a kernel that is running anyway)
 int tsem_ensure_indices(tsem_ctx* h);                      // the CSR column ids, rebuilt from the popularity ids if option "drop_csr_indices" freed them
 // tsem_em.hip

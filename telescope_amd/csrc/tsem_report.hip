@@ -7,6 +7,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include "tsem_npsum.h"
+#include <atomic>
 
 // ---- near-ties: rows whose integer outputs hang on the last bits of 1 / rowsum ---------------------------------------------------
 // The masks compare z_j = fl(n_j r), r = fl(1 / rowsum), with each other (`==`, sparse_plus.py:125) and with conf_prob (`>=`,
@@ -1385,6 +1386,17 @@ __global__ void k_ties_of_deferred(const unsigned long long* __restrict__ nd, co
     if (nbest[row] > 1) out[atomicAdd(n_out, 1ull)] = row;
   }
 }
+// HIP loads a translation unit's code object at the first launch (or attribute query) of one of its kernels — ~10 ms for this unit,
+// which used to sit at the head of the first report of a process (11 of its 14.5 ms at 50M rows).  build_layout calls this once the fill
+// of the blocked layout is enqueued, next to the fused unit's load: the host loads while the device is busy.  (From tsem_em_chunk, behind
+// eight enqueued iterations, the load was NOT hidden: em() grew by the same 10 ms.)
+void tsem_report_preload(void) {
+  static std::atomic<bool> done{false};
+  if (done.exchange(true)) return;
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, (const void*)k_report_finish);
+}
+
 // the chunk table of k_report_pack32: built on the first report of a matrix (or when the entries per lane change), kept until the matrix goes
 static int ensure_report_chunks(tsem_ctx* h, int E) {
   if (h->d_rep_chunks && h->rep_chunk_E == E) return TSEM_OK;
@@ -1419,6 +1431,7 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
   if (!h || !h->d_indptr || !out3K) return TSEM_ERR_ARG;
   if (int rc = ensure_device(h)) return rc;
   const bool want_conf = !(thresh < 0.0);                  // thresh < 0: no `conf` column wanted (its third of out3K stays 0)
+  PhaseTimer pt(h->stream);                                // (TSEM_TRACE=1)
   if (!want_conf) thresh = 0.9;                            // (what the paths that compute it anyway use)
   IndicesGuard ig(h);
   RowPassArgs A;
@@ -1437,6 +1450,7 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
     int32_t *const d_nb = h->d_rep_nb, *const d_rows = h->d_rep_rows;
     unsigned long long* const d_n = h->d_rep_n;
     A.thresh = thresh; A.colsums = d_cs; A.nbest = d_nb;
+    pt.lap("report: scratch");
     if (h->opt_report_kernel != 0 && which != TSEM_Z_USER && h->d_rid16 && h->d_col_of_id && A.lut_len > 0) {
       // the streaming report kernel (k_report_rows): lanes per row x entries per lane = the smallest capacity that
       // fewer than 0.5 % of the rows exceed (row-length histogram of tsem_rowstats); the rest goes to k_report_slow
@@ -1493,12 +1507,18 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
       R.dbg = (int)h->opt_report_dbg;
       R.defer_rows = d_rows; R.defer_n = d_n;               // (d_rows is the tie list later: the slow kernel is done with it by then)
       TSEM_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream));
+      h->rep_timed = h->opt_timing != 0; h->rep_kernel = packed ? 4 : (codes_only ? 3 : 2); h->rep_deferred = 0;
+      if (h->rep_timed) {
+        for (int q = 0; q < 2; ++q) if (!h->ev_rep[q]) TSEM_HIP(hipEventCreate(&h->ev_rep[q]));
+      }
       if (packed) {
         // tsem_report_pack.h: fp32 tables (by id), the per-row winner records, the chunk table; LDS = the table of as many ids as fit
         // (all of them up to ~34 000 slots) + the score table + 16 B per lane of row slots
         // entries per lane: 16 amortise the per-chunk work (row map, scan, prefetch) over twice the entries; short rows fill 8 better
         const int pkE = (h->opt_report_dbg & 128) ? 8 : ((h->opt_report_dbg & 256) ? 16 : (h->nnz >= 24 * h->N ? 16 : 8));
+        pt.lap("report: by-id tables");
         if (int rc = ensure_report_chunks(h, pkE)) return rc;
+        pt.lap("report: chunk table");
         uint32_t* d_t32 = nullptr; float* d_l32 = nullptr;
         TSEM_SCOPED(d_t32); TSEM_SCOPED(d_l32);
         TSEM_ALLOC(d_t32, (int64_t)IDN + 1); TSEM_ALLOC(d_l32, R.lut_len);
@@ -1516,17 +1536,24 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
         void (*pk)(Rp32Args) = pkE == 16 ? (P.HC < IDN ? k_report_pack32<16, true> : k_report_pack32<16, false>)
                                          : (P.HC < IDN ? k_report_pack32<8, true> : k_report_pack32<8, false>);
         TSEM_HIP(hipFuncSetAttribute((const void*)pk, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
+        if (h->rep_timed) TSEM_HIP(hipEventRecord(h->ev_rep[0], h->stream));
         pk<<<h->n_cu, nwv * 64, lds, h->stream>>>(P);
+        if (h->rep_timed) TSEM_HIP(hipEventRecord(h->ev_rep[1], h->stream));
         TSEM_HIP(hipGetLastError());
+        pt.lap("report: k_report_pack32");
         // the winners per id: the whole LDS for counters, the ids in windows
         const int W = std::min(IDN, (TS_LDS_MAX - 1024) / 8);
         TSEM_HIP(hipFuncSetAttribute((const void*)k_report_hist, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024));
         for (int id0 = 0; id0 < IDN; id0 += W)
           k_report_hist<<<h->n_cu, 1024, (size_t)std::min(W, IDN - id0) * 8, h->stream>>>(h->N, reinterpret_cast<const uint32_t*>(d_nb), id0, std::min(W, IDN - id0), R.g_n1, R.g_conf);
-      } else if (codes_only) rk<<<h->n_cu * cw, 1024, (size_t)R.Hs * 8, h->stream>>>(R);
-      else
-      rk<<<h->n_cu * wgs, rr_nt(init), (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * slot_bytes, h->stream>>>(R);
+      } else {
+        if (h->rep_timed) TSEM_HIP(hipEventRecord(h->ev_rep[0], h->stream));
+        if (codes_only) rk<<<h->n_cu * cw, 1024, (size_t)R.Hs * 8, h->stream>>>(R);
+        else rk<<<h->n_cu * wgs, rr_nt(init), (size_t)R.lut_len * 8 + (size_t)R.HC * 8 + (size_t)R.Hs * slot_bytes, h->stream>>>(R);
+        if (h->rep_timed) TSEM_HIP(hipEventRecord(h->ev_rep[1], h->stream));
+      }
       TSEM_HIP(hipGetLastError());
+      pt.lap("report: pass (+ histogram)");
       if (init) k_report_slow<true><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
       else k_report_slow<false><<<h->n_cu * 2, 256, 0, h->stream>>>(R);
       TSEM_HIP(hipGetLastError());
@@ -1538,6 +1565,8 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
         TSEM_HIP(hipMemcpyAsync(&nd, d_n, 8, hipMemcpyDeviceToHost, h->stream));
         TSEM_HIP(hipMemcpyAsync(out3K, d_cs, sizeof(double) * 3 * K, hipMemcpyDeviceToHost, h->stream));
         TSEM_HIP(hipStreamSynchronize(h->stream));
+        h->rep_deferred = (int64_t)nd;
+        pt.lap("report: exact rows, by column");
         if (nd) {
           int32_t *d_unsorted = nullptr, *d_sorted = nullptr;
           unsigned long long* d_nt = nullptr;
@@ -1565,12 +1594,14 @@ int tsem_report_colsums(tsem_ctx* h, int which, double thresh, double* out3K, in
             TSEM_HIP(hipStreamSynchronize(h->stream));
           }
         }
+        pt.lap("report: tied rows");
         h->n_ties = (int64_t)nt;
         if (n_ties) *n_ties = (int64_t)nt;
         return TSEM_OK;
       }
       TSEM_HIP(hipStreamSynchronize(h->stream));
     } else if (h->d_colmap && h->d_col_of_pc && h->P > 0) {
+      h->rep_timed = false; h->rep_kernel = 1; h->rep_deferred = 0;
       if (int rc = with_indices(h, A)) return rc;
       const int wgs = h->opt_rowpass_wgs < 2 ? 1 : 2;
       A.colmap = h->d_colmap; A.col_of_pc = h->d_col_of_pc; A.P = h->P; A.Kp = h->Kp;

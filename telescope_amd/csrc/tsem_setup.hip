@@ -1387,6 +1387,7 @@ int tsem_build_layout(tsem_ctx* h) {
       fz_fn f0 = P <= FZ_MAX_P ? fz_kernel(P, h->split ? 5 : 0, fz_fmt(h), h->geo) : nullptr;
       if (f0) (void)hipFuncSetAttribute((const void*)f0, hipFuncAttributeMaxDynamicSharedMemorySize, TS_LDS_MAX - 1024);
     }
+    tsem_report_preload();                                 // (round 6: the report unit's too — ~10 ms that used to sit in the first report)
     TSEM_HIP(hipStreamSynchronize(h->stream));
     // option "drop_csr_indices": the fill was the last reader of the CSR column ids (the report pass and this layout carry 2-byte
     // popularity ids; col = col_of_id[id]): 10 instead of 14 B per stored entry stay resident.
