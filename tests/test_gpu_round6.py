@@ -275,3 +275,30 @@ def test_packed_report_kernel_on_rows_of_every_shape(gpu_device, kind, n, k):
         assert np.allclose(a[2], np.asarray(om.reassign('conf', th).sum(0)).ravel(), rtol=1e-9, atol=1e-9), th
         assert np.array_equal(a[3], np.flatnonzero(nb > 1)) and np.array_equal(a[4], nb[nb > 1]), th
     eng.close()
+
+
+def test_report_stats_name_the_kernel_that_ran(gpu_device):
+    """tsem_report_stats (bench.py's `report_pass`): the final z at conf_prob 0.9 runs the packed fp32 filter and leaves only a handful of
+    rows to the exact row kernel; report_dbg = 8 the capacity kernel; the initial z without a conf column the score-code kernel; with
+    `kernel_timing` on, the pass's HIP-event time is there; the column sums do not depend on which kernel ran."""
+    from telescope_amd import _lib
+    from test_gpu_parity import _synthetic_tl
+    tl = _synthetic_tl(400_000, 30_000, 24, 'zipf', uniq=0.05, opts=Opts(max_iter=4, em_epsilon=0.0))
+    tl.em()
+    eng = tl._eng
+    eng.set_option('kernel_timing', 1)
+    sums, r, c = eng.report_colsums(_lib.Z_PREV, 0.9)
+    st = eng.report_stats()
+    assert st['kernel'] == 'k_report_pack32' and st['kernel_ms'] > 0 and st['algo_bytes'] == 4 * eng.dims()[2] + 12 * eng.dims()[0]
+    assert 0 <= st['deferred_rows'] < 4000, st                      # ~1e-4 of the rows sit inside the filter's margins
+    eng.set_option('report_dbg', 8)
+    sums8, r8, c8 = eng.report_colsums(_lib.Z_PREV, 0.9)
+    assert eng.report_stats()['kernel'] == 'k_report_rows'
+    eng.set_option('report_dbg', 0)
+    assert np.array_equal(sums['exclude'], sums8['exclude']) and np.array_equal(r, r8) and np.array_equal(c, c8)
+    assert np.allclose(sums['conf'], sums8['conf'], rtol=1e-12, atol=1e-9) and np.allclose(sums['average'], sums8['average'], rtol=1e-12, atol=1e-9)
+    eng.report_colsums(_lib.Z_INITIAL, -1.0)
+    assert eng.report_stats()['kernel'] == 'k_report_init_codes'
+    eng.set_option('kernel_timing', 0)
+    eng.report_colsums(_lib.Z_PREV, 0.9)
+    assert eng.report_stats()['kernel_ms'] == 0.0
