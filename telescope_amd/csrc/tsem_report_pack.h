@@ -4,14 +4,17 @@
 // capacity of 64, 38 % of the lane-entries are padding, and the kernel is bound by instruction issue (37 VALU per lane-entry,
 // profiles/r05_report_pmc.txt) — its time follows the capacity, not the entries.  Two changes, one kernel (k_report_pack32):
 //
-// 1. PACKING.  A row takes ceil(len / E) lanes (E = 16 entries per lane, 8 where the rows are short), rows follow each other without gaps inside a wave, and a wave's work is a CHUNK of
-//    whole rows that fills 64 lanes (k_report_chunks packs them greedily once per matrix: ~9 % padding in the rows' last lanes + ~4 %
-//    at the chunks' ends).  Lane -> row: the chunk's descriptor carries a 64-bit mask of the lanes that start a row; a lane's row is
-//    the number of such lanes at or below it (v_bcnt), its place inside the row the distance to the nearest one (v_ffbh).  Descriptors
-//    are fetched three iterations ahead, row pointers two, entries one.  Row sum and row maximum: one LDS atomic each per LANE into
-//    the row's slot of a wave-private LDS array, read back by the row's lanes — LDS instructions of a wave execute in order: no barrier.
-//    (A first version did this with the fp64 arithmetic of k_report_rows: 4.86 against 5.67 ms, profiles/r06_report_pack64_first.txt —
-//    without the padding the pass is bound by the fp64 per-entry work, the L2 gathers of the cold pi*theta and the winners' atomics.)
+// 1. PACKING.  A row takes ceil(len / E) lanes (E = 16 entries per lane, 8 where the rows are short), rows follow each other without
+//    gaps inside a wave, and a wave's work is a CHUNK of whole rows that fills 64 lanes (k_report_chunks packs them greedily once per
+//    matrix: ~9 % padding in the rows' last lanes + ~4 % at the chunks' ends).  Lane -> row: the chunk's descriptor carries a 64-bit
+//    mask of the lanes that start a row; a lane's row is the number of such lanes at or below it (v_bcnt), its place inside the row
+//    the distance to the nearest one (v_ffbh).  Descriptors are fetched three iterations ahead, row pointers two, entries one.  A row's
+//    (sum, maximum, runner-up, id of the maximum) is a segmented scan over its lanes on the VALU (rp_scan_step); the row's LAST lane
+//    holds the totals and decides.
+//    (History, all in profiles/r06_report_*: packed rows with the fp64 arithmetic of k_report_rows 4.86 against 5.67 ms — bound by the
+//    fp64 per-entry work, the L2 gathers of the cold pi*theta and the winners' atomics; the fp32 filter with LDS atomics per row for
+//    sum / max / count 3.16 ms — LDS-bound; the scan 2.4; 16 entries per lane, integer max, LDS mask table 2.2; counted waits and the
+//    next chunks' loads at the top of the iteration 2.0-2.15 ms.)
 //
 // 2. AN fp32 FILTER WITH AN EXACT FALL-BACK.  What the pass emits per row are INTEGERS — which entry is the best hit, whether its z
 //    reaches conf_prob (conf's value z / z is 1 to 2^-53) — and for all but a few thousand rows of 5e7 they are decided by a wide
@@ -21,13 +24,14 @@
 //    A row is DECIDED when   its largest p is >= 2^-40 (nothing that underflowed can matter),
 //                            no other p lies within 2^-16 of it (the true gap is then > 2^-17: one best hit, no near-tie), and
 //                            M / S is farther than 2^-15 from conf_prob (the true z_max lies within 2^-17 of it);
-//    everything else — exact ties, near-ties, rows on the threshold, rows whose products all vanish, rows longer than 512 entries —
+//    everything else — exact ties, near-ties, rows on the threshold, rows whose products all vanish, rows of more than 64 lanes —
 //    goes to k_report_slow, which does the exact fp64 arithmetic and forms near-tied row sums in the reference's order (near_band).
 //    With 4-byte tables pi*theta of ALL ids fits LDS up to ~34 000 slots (K <= 30 720): no gather leaves the CU; beyond, the tail
 //    comes from L2 (COLD).  Unique rows (one entry: pi instead of pi*theta, model.py:706-714) need no arithmetic: their entry is the
 //    best hit with z = 1 unless pi or Q vanish — the table's sign bit says whether pi is safely above 0.
-//    Winners are not counted here: the row's first lane stores (id | pass) next to the best-hit count, 4 B per row, and k_report_hist
-//    counts them per id with the whole LDS for its counters — no global atomic, no counter competing with the tables for LDS.
+//    Winners are not counted here: the row's last lane stores a record (id | pass | decided), 4 B per row, into the best-hit array, and
+//    k_report_hist counts the records per id with the whole LDS for its counters — no global atomic, no counter competing with the
+//    tables for LDS; the deferred rows' words are rewritten by k_report_slow with their best-hit counts afterwards.
 //
 // Integer outputs are exact by construction (a decided row's outputs do not depend on rounding; the others are computed exactly);
 // `conf` sums 1.0 per passing row where the reference sums fl(z fl(1 / z)) in {1, 1 - 2^-53}.
