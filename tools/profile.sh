@@ -8,7 +8,8 @@ TAG=${1:-r}
 OUT=gpurun_out/prof/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-sweep --no-reproducible-leg --kernel-timing 1"
+# (round 6: the driver's own step counts — with 2 warm-up steps the 6 timed launches were still on the ramp after the generator: 4.5 .. 4.14 ms)
+B="python bench.py --steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-5} --no-cpu-baseline --no-precision-sweep --no-reproducible-leg --kernel-timing 1"
 STAGES=${STAGES:-"trace pmc lds rest"}
 has() { [[ " $STAGES " == *" $1 "* ]]; }
 if has trace; then

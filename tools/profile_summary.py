@@ -21,7 +21,7 @@ def short(name):
     return name.split('(')[0].replace('void ', '')
 
 
-WARMUP = 2          # launches of the EM kernel before bench.py's timed region (--warmup 2 in tools/profile.sh)
+WARMUP = 2          # launches of the EM kernel before bench.py's timed region (overwritten with the profiled run's own --warmup)
 
 
 def kernel_table(path, steps=None):
@@ -67,15 +67,25 @@ def main():
     src, prefix = sys.argv[1], sys.argv[2]
     one = lambda pat: sorted(glob.glob(os.path.join(src, pat)))[0]
     bench = json.load(open(os.path.join(src, 'bench.json')))
-    cmd = 'python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-sweep --no-reproducible-leg'
-    kl, avg = kernel_table(one('trace/*/*_kernel_trace.csv'), steps=6)
+    global WARMUP
+    steps = 6
+    try:   # the profiled run's own result line (trace.log): its --steps / --warmup and the HIP-event kernel time to compare with
+        own = json.loads([l for l in open(os.path.join(src, 'trace.log'), errors='replace') if l.startswith('{"metric"')][-1])
+        steps, WARMUP = int(own['steps']), int(own['warmup'])
+    except Exception:   # noqa: BLE001
+        own = None
+    cmd = 'python bench.py --steps %d --warmup %d --no-cpu-baseline --no-precision-sweep --no-reproducible-leg' % (steps, WARMUP)
+    kl, avg = kernel_table(one('trace/*/*_kernel_trace.csv'), steps=steps)
     with open(os.path.join(ROOT, 'profiles', prefix + '_fused_kernel_stats.txt'), 'w') as f:
         f.write('# rocprofv3 --kernel-trace --stats -- %s   (default workload; the run times the headline fp64\n'
                 '# layout k_em_fused<4, 0, 2, 0> and then the 2-byte-code layout k_em_fused<4, 0, 1, 0>;\n# template arguments: team size, mode (0 EM / 1 lnl), entry format, geometry)\n'
-                '# k_em_fused rows: the 6 launches of the TIMED region of each engine (the %d warm-up launches before it and the phase-timing / whole-call legs behind it are left out).  lds_B is the STATIC\n'
+                '# k_em_fused rows: the launches of the TIMED region of each engine (the %d warm-up launches before it and the phase-timing / whole-call legs behind it are left out).  lds_B is the STATIC\n'
                 '# allocation; the fused kernel allocates its LDS dynamically: %s B per workgroup (tsem.hip fz_lds_bytes).\n'
                 % (cmd, WARMUP, bench['config']['layout'].get('lds_bytes', 'n/a')))
         f.write('\n'.join(kl) + '\n')
+        if own:
+            f.write('# the same run\'s own result line: roofline.kernel_ms %.4f (HIP events on the engine\'s stream around the timed launches), ms_per_step %.4f\n'
+                    % (own['roofline']['kernel_ms'], own['ms_per_step']))
     fl, fetch = pmc_table(one('fetch/*/*_counter_collection.csv'), 'FETCH_SIZE')
     wl, write = pmc_table(one('write/*/*_counter_collection.csv'), 'WRITE_SIZE')
     runs = []
