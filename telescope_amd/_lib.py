@@ -38,8 +38,7 @@ def build_library(force=False, verbose=False, extra_flags=(), out=None):
     from concurrent.futures import ThreadPoolExecutor
     csrc = os.path.join(HERE, 'csrc')
     units = [os.path.join(csrc, u + '.hip') for u in LIB_UNITS + FZ_UNITS]
-    deps = units + [os.path.join(csrc, h) for h in ('tsem_common.h', 'tsem_internal.h', 'tsem_fused.h', 'tsem_device.h', 'tsem_fused_inst.h')] + \
-        [os.path.join(ROOT, 'include', 'telescope_em.h')]
+    deps = units + sorted(os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith('.h')) + [os.path.join(ROOT, 'include', 'telescope_em.h')]
     target = out or LIB_PATH
     objdir = os.path.join(csrc, '_obj' + ('' if out is None else '_' + os.path.basename(out)))
     common = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-ffp-contract=off',
