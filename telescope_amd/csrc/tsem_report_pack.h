@@ -249,8 +249,10 @@ __global__ __launch_bounds__(1024) void k_report_pack32(Rp32Args A) {
     return p;
   };
   auto load_ent = [&](const Ip& p) -> Ent {
-    // lanes past the row's end read what follows it (the arrays carry TS_ENTRY_PAD entries of padding: never out of bounds)
-    const int64_t k = p.s + (p.toolong ? 0 : E * p.pos);
+    // lanes past the row's end read what follows it (the arrays carry TS_ENTRY_PAD entries of padding: never out of bounds); the
+    // lanes behind a chunk's last row (and every lane of a wave without a chunk) read the chunk's first entries — their distance
+    // from the unused tail's head times E would reach up to 1008 entries past them (round 6: a memory fault once in 1128 soak cases)
+    const int64_t k = p.s + (p.valid && !p.toolong ? E * p.pos : 0);
     Ent t;
 #pragma unroll
     for (int q = 0; q < E / 8; ++q) {
