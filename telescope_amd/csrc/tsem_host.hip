@@ -279,6 +279,11 @@ int tsem_load_scores(tsem_ctx* h, int64_t n_rows, int32_t n_cols, const int64_t*
   TSEM_ALLOC(h->d_indptr, n_rows + 1);
   TSEM_ALLOC(h->d_indices, nnz + TS_ENTRY_PAD);           // (k_report_rows reads whole lanes of 16 entries past a row's end)
   TSEM_ALLOC(h->d_raw, nnz + TS_ENTRY_PAD);
+  // ... and what they find there must be a valid column / score code / (tsem_setup.hip) popularity id: the report kernels mask the
+  // VALUES of entries past a row's end, but index tables with them first (k_report_pack32<E, true> reads its global pi*theta table at
+  // the id: a stale 65535 would be 256 KB into whatever follows a 200 KB table)
+  TSEM_HIP(hipMemsetAsync(h->d_indices + nnz, 0, sizeof(int32_t) * TS_ENTRY_PAD, h->stream));
+  TSEM_HIP(hipMemsetAsync(h->d_raw + nnz, 0, sizeof(uint16_t) * TS_ENTRY_PAD, h->stream));
   // plain hipMemcpy from the caller's pageable arrays: 55 GB/s on the GPU box (tools/time_host_upload.py; a pipeline
   // through pinned staging buffers filled by 8 host threads was slower: 37 GB/s)
   TSEM_HIP(hipMemcpy(h->d_indptr, indptr, sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice));
@@ -345,6 +350,8 @@ int tsem_generate(tsem_ctx* h, int64_t row_begin, int64_t row_end, int32_t n_col
   h->nnz = nnz;
   TSEM_ALLOC(h->d_indices, nnz + TS_ENTRY_PAD);
   TSEM_ALLOC(h->d_raw, nnz + TS_ENTRY_PAD);
+  TSEM_HIP(hipMemsetAsync(h->d_indices + nnz, 0, sizeof(int32_t) * TS_ENTRY_PAD, h->stream));   // (see tsem_load_scores)
+  TSEM_HIP(hipMemsetAsync(h->d_raw + nnz, 0, sizeof(uint16_t) * TS_ENTRY_PAD, h->stream));
   if (n) {
     k_gen_rows<<<cdiv64(n, 128), 128, 0, h->stream>>>(row_begin, n, n_cols, seed, dist, h->d_indptr, h->d_indices, h->d_raw);
     TSEM_HIP(hipGetLastError());

@@ -1171,6 +1171,8 @@ int tsem_build_layout(tsem_ctx* h) {
     TSEM_ALLOC(h->d_col_of_id, h->Kpad);
     TSEM_HIP(hipMemcpy(h->d_col_of_id, col_of_id.data(), sizeof(int32_t) * h->Kpad, hipMemcpyHostToDevice));
     TSEM_ALLOC(h->d_rid16, h->nnz + TS_ENTRY_PAD);
+    // the padding holds id 0: lanes past the LAST row's end index the pi*theta tables with what they find there (tsem_host.hip)
+    TSEM_HIP(hipMemsetAsync(h->d_rid16 + h->nnz, 0, sizeof(uint16_t) * TS_ENTRY_PAD, h->stream));
   }
   pt.lap("layout: maps to the device, rid16 alloc");
   // 3. row blocks.  Two-pass layout: R rows each.  Fused layout: as many consecutive rows as the
