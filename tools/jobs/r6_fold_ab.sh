@@ -1,4 +1,6 @@
 #!/bin/bash
+# (an experiment that was reverted: `git apply tools/scratch/r06_fold_tail.patch` first — without it fused_dbg bit 16 selects nothing and both legs run the
+# three kernels; results: profiles/r06_fold_tail_ab.txt)
 # the folded tail of the EM pass (FzFold) against the three-kernel iteration (fused_dbg bit 16), same box: parity tests of the goldens,
 # then BASELINE configs 2, 3, the 8-GPU shard and the headline   ->  gpurun_out/r6_fold/
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6_fold; export TMPDIR=/tmp

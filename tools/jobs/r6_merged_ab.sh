@@ -1,4 +1,6 @@
 #!/bin/bash
+# (an experiment that was reverted: `git apply tools/scratch/r06_merged_reduce_update.patch` first — without it fused_dbg bit 16 selects nothing and both legs run the
+# three kernels; results: profiles/r06_fold_tail_ab.txt)
 # k_reduce_update (column reduce + M-step in one kernel, single GPU) against k_colreduce + k_update (fused_dbg bit 16), same box:
 # its tests, the time-out / chunk tests around it, then BASELINE configs 2, 3 and the headline  ->  gpurun_out/r6_merged/
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6_merged; export TMPDIR=/tmp
